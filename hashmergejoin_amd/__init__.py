@@ -1,0 +1,14 @@
+"""hashmergejoin_amd -- MI355X-native radix-partitioned hash join (host-side Python binding).
+
+The product is libhmj_hip.so (hand-written HIP for gfx950 behind the C ABI of include/hmj.h).  This
+package is a thin ctypes binding over that ABI plus a mirror of the reference's operator surface
+(`HashMergeJoin`, reference hashjoin.h:33-199).  There is no CPU implementation here: if the
+library or a GPU is missing, calls raise.
+"""
+from ._lib import (HMJ_CHECKSUM, HMJ_FIRST_WINS, HMJ_MATERIALIZE, HMJ_ORDERED, HMJ_SUM_PROBE,
+                   HmjError, JoinResult, Timing, lib_path, load_library)
+from .join import Executor, HashMergeJoin, plan
+
+__all__ = ["Executor", "HashMergeJoin", "plan", "HmjError", "JoinResult", "Timing", "load_library",
+           "lib_path", "HMJ_MATERIALIZE", "HMJ_ORDERED", "HMJ_FIRST_WINS", "HMJ_CHECKSUM",
+           "HMJ_SUM_PROBE"]

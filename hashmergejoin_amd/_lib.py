@@ -1,0 +1,103 @@
+"""ctypes binding of include/hmj.h.  Loads hashmergejoin_amd/libhmj_hip.so (built in-tree by
+`make`); raises loudly if it is missing -- there is no fallback path."""
+import ctypes as C
+import os
+
+HMJ_MATERIALIZE = 0x01
+HMJ_ORDERED = 0x02
+HMJ_FIRST_WINS = 0x04
+HMJ_CHECKSUM = 0x08
+HMJ_SUM_PROBE = 0x10
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_U64P = C.POINTER(C.c_uint64)
+
+
+class HmjError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hmj error %d: %s" % (code, msg))
+        self.code = code
+
+
+class JoinResult(C.Structure):
+    _fields_ = [("n_matches", C.c_uint64), ("sum_r", C.c_uint64), ("sum_s", C.c_uint64),
+                ("xor_fold", C.c_uint64), ("mix_sum", C.c_uint64), ("sum_probe_all", C.c_uint64),
+                ("key", C.c_void_p), ("rval", C.c_void_p), ("sval", C.c_void_p)]
+
+    def checks(self):
+        return {k: int(getattr(self, k)) for k in ("n_matches", "sum_r", "sum_s", "xor_fold", "mix_sum")}
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_h2d", C.c_float), ("ms_d2h", C.c_float),
+                ("ms_partition_build", C.c_float), ("ms_partition_probe", C.c_float),
+                ("ms_hist", C.c_float), ("ms_scan", C.c_float), ("ms_scatter", C.c_float),
+                ("ms_offsets", C.c_float), ("ms_probe_count", C.c_float),
+                ("ms_out_scan", C.c_float), ("ms_probe_write", C.c_float), ("ms_order", C.c_float),
+                ("radix_bits", C.c_int), ("radix_passes", C.c_int),
+                ("n_scatter_launches", C.c_int), ("reserved", C.c_int),
+                ("bytes_scatter", C.c_uint64), ("bytes_hist", C.c_uint64),
+                ("bytes_probe_count", C.c_uint64), ("bytes_probe_write", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhmj_hip.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load libhmj_hip.so.  torch (if used by the caller) must be imported BEFORE this so that both
+    share one HIP runtime (the wheel bundles libamdhip64 under the same SONAME)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HmjError(-100, "HIP extension not built: %s is missing (run `make` at the repo root)" % path)
+    L = C.CDLL(path)
+    u, i, vp, cp = C.c_uint64, C.c_int, C.c_void_p, C.c_char_p
+    L.hmj_create.restype = i
+    L.hmj_create.argtypes = [C.POINTER(vp), i]
+    L.hmj_destroy.restype = None
+    L.hmj_destroy.argtypes = [vp]
+    L.hmj_set_stream.restype = i
+    L.hmj_set_stream.argtypes = [vp, vp]
+    L.hmj_reserve.restype = i
+    L.hmj_reserve.argtypes = [vp, u, u, u, C.c_uint32]
+    L.hmj_set_radix_bits.restype = i
+    L.hmj_set_radix_bits.argtypes = [vp, i]
+    L.hmj_plan.restype = i
+    L.hmj_plan.argtypes = [u, C.POINTER(i), C.POINTER(i), C.POINTER(i * 4)]
+    L.hmj_set_profiling.restype = i
+    L.hmj_set_profiling.argtypes = [vp, i]
+    L.hmj_last_timing.restype = i
+    L.hmj_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.hmj_strerror.restype = cp
+    L.hmj_strerror.argtypes = [i]
+    L.hmj_last_error.restype = cp
+    L.hmj_last_error.argtypes = [vp]
+    L.hmj_version.restype = cp
+    L.hmj_version.argtypes = []
+    L.hmj_join_u64_device.restype = i
+    L.hmj_join_u64_device.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult)]
+    L.hmj_join_u64.restype = i
+    L.hmj_join_u64.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult)]
+    L.hmj_release_result.restype = None
+    L.hmj_release_result.argtypes = [vp]
+    L.hmj_partition_u64_device.restype = i
+    L.hmj_partition_u64_device.argtypes = [vp, vp, u, i, i, vp, vp]
+    L.hmj_gen_build_u64_device.restype = i
+    L.hmj_gen_build_u64_device.argtypes = [vp, vp, u, u, u]
+    L.hmj_gen_probe_u64_device.restype = i
+    L.hmj_gen_probe_u64_device.argtypes = [vp, vp, u, u, u, u, u]
+    L.hmj_gen_from_cdf_u64_device.restype = i
+    L.hmj_gen_from_cdf_u64_device.argtypes = [vp, vp, u, u, vp, u, u, u]
+    L.hmj_gen_uniform_domain_u64_device.restype = i
+    L.hmj_gen_uniform_domain_u64_device.argtypes = [vp, vp, u, u, u, u, u]
+    _LIB = L
+    return L

@@ -1,0 +1,604 @@
+// extern "C" ABI of libhmj_hip.so (include/hmj.h): context, workspace, planner and the join
+// driver that sequences the gfx950 kernels on one HIP stream.  No CPU compute path exists here:
+// every entry point either runs the HIP kernels or returns an error code.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hmj.h"
+#include "hmj_dev.h"
+#include "hmj_launch.h"
+
+using hmj::u32;
+using hmj::u64;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+enum Kind {
+  K_TOTAL = 0, K_H2D, K_D2H, K_HIST, K_SCAN, K_SCATTER, K_OFFSETS, K_PROBE_COUNT, K_OUT_SCAN,
+  K_PROBE_WRITE, K_ORDER, K_NKINDS
+};
+struct Span {
+  int kind, rel, e0, e1;  // rel: 0 = build side, 1 = probe side, -1 = n/a
+};
+
+}  // namespace
+
+struct hmj_ctx {
+  int device = 0, num_cus = 256;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
+      out_key, out_rval, out_sval, offs64;
+  HostBuf h_accum, h_key, h_rval, h_sval;
+  int force_bits = -1;
+  bool profiling = false;
+  std::vector<hipEvent_t> events;
+  std::vector<Span> spans;
+  int ev_used = 0;
+  hmj_timing timing;
+  std::string last_error;
+};
+
+namespace {
+
+constexpr int kMaxEvents = 256;
+
+int fail(hmj_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->last_error = what;
+    if (e != hipSuccess) {
+      c->last_error += ": ";
+      c->last_error += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define HIP_TRY(expr)                                                   \
+  do {                                                                  \
+    hipError_t _e = (expr);                                             \
+    if (_e != hipSuccess) return fail(c, HMJ_E_HIP, #expr, _e);         \
+  } while (0)
+
+int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return HMJ_OK;
+  if (b.p) {
+    hipError_t e = hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    if (e != hipSuccess) return fail(c, HMJ_E_HIP, "hipFree", e);
+  }
+  size_t want = bytes + (bytes >> 4) + 256;  // a little headroom against regrowth
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    (void)hipGetLastError();
+    return fail(c, HMJ_E_OOM, "hipMalloc", e);
+  }
+  b.cap = want;
+  return HMJ_OK;
+}
+
+int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return HMJ_OK;
+  if (b.p) {
+    (void)hipHostFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + (bytes >> 4) + 256;
+  hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    (void)hipGetLastError();
+    return fail(c, HMJ_E_OOM, "hipHostMalloc", e);
+  }
+  b.cap = want;
+  return HMJ_OK;
+}
+
+void free_dev(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+void free_host(HostBuf& b) {
+  if (b.p) (void)hipHostFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+// ---- profiling spans ---------------------------------------------------------------------------
+int span_begin(hmj_ctx* c, int kind, int rel) {
+  if (!c->profiling || c->ev_used + 2 > (int)c->events.size()) return -1;
+  Span s{kind, rel, c->ev_used, c->ev_used + 1};
+  c->ev_used += 2;
+  (void)hipEventRecord(c->events[s.e0], c->stream);
+  c->spans.push_back(s);
+  return (int)c->spans.size() - 1;
+}
+void span_end(hmj_ctx* c, int id) {
+  if (id < 0) return;
+  (void)hipEventRecord(c->events[c->spans[id].e1], c->stream);
+}
+void spans_reset(hmj_ctx* c) {
+  c->spans.clear();
+  c->ev_used = 0;
+  std::memset(&c->timing, 0, sizeof(c->timing));
+}
+void spans_collect(hmj_ctx* c) {  // call after the stream is synchronized
+  hmj_timing& t = c->timing;
+  for (const Span& s : c->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->events[s.e0], c->events[s.e1]) != hipSuccess) continue;
+    switch (s.kind) {
+      case K_TOTAL: t.ms_total += ms; break;
+      case K_H2D: t.ms_h2d += ms; break;
+      case K_D2H: t.ms_d2h += ms; break;
+      case K_HIST: t.ms_hist += ms; break;
+      case K_SCAN: t.ms_scan += ms; break;
+      case K_SCATTER: t.ms_scatter += ms; t.n_scatter_launches++; break;
+      case K_OFFSETS: t.ms_offsets += ms; break;
+      case K_PROBE_COUNT: t.ms_probe_count += ms; break;
+      case K_OUT_SCAN: t.ms_out_scan += ms; break;
+      case K_PROBE_WRITE: t.ms_probe_write += ms; break;
+      case K_ORDER: t.ms_order += ms; break;
+    }
+    if (s.kind == K_HIST || s.kind == K_SCAN || s.kind == K_SCATTER) {
+      if (s.rel == 0) t.ms_partition_build += ms;
+      if (s.rel == 1) t.ms_partition_probe += ms;
+    }
+  }
+}
+
+// ---- planner -------------------------------------------------------------------------------------
+// Partition count: enough most-significant key bits that an average build partition holds
+// <= PB_TARGET_AVG rows and so fits the LDS table of probe.hip (the reference's optimal_partition,
+// radix_hash.h:38-57, sizes for CPU caches instead).  Passes: LSD order, <= RP_MAX_BITS each.
+void plan_bits(u64 n_build, int force, int* total, int* passes, int pass_bits[4]) {
+  int B = 0;
+  if (force >= 0) {
+    B = force;
+  } else {
+    u64 parts = (n_build + hmj::PB_TARGET_AVG - 1) / hmj::PB_TARGET_AVG;
+    while ((1ull << B) < parts) B++;
+  }
+  if (B > 27) B = 27;
+  int np = (B + hmj::RP_MAX_BITS - 1) / hmj::RP_MAX_BITS;
+  for (int i = 0; i < 4; i++) pass_bits[i] = 0;
+  // pass 0 handles the LEAST significant of the B bits; earlier passes get the extra bit
+  for (int i = 0; i < np; i++) pass_bits[i] = B / np + (i < B % np ? 1 : 0);
+  *total = B;
+  *passes = np;
+}
+
+// one stable LSD pass src -> dst
+int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bits, int rel,
+               u64* offsets_out) {
+  u32 nblk, rpb;
+  hmj::radix_pass_geometry(n, &nblk, &rpb);
+  int rc;
+  if ((rc = ensure_dev(c, c->hist, (size_t)(1u << bits) * nblk * sizeof(u32))) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->totals, (size_t)hmj::RP_MAXD * sizeof(u32))) != HMJ_OK) return rc;
+  int s = span_begin(c, K_HIST, rel);
+  HIP_TRY(hmj::launch_radix_hist(src, n, shift, bits, (u32*)c->hist.p, nblk, rpb, c->stream));
+  span_end(c, s);
+  s = span_begin(c, K_SCAN, rel);
+  HIP_TRY(hmj::launch_radix_rowscan((u32*)c->hist.p, nblk, bits, (u32*)c->totals.p, c->stream));
+  span_end(c, s);
+  s = span_begin(c, K_SCATTER, rel);
+  HIP_TRY(hmj::launch_radix_scatter(src, dst, n, shift, bits, (const u32*)c->hist.p,
+                                    (const u32*)c->totals.p, nblk, rpb, offsets_out, c->stream));
+  span_end(c, s);
+  c->timing.bytes_hist += 16ull * n;
+  c->timing.bytes_scatter += 32ull * n;
+  return HMJ_OK;
+}
+
+// all passes of one relation; *result = where the partitioned rows ended up
+int partition_relation(hmj_ctx* c, const void* in, u32 n, DevBuf buf[2], int B, int passes,
+                       const int pass_bits[4], int rel, const void** result) {
+  *result = in;
+  if (passes == 0 || n == 0) return HMJ_OK;
+  int rc;
+  if ((rc = ensure_dev(c, buf[0], (size_t)n * 16)) != HMJ_OK) return rc;
+  if (passes > 1 && (rc = ensure_dev(c, buf[1], (size_t)n * 16)) != HMJ_OK) return rc;
+  const void* src = in;
+  int shift = 64 - B;
+  for (int i = 0; i < passes; i++) {
+    void* dst = buf[i & 1].p;
+    if ((rc = radix_pass(c, src, dst, n, shift, pass_bits[i], rel, nullptr)) != HMJ_OK) return rc;
+    shift += pass_bits[i];
+    src = dst;
+  }
+  *result = src;
+  return HMJ_OK;
+}
+
+int check_rel(hmj_ctx* c, const void* p, uint64_t n, const char* name) {
+  if (n > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "more than 2^32-1 rows in one call");
+  if (n && !p) return fail(c, HMJ_E_ARG, name);
+  if (((uintptr_t)p & 15) != 0) return fail(c, HMJ_E_ARG, "relation pointer must be 16-byte aligned");
+  return HMJ_OK;
+}
+
+int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
+                uint32_t flags, hmj_result* out, bool to_host) {
+  int rc;
+  if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
+  std::memset(out, 0, sizeof(*out));
+  if ((rc = check_rel(c, R, n_build, "build_aos is NULL")) != HMJ_OK) return rc;
+  if ((rc = check_rel(c, S, n_probe, "probe_aos is NULL")) != HMJ_OK) return rc;
+  if (flags & HMJ_ORDERED) flags |= HMJ_MATERIALIZE;
+  const bool materialize = flags & HMJ_MATERIALIZE, first = flags & HMJ_FIRST_WINS;
+  const bool extra = flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE);
+  const u32 nb = (u32)n_build, np = (u32)n_probe;
+
+  int B, passes, pass_bits[4];
+  plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
+  const u32 P = 1u << B;
+  // probe slices: when there are few partitions, several workgroups share one partition's table
+  u32 Q = 1;
+  const u32 target_items = (u32)hmj::probe_default_grid(c->num_cus);
+  if (P < target_items) {
+    u64 by_grid = (target_items + P - 1) / P;
+    u64 by_rows = ((u64)np / P + hmj::PB_TARGET_AVG - 1) / hmj::PB_TARGET_AVG;
+    Q = (u32)(by_grid < by_rows ? by_grid : by_rows);
+    if (Q < 1) Q = 1;
+  }
+  const u64 items = (u64)P * Q;
+
+  if ((rc = ensure_dev(c, c->r_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->s_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  if (materialize) {
+    if ((rc = ensure_dev(c, c->part_count, (size_t)items * 8)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->part_out_off, ((size_t)items + 1) * 8)) != HMJ_OK) return rc;
+  }
+  c->timing.radix_bits = B;
+  c->timing.radix_passes = passes;
+
+  HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+  const void *Rp, *Sp;
+  if ((rc = partition_relation(c, R, nb, c->rbuf, B, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
+  if ((rc = partition_relation(c, S, np, c->sbuf, B, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
+  int s = span_begin(c, K_OFFSETS, -1);
+  HIP_TRY(hmj::launch_part_offsets(Rp, nb, B, (u32*)c->r_off.p, c->stream));
+  HIP_TRY(hmj::launch_part_offsets(Sp, np, B, (u32*)c->s_off.p, c->stream));
+  span_end(c, s);
+
+  hmj::ProbeArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.R = Rp;
+  a.r_off = (const u32*)c->r_off.p;
+  a.S = Sp;
+  a.s_off = (const u32*)c->s_off.p;
+  a.P = P;
+  a.Q = Q;
+  a.accum = (u64*)c->accum.p;
+  a.part_count = (u64*)c->part_count.p;
+  a.part_out_off = (const u64*)c->part_out_off.p;
+  const int grid = hmj::probe_default_grid(c->num_cus);
+
+  s = span_begin(c, K_PROBE_COUNT, -1);
+  HIP_TRY(hmj::launch_probe(a, materialize ? 1 : 0, first, extra, grid, c->stream));
+  span_end(c, s);
+  c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
+  if (materialize) {
+    s = span_begin(c, K_OUT_SCAN, -1);
+    HIP_TRY(hmj::launch_scan_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p, (u32)items,
+                                 c->stream));
+    span_end(c, s);
+  }
+  u64* h = (u64*)c->h_accum.p;
+  HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h[hmj::ACC_ERR] & hmj::ERR_FIRST_WINS_OVERFLOW)
+    return fail(c, HMJ_E_UNSUPPORTED,
+                "HMJ_FIRST_WINS: a build partition exceeds the LDS table (skewed build side)");
+  out->n_matches = h[hmj::ACC_N];
+  out->sum_r = h[hmj::ACC_SUM_R];
+  out->sum_s = h[hmj::ACC_SUM_S];
+  out->xor_fold = h[hmj::ACC_XOR];
+  out->mix_sum = h[hmj::ACC_MIX];
+  out->sum_probe_all = h[hmj::ACC_SUM_P];
+
+  if (materialize && out->n_matches) {
+    const size_t bytes = (size_t)out->n_matches * 8;
+    if ((rc = ensure_dev(c, c->out_key, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return rc;
+    a.out_key = (u64*)c->out_key.p;
+    a.out_rval = (u64*)c->out_rval.p;
+    a.out_sval = (u64*)c->out_sval.p;
+    s = span_begin(c, K_PROBE_WRITE, -1);
+    HIP_TRY(hmj::launch_probe(a, 2, first, false, grid, c->stream));
+    span_end(c, s);
+    c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
+    if (flags & HMJ_ORDERED) {
+      s = span_begin(c, K_ORDER, -1);
+      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, P, Q, a.out_key, a.out_rval,
+                                a.out_sval, a.accum, c->num_cus * 2, c->stream));
+      span_end(c, s);
+    }
+    if (to_host) {
+      if ((rc = ensure_host(c, c->h_key, bytes)) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_rval, bytes)) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_sval, bytes)) != HMJ_OK) return rc;
+      s = span_begin(c, K_D2H, -1);
+      HIP_TRY(hipMemcpyAsync(c->h_key.p, a.out_key, bytes, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_rval.p, a.out_rval, bytes, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_sval.p, a.out_sval, bytes, hipMemcpyDeviceToHost, c->stream));
+      span_end(c, s);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->key = to_host ? (const uint64_t*)c->h_key.p : (const uint64_t*)a.out_key;
+    out->rval = to_host ? (const uint64_t*)c->h_rval.p : (const uint64_t*)a.out_rval;
+    out->sval = to_host ? (const uint64_t*)c->h_sval.p : (const uint64_t*)a.out_sval;
+  }
+  return HMJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hmj_create(hmj_ctx** out, int device_id) {
+  if (!out) return HMJ_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return HMJ_E_NODEV;
+  }
+  if (device_id < 0 && hipGetDevice(&device_id) != hipSuccess) return HMJ_E_NODEV;
+  if (device_id >= ndev) return HMJ_E_ARG;
+  if (hipSetDevice(device_id) != hipSuccess) return HMJ_E_NODEV;
+  hmj_ctx* c = new hmj_ctx();
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return HMJ_E_HIP;
+  }
+  c->stream = c->own_stream;
+  c->events.resize(kMaxEvents);
+  for (auto& e : c->events)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return HMJ_E_HIP;
+    }
+  std::memset(&c->timing, 0, sizeof(c->timing));
+  *out = c;
+  return HMJ_OK;
+}
+
+void hmj_destroy(hmj_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* devs[] = {&c->rbuf[0], &c->rbuf[1], &c->sbuf[0], &c->sbuf[1], &c->in_r, &c->in_s,
+                    &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
+                    &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
+                    &c->offs64};
+  for (DevBuf* b : devs) free_dev(*b);
+  HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
+  for (HostBuf* b : hosts) free_host(*b);
+  for (auto& e : c->events)
+    if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int hmj_set_stream(hmj_ctx* c, void* hip_stream) {
+  if (!c) return HMJ_E_ARG;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return HMJ_OK;
+}
+
+int hmj_set_radix_bits(hmj_ctx* c, int total_bits) {
+  if (!c || total_bits > 27) return HMJ_E_ARG;
+  c->force_bits = total_bits < 0 ? -1 : total_bits;
+  return HMJ_OK;
+}
+
+int hmj_plan(uint64_t n_build, int* total_bits, int* n_passes, int pass_bits[4]) {
+  if (!total_bits || !n_passes || !pass_bits) return HMJ_E_ARG;
+  plan_bits(n_build, -1, total_bits, n_passes, pass_bits);
+  return HMJ_OK;
+}
+
+int hmj_set_profiling(hmj_ctx* c, int enabled) {
+  if (!c) return HMJ_E_ARG;
+  c->profiling = enabled != 0;
+  return HMJ_OK;
+}
+
+int hmj_last_timing(hmj_ctx* c, hmj_timing* out) {
+  if (!c || !out) return HMJ_E_ARG;
+  *out = c->timing;
+  return HMJ_OK;
+}
+
+const char* hmj_strerror(int code) {
+  switch (code) {
+    case HMJ_OK: return "ok";
+    case HMJ_E_ARG: return "invalid argument";
+    case HMJ_E_NODEV: return "no usable HIP device";
+    case HMJ_E_OOM: return "out of device or pinned host memory";
+    case HMJ_E_HIP: return "HIP runtime error";
+    case HMJ_E_UNSUPPORTED: return "unsupported flag combination for this input";
+    default: return "unknown error";
+  }
+}
+
+const char* hmj_last_error(hmj_ctx* c) { return c ? c->last_error.c_str() : ""; }
+const char* hmj_version(void) { return "hashmergejoin_amd 0.1 (gfx950)"; }
+
+int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_matches,
+                uint32_t flags) {
+  if (!c) return HMJ_E_ARG;
+  if (n_build > 0xFFFFFFFFull || n_probe > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "too many rows");
+  HIP_TRY(hipSetDevice(c->device));
+  int B, passes, pass_bits[4], rc;
+  plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
+  const size_t P = (size_t)1 << B;
+  const size_t items = P < 4096 ? 4096 : P;
+  if (passes >= 1) {
+    if ((rc = ensure_dev(c, c->rbuf[0], n_build * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->sbuf[0], n_probe * 16)) != HMJ_OK) return rc;
+  }
+  if (passes >= 2) {
+    if ((rc = ensure_dev(c, c->rbuf[1], n_build * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->sbuf[1], n_probe * 16)) != HMJ_OK) return rc;
+  }
+  if ((rc = ensure_dev(c, c->hist, (size_t)hmj::RP_MAXD * hmj::RP_MAX_BLOCKS * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->totals, (size_t)hmj::RP_MAXD * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->r_off, (P + 1) * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->s_off, (P + 1) * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->accum, 64)) != HMJ_OK) return rc;
+  if ((rc = ensure_host(c, c->h_accum, 64)) != HMJ_OK) return rc;
+  if (flags & (HMJ_MATERIALIZE | HMJ_ORDERED)) {
+    if ((rc = ensure_dev(c, c->part_count, items * 8)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->part_out_off, (items + 1) * 8)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->out_key, max_matches * 8)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->out_rval, max_matches * 8)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->out_sval, max_matches * 8)) != HMJ_OK) return rc;
+  }
+  return HMJ_OK;
+}
+
+int hmj_join_u64_device(hmj_ctx* c, const void* build_aos_dev, uint64_t n_build,
+                        const void* probe_aos_dev, uint64_t n_probe, uint32_t flags,
+                        hmj_result* out) {
+  if (!c) return HMJ_E_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  spans_reset(c);
+  int st = span_begin(c, K_TOTAL, -1);
+  int rc = join_device(c, build_aos_dev, n_build, probe_aos_dev, n_probe, flags, out, false);
+  span_end(c, st);
+  if (c->profiling) {
+    (void)hipStreamSynchronize(c->stream);
+    spans_collect(c);
+  }
+  return rc;
+}
+
+int hmj_join_u64(hmj_ctx* c, const void* build_aos_host, uint64_t n_build,
+                 const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out) {
+  if (!c) return HMJ_E_ARG;
+  if (n_build > 0xFFFFFFFFull || n_probe > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "too many rows");
+  if ((n_build && !build_aos_host) || (n_probe && !probe_aos_host))
+    return fail(c, HMJ_E_ARG, "relation pointer is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  spans_reset(c);
+  int rc;
+  if ((rc = ensure_dev(c, c->in_r, n_build * 16 + 16)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->in_s, n_probe * 16 + 16)) != HMJ_OK) return rc;
+  int st = span_begin(c, K_TOTAL, -1);
+  int s = span_begin(c, K_H2D, -1);
+  if (n_build)
+    HIP_TRY(hipMemcpyAsync(c->in_r.p, build_aos_host, n_build * 16, hipMemcpyHostToDevice, c->stream));
+  if (n_probe)
+    HIP_TRY(hipMemcpyAsync(c->in_s.p, probe_aos_host, n_probe * 16, hipMemcpyHostToDevice, c->stream));
+  span_end(c, s);
+  rc = join_device(c, c->in_r.p, n_build, c->in_s.p, n_probe, flags, out, true);
+  span_end(c, st);
+  if (c->profiling) {
+    (void)hipStreamSynchronize(c->stream);
+    spans_collect(c);
+  }
+  return rc;
+}
+
+void hmj_release_result(hmj_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_dev(c->out_key);
+  free_dev(c->out_rval);
+  free_dev(c->out_sval);
+  free_host(c->h_key);
+  free_host(c->h_rval);
+  free_host(c->h_sval);
+}
+
+int hmj_partition_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, int shift, int bits,
+                             void* out_aos_dev, uint64_t* offsets_dev) {
+  if (!c) return HMJ_E_ARG;
+  if (bits < 1 || bits > hmj::RP_MAX_BITS || shift < 0 || shift + bits > 64)
+    return fail(c, HMJ_E_ARG, "bits must be in 1..9 and shift+bits <= 64");
+  int rc;
+  if ((rc = check_rel(c, in_aos_dev, n, "in_aos is NULL")) != HMJ_OK) return rc;
+  if ((rc = check_rel(c, out_aos_dev, n, "out_aos is NULL")) != HMJ_OK) return rc;
+  if (!offsets_dev) return fail(c, HMJ_E_ARG, "offsets_dev is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  spans_reset(c);
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(offsets_dev, 0, ((size_t)(1u << bits) + 1) * 8, c->stream));
+  } else if ((rc = radix_pass(c, in_aos_dev, out_aos_dev, (u32)n, shift, bits, -1,
+                              (u64*)offsets_dev)) != HMJ_OK) {
+    return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->profiling) spans_collect(c);
+  return HMJ_OK;
+}
+
+#define GEN_PROLOGUE                                                        \
+  if (!c) return HMJ_E_ARG;                                                 \
+  if (n && !out_aos_dev) return fail(c, HMJ_E_ARG, "out_aos is NULL");      \
+  HIP_TRY(hipSetDevice(c->device));                                         \
+  if (n == 0) return HMJ_OK;
+
+int hmj_gen_build_u64_device(hmj_ctx* c, void* out_aos_dev, uint64_t n, uint64_t start,
+                             uint64_t seed) {
+  GEN_PROLOGUE
+  HIP_TRY(hmj::launch_gen_build(out_aos_dev, n, start, seed, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HMJ_OK;
+}
+
+int hmj_gen_probe_u64_device(hmj_ctx* c, void* out_aos_dev, uint64_t n, uint64_t start,
+                             uint64_t n_build, uint64_t seed, uint64_t miss_mod) {
+  GEN_PROLOGUE
+  HIP_TRY(hmj::launch_gen_probe(out_aos_dev, n, start, n_build, seed, miss_mod, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HMJ_OK;
+}
+
+int hmj_gen_from_cdf_u64_device(hmj_ctx* c, void* out_aos_dev, uint64_t n, uint64_t start,
+                                const uint64_t* thr_dev, uint64_t domain, uint64_t seed,
+                                uint64_t zseed) {
+  GEN_PROLOGUE
+  if (!thr_dev || domain == 0) return fail(c, HMJ_E_ARG, "thr_dev/domain");
+  HIP_TRY(hmj::launch_gen_from_cdf(out_aos_dev, n, start, (const u64*)thr_dev, domain, seed, zseed,
+                                   c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HMJ_OK;
+}
+
+int hmj_gen_uniform_domain_u64_device(hmj_ctx* c, void* out_aos_dev, uint64_t n, uint64_t start,
+                                      uint64_t domain, uint64_t seed, uint64_t zseed) {
+  GEN_PROLOGUE
+  if (domain == 0) return fail(c, HMJ_E_ARG, "domain");
+  HIP_TRY(hmj::launch_gen_uniform_domain(out_aos_dev, n, start, domain, seed, zseed, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HMJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Shared device-side definitions for the gfx950 kernels (wave64, CDNA4).  Internal header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmj {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+
+// One relation row: std::pair<uint64_t,uint64_t>, moved as one dwordx4.
+struct __attribute__((aligned(16))) Tup {
+  u64 key;
+  u64 val;
+};
+
+constexpr int kWave = 64;
+
+// ---- radix pass geometry (radix.hip) -------------------------------------------------------
+constexpr int RP_THREADS = 512;                  // 8 waves
+constexpr int RP_WAVES = RP_THREADS / kWave;
+constexpr int RP_ITEMS = 8;                      // rows per thread per tile
+constexpr int RP_TILE = RP_THREADS * RP_ITEMS;   // 4096 rows = 64 KiB staged in LDS
+constexpr int RP_MAX_BITS = 9;                   // fan-out <= 512 per pass
+constexpr int RP_MAXD = 1 << RP_MAX_BITS;
+constexpr int RP_MAX_BLOCKS = 2048;              // "workers" (reference: threads) per pass
+
+// ---- build+probe geometry (probe.hip) ------------------------------------------------------
+constexpr int PB_THREADS = 512;
+constexpr int PB_CAP = 3072;          // build rows resident in LDS per chunk
+constexpr int PB_LOG_NB = 12;         // 4096 chain heads
+constexpr int PB_TARGET_AVG = 2048;   // planner: average build rows per partition
+constexpr int OR_CAP = 4096;          // rows per partition the ordered epilogue sorts in LDS
+
+// accumulator slots (global u64[8])
+enum { ACC_N = 0, ACC_SUM_R, ACC_SUM_S, ACC_XOR, ACC_MIX, ACC_SUM_P, ACC_ERR, ACC_PAD };
+constexpr u64 ERR_FIRST_WINS_OVERFLOW = 1;  // HMJ_FIRST_WINS with a build partition > PB_CAP
+
+__device__ __forceinline__ u64 mix64(u64 x) {  // same constants as oracle/hmj_oracle.c
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+__device__ __forceinline__ u64 tmix(u64 key, u64 rval, u64 sval) {
+  u64 t = mix64(key);
+  t = mix64(t ^ rval);
+  t = mix64(t + sval);
+  return t;
+}
+
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// number of set bits of `m` strictly below this lane
+__device__ __forceinline__ u32 popc_below(u64 m) {
+  return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    u32 t = __shfl_up(v, o, kWave);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+__device__ __forceinline__ u64 wave_xor_u64(u64 v) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) v ^= __shfl_xor(v, o, kWave);
+  return v;
+}
+
+// Block-wide exclusive scan of one u32 per thread.  scratch: >= THREADS/64 + 1 words of LDS.
+// Returns the exclusive prefix; *total receives the block sum.  Contains two barriers.
+template <int THREADS>
+__device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* scratch, u32* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = THREADS / kWave;
+  u32 incl = wave_incl_scan_u32(v, lane);
+  if (lane == 63) scratch[w] = incl;
+  __syncthreads();
+  u32 pre = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    u32 s = scratch[k];
+    if (k < w) pre += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return pre + incl - v;
+}
+
+}  // namespace hmj

@@ -1,0 +1,53 @@
+// Host-callable launchers of the gfx950 kernels.  Internal header (api.hip <-> *.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace hmj {
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// radix.hip
+void radix_pass_geometry(u32 n, u32* nblk, u32* rows_per_block);
+size_t radix_scatter_smem_bytes();
+hipError_t launch_radix_hist(const void* in, u32 n, int shift, int bits, u32* hist, u32 nblk,
+                             u32 rows_per_block, hipStream_t st);
+hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipStream_t st);
+hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int shift, int bits,
+                                const u32* hist_scanned, const u32* totals, u32 nblk,
+                                u32 rows_per_block, u64* offsets_out, hipStream_t st);
+hipError_t launch_part_offsets(const void* a, u32 n, int bits, u32* off, hipStream_t st);
+
+// probe.hip
+struct ProbeArgs {
+  const void* R;        // partitioned build rows
+  const u32* r_off;     // P+1
+  const void* S;        // partitioned probe rows
+  const u32* s_off;     // P+1
+  u32 P;                   // partitions
+  u32 Q;                   // probe slices per partition; work item w = p*Q + q
+  u64* part_count;         // P*Q    (count mode with per-item counts)
+  const u64* part_out_off; // P*Q+1  (write mode)
+  u64* out_key;
+  u64* out_rval;
+  u64* out_sval;
+  u64* accum;              // 8 x u64, see hmj_dev.h ACC_*
+};
+// mode: 0 = count/sums only, 1 = count + per-partition counts, 2 = write
+hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
+                        hipStream_t st);
+int probe_default_grid(int num_cus);
+hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
+hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rval, u64* sval, u64* accum,
+                        int grid, hipStream_t st);
+
+// gen.hip
+hipError_t launch_gen_build(void* out, u64 n, u64 start, u64 seed, hipStream_t st);
+hipError_t launch_gen_probe(void* out, u64 n, u64 start, u64 n_build, u64 seed, u64 miss_mod,
+                            hipStream_t st);
+hipError_t launch_gen_from_cdf(void* out, u64 n, u64 start, const u64* thr, u64 domain, u64 seed,
+                               u64 zseed, hipStream_t st);
+hipError_t launch_gen_uniform_domain(void* out, u64 n, u64 start, u64 domain, u64 seed, u64 zseed,
+                                     hipStream_t st);
+}  // namespace hmj

@@ -1,0 +1,397 @@
+// Bucket-local build + probe for gfx950.  One workgroup per radix partition (grid-stride):
+//   build : the partition's R rows are copied into LDS and linked into a chained hash table
+//           (one ds atomic exchange per row) -- the GPU form of tables[p].insert(item),
+//           partitioned_hash.h:166-170 (partitioned_table_worker) / :173-215;
+//   probe : the partition's S rows stream through in coalesced 16-byte loads and walk the chain
+//           -- the loop of hashjoin_bench.cc:92-96, which only ever meets table p with bucket p.
+// The rows it yields are the (key, rval, sval) of HashMergeJoin::iterator::operator*
+// (hashjoin.h:168-173); count mode computes the reduction hashjoin_bench.cc:131-133 performs.
+// Build partitions larger than PB_CAP rows (skew) are processed in LDS-sized chunks, re-streaming
+// the probe partition per chunk.
+#include "hmj_dev.h"
+#include "hmj_launch.h"
+
+namespace hmj {
+
+constexpr u32 PB_NB = 1u << PB_LOG_NB;
+constexpr u32 NIL = 0xFFFFu;
+static_assert(PB_CAP < 0xFFFF, "chain links are 16-bit");
+
+struct ProbeSmem {
+  u64 key[PB_CAP];
+  u64 val[PB_CAP];
+  u32 head[PB_NB];
+  u16 next[PB_CAP];
+  u32 scratch[PB_THREADS / kWave + 1];
+  u64 pcount;
+};
+
+__device__ __forceinline__ u32 tab_hash(u64 k) {
+  u32 x = (u32)k ^ ((u32)(k >> 32) * 0x85EBCA6Bu);
+  x *= 0x9E3779B1u;
+  return x >> (32 - PB_LOG_NB);
+}
+
+// MODE 0: count + sums.  MODE 1: also per-partition match counts.  MODE 2: write result columns.
+// FIRST: HMJ_FIRST_WINS.  EXTRA: HMJ_CHECKSUM / HMJ_SUM_PROBE accumulators.
+template <int MODE, bool FIRST, bool EXTRA>
+__global__ __launch_bounds__(PB_THREADS, 4) void probe_kernel(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ProbeSmem& sm = *reinterpret_cast<ProbeSmem*>(smem_raw);
+  const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
+  const Tup* __restrict__ S = static_cast<const Tup*>(a.S);
+  const int tid = threadIdx.x, lane = tid & 63;
+
+  u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
+  bool err = false;
+  if (MODE == 1 && tid == 0) sm.pcount = 0;
+
+  const u64 items = (u64)a.P * a.Q;
+  for (u64 w = blockIdx.x; w < items; w += gridDim.x) {
+    const u32 p = (u32)(w / a.Q), q = (u32)(w % a.Q);
+    const u32 rb = a.r_off[p], nb = a.r_off[p + 1] - rb;
+    const u32 sb0 = a.s_off[p], np0 = a.s_off[p + 1] - sb0;
+    const u32 lo = (u32)((u64)np0 * q / a.Q), hi = (u32)((u64)np0 * (q + 1) / a.Q);
+    const u32 sb = sb0 + lo, np = hi - lo;  // this item's slice of partition p's probe rows
+    if (nb == 0 || np == 0) {
+      if (EXTRA && MODE != 2)
+        for (u32 j = tid; j < np; j += PB_THREADS) acc_p += S[sb + j].val;
+      if (MODE == 1 && tid == 0) a.part_count[w] = 0;
+      continue;
+    }
+    if (FIRST && nb > PB_CAP) err = true;
+    u64 pc = 0;                                   // this thread's matches in partition p
+    u64 run = (MODE == 2) ? a.part_out_off[w] : 0;  // next output row of this item
+
+    for (u32 c0 = 0; c0 < nb; c0 += PB_CAP) {
+      const u32 cn = (nb - c0 < PB_CAP) ? nb - c0 : PB_CAP;
+      __syncthreads();
+      for (u32 i = tid; i < PB_NB; i += PB_THREADS) sm.head[i] = NIL;
+      __syncthreads();
+      // ---- build: copy rows to LDS, push each on its chain
+      for (u32 i0 = 0; i0 < cn; i0 += PB_THREADS * 2) {
+        Tup t[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          u32 i = i0 + k * PB_THREADS + tid;
+          if (i < cn) t[k] = R[(u64)rb + c0 + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          u32 i = i0 + k * PB_THREADS + tid;
+          if (i < cn) {
+            sm.key[i] = t[k].key;
+            sm.val[i] = t[k].val;
+            u32 old = atomicExch(&sm.head[tab_hash(t[k].key)], i);
+            sm.next[i] = (u16)old;
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- probe
+      if (MODE != 2) {
+        for (u32 j0 = 0; j0 < np; j0 += PB_THREADS * 4) {
+          Tup t[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            u32 j = j0 + k * PB_THREADS + tid;
+            if (j < np) t[k] = S[(u64)sb + j];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            u32 j = j0 + k * PB_THREADS + tid;
+            if (j < np) {
+              const u64 key = t[k].key, sval = t[k].val;
+              if (EXTRA && c0 == 0) acc_p += sval;
+              u32 i = sm.head[tab_hash(key)];
+              u32 best = NIL;
+              while (i != NIL) {
+                if (sm.key[i] == key) {
+                  if (FIRST) {
+                    best = (i < best) ? i : best;
+                  } else {
+                    const u64 rval = sm.val[i];
+                    pc++;
+                    acc_r += rval;
+                    acc_s += sval;
+                    if (EXTRA) {
+                      u64 m = tmix(key, rval, sval);
+                      acc_x ^= m;
+                      acc_m += m;
+                    }
+                  }
+                }
+                i = sm.next[i];
+              }
+              if (FIRST && best != NIL) {
+                const u64 rval = sm.val[best];
+                pc++;
+                acc_r += rval;
+                acc_s += sval;
+                if (EXTRA) {
+                  u64 m = tmix(key, rval, sval);
+                  acc_x ^= m;
+                  acc_m += m;
+                }
+              }
+            }
+          }
+        }
+      } else {
+        for (u32 j0 = 0; j0 < np; j0 += PB_THREADS) {
+          const u32 j = j0 + tid;
+          u64 key = 0, sval = 0;
+          u32 m = 0, first = NIL;
+          if (j < np) {
+            Tup t = S[(u64)sb + j];
+            key = t.key;
+            sval = t.val;
+            u32 i = sm.head[tab_hash(key)];
+            while (i != NIL) {
+              if (sm.key[i] == key) {
+                if (FIRST) {
+                  first = (i < first) ? i : first;
+                } else {
+                  if (m == 0) first = i;
+                  m++;
+                }
+              }
+              i = sm.next[i];
+            }
+            if (FIRST) m = (first != NIL) ? 1u : 0u;
+          }
+          u32 tot;
+          const u32 off = block_excl_scan_u32<PB_THREADS>(m, sm.scratch, &tot);
+          if (m) {
+            u64 o = run + off;
+            if (m == 1) {
+              a.out_key[o] = key;
+              a.out_rval[o] = sm.val[first];
+              a.out_sval[o] = sval;
+            } else {
+              u32 i = sm.head[tab_hash(key)];
+              while (i != NIL) {
+                if (sm.key[i] == key) {
+                  a.out_key[o] = key;
+                  a.out_rval[o] = sm.val[i];
+                  a.out_sval[o] = sval;
+                  o++;
+                }
+                i = sm.next[i];
+              }
+            }
+          }
+          run += tot;
+        }
+      }
+    }
+
+    acc_n += pc;
+    if (MODE == 1) {
+      u64 ws = wave_sum_u64(pc);
+      if (lane == 0 && ws) atomicAdd(&sm.pcount, ws);
+      __syncthreads();
+      if (tid == 0) {
+        a.part_count[w] = sm.pcount;
+        sm.pcount = 0;
+      }
+    }
+  }
+
+  if (MODE != 2) {
+    acc_n = wave_sum_u64(acc_n);
+    acc_r = wave_sum_u64(acc_r);
+    acc_s = wave_sum_u64(acc_s);
+    if (EXTRA) {
+      acc_x = wave_xor_u64(acc_x);
+      acc_m = wave_sum_u64(acc_m);
+      acc_p = wave_sum_u64(acc_p);
+    }
+    if (lane == 0) {
+      if (acc_n) atomicAdd(&a.accum[ACC_N], acc_n);
+      if (acc_r) atomicAdd(&a.accum[ACC_SUM_R], acc_r);
+      if (acc_s) atomicAdd(&a.accum[ACC_SUM_S], acc_s);
+      if (EXTRA) {
+        if (acc_x) atomicXor(&a.accum[ACC_XOR], acc_x);
+        if (acc_m) atomicAdd(&a.accum[ACC_MIX], acc_m);
+        if (acc_p) atomicAdd(&a.accum[ACC_SUM_P], acc_p);
+      }
+    }
+  }
+  if (err && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_FIRST_WINS_OVERFLOW);
+}
+
+// Exclusive scan of n u64 counts into n+1 offsets (single workgroup; n = partition count).
+__global__ __launch_bounds__(1024) void scan_u64_kernel(const u64* __restrict__ in,
+                                                        u64* __restrict__ out, u32 n) {
+  __shared__ u64 wsum[16];
+  __shared__ u64 carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (u32 base = 0; base < n; base += 1024) {
+    u32 i = base + tid;
+    u64 v = (i < n) ? in[i] : 0, incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      u64 t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    u64 pre = carry_s, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      u64 s = wsum[k];
+      if (k < w) pre += s;
+      tot += s;
+    }
+    if (i < n) out[i] = pre + incl - v;
+    __syncthreads();
+    if (tid == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = carry_s;
+}
+
+// HMJ_ORDERED epilogue: sort each partition's result rows by (key, rval, sval) with a bitonic
+// network.  Partitions are key ranges in ascending order (partitioning uses the most significant
+// key bits, radix_hash.h:369), so sorted partitions concatenate to the ascending-key order
+// HashMergeJoin iteration has (hashjoin.h:86-101).
+// The network is the "all ascending" form (first stage of each merge pairs mirrored positions), so
+// rows beyond the segment behave as +infinity and a pair reaching past the end is skipped: no
+// padding.  Segments up to OR_CAP rows are sorted in LDS; longer ones (probe side much larger than
+// the build side, or duplicate-heavy keys) run the same network on the global columns.
+struct OrderSmem {
+  u64 k[OR_CAP];
+  u64 r[OR_CAP];
+  u64 s[OR_CAP];
+};
+
+template <typename A>
+__device__ __forceinline__ void order_network(A k, A r, A s, u32 L, int tid) {
+  u32 n2 = 2;
+  while (n2 < L) n2 <<= 1;
+  for (u32 size = 2; size <= n2; size <<= 1) {
+    for (u32 j = size >> 1; j > 0; j >>= 1) {
+      const bool mirror = (j == (size >> 1));
+      for (u32 t = tid; t < (n2 >> 1); t += 512) {
+        u32 i, l;
+        if (mirror) {
+          u32 blk = t / j, idx = t % j;
+          i = blk * size + idx;
+          l = blk * size + (size - 1 - idx);
+        } else {
+          i = 2 * t - (t & (j - 1));
+          l = i + j;
+        }
+        if (l < L) {
+          u64 ki = k[i], kl = k[l], ri = r[i], rl = r[l], si = s[i], sl = s[l];
+          bool gt = (ki != kl) ? (ki > kl) : (ri != rl) ? (ri > rl) : (si > sl);
+          if (gt) {
+            k[i] = kl; k[l] = ki;
+            r[i] = rl; r[l] = ri;
+            s[i] = sl; s[l] = si;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void order_kernel(const u64* __restrict__ off, u32 P, u32 Q,
+                                                       u64* key, u64* rval, u64* sval) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  OrderSmem& sm = *reinterpret_cast<OrderSmem*>(smem_raw);
+  const int tid = threadIdx.x;
+  for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
+    const u64 b = off[(u64)p * Q], L64 = off[((u64)p + 1) * Q] - b;
+    if (L64 < 2) continue;
+    if (L64 > OR_CAP) {
+      if (L64 > 0x7FFFFFFFull) continue;  // cannot happen: n_matches per partition < 2^31 rows
+      __syncthreads();
+      order_network<u64*>(key + b, rval + b, sval + b, (u32)L64, tid);
+      continue;
+    }
+    const u32 L = (u32)L64;
+    __syncthreads();
+    for (u32 i = tid; i < L; i += 512) {
+      sm.k[i] = key[b + i];
+      sm.r[i] = rval[b + i];
+      sm.s[i] = sval[b + i];
+    }
+    __syncthreads();
+    order_network<u64*>(sm.k, sm.r, sm.s, L, tid);
+    for (u32 i = tid; i < L; i += 512) {
+      key[b + i] = sm.k[i];
+      rval[b + i] = sm.r[i];
+      sval[b + i] = sm.s[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool FIRST, bool EXTRA>
+static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(probe_kernel<MODE, FIRST, EXTRA>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProbeSmem));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((probe_kernel<MODE, FIRST, EXTRA>), dim3(grid), dim3(PB_THREADS),
+                     sizeof(ProbeSmem), st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
+                        hipStream_t st) {
+  if ((u64)grid > (u64)a.P * a.Q) grid = (int)((u64)a.P * a.Q);
+  if (grid < 1) grid = 1;
+#define HMJ_DISPATCH(M)                                                          \
+  if (first_wins)                                                                \
+    return extra ? launch_probe_t<M, true, true>(a, grid, st)                    \
+                 : launch_probe_t<M, true, false>(a, grid, st);                  \
+  else                                                                           \
+    return extra ? launch_probe_t<M, false, true>(a, grid, st)                   \
+                 : launch_probe_t<M, false, false>(a, grid, st);
+  if (mode == 0) {
+    HMJ_DISPATCH(0)
+  } else if (mode == 1) {
+    HMJ_DISPATCH(1)
+  } else {
+    if (first_wins) return launch_probe_t<2, true, false>(a, grid, st);
+    return launch_probe_t<2, false, false>(a, grid, st);
+  }
+#undef HMJ_DISPATCH
+}
+
+int probe_default_grid(int num_cus) { return num_cus * 2 * 4; }
+
+hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st) {
+  hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, in, out_excl, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rval, u64* sval, u64* accum,
+                        int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(order_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(OrderSmem));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if ((u32)grid > P) grid = (int)P;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(512), sizeof(OrderSmem), st, part_out_off, P, Q,
+                     key, rval, sval);
+  return hipGetLastError();
+}
+
+}  // namespace hmj

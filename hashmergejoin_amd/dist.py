@@ -1,0 +1,89 @@
+"""Multi-GPU radix partition exchange.  One process per GPU; the radix fan-out
+shards the join: the owner of a row is the top log2(G) bits of its key -- the same
+most-significant-bits rule the reference partitions with (radix_hash.h:369, partitioned_hash.h:102)
+-- so rank g ends up with key range g and the per-rank results concatenate in key order.
+
+Exchange = counts all-to-all + one all_to_all_single (grouped send/recv) per relation over
+torch.distributed (backend "nccl" is RCCL over xGMI on ROCm; "gloo" on CPU for tests).  The local
+split is the HIP radix pass (hmj_partition_u64_device); the local join is hmj_join_u64_device.
+Nothing here computes a join on the CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def owner_bits(world_size):
+    b = world_size.bit_length() - 1
+    if world_size < 1 or (1 << b) != world_size:
+        raise ValueError("world size must be a power of two (owner = top log2(G) key bits)")
+    return b
+
+
+def split_counts_from_offsets(offsets):
+    """offsets: [G+1] bucket starts -> python list of G row counts."""
+    o = offsets.to("cpu", torch.int64)
+    return [int(x) for x in (o[1:] - o[:-1]).tolist()]
+
+
+def exchange_rows(parted, send_counts, group=None):
+    """parted: [n,2] int64 rows already grouped by owner (owner-major); send_counts[g] rows go to
+    rank g.  Returns ([m,2] rows received, recv_counts).  Works on CPU tensors (gloo) and device
+    tensors (RCCL)."""
+    world = dist.get_world_size(group)
+    assert len(send_counts) == world and sum(send_counts) == parted.shape[0]
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=parted.device)
+    rc = torch.empty(world, dtype=torch.int64, device=parted.device)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.tolist()]
+    out = torch.empty((sum(recv_counts), 2), dtype=parted.dtype, device=parted.device)
+    dist.all_to_all_single(out, parted.contiguous(), output_split_sizes=recv_counts,
+                           input_split_sizes=list(send_counts), group=group)
+    return out, recv_counts
+
+
+def allreduce_checks(local, device, group=None):
+    """local: dict n_matches/sum_r/sum_s/xor_fold/mix_sum (python ints mod 2^64) -> global dict.
+    Sums wrap mod 2^64 (two's complement int64 add); the xor is folded after an all_gather."""
+    world = dist.get_world_size(group)
+
+    def s64(x):
+        x &= (1 << 64) - 1
+        return x - (1 << 64) if x >= (1 << 63) else x
+
+    keys = ["n_matches", "sum_r", "sum_s", "mix_sum"]
+    # split each 64-bit value in 32-bit halves so the reduction cannot overflow a signed add
+    halves = []
+    for k in keys:
+        v = local[k] & ((1 << 64) - 1)
+        halves += [v & 0xFFFFFFFF, v >> 32]
+    t = torch.tensor(halves, dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    h = t.tolist()
+    out = {}
+    for i, k in enumerate(keys):
+        out[k] = (h[2 * i] + (h[2 * i + 1] << 32)) & ((1 << 64) - 1)
+    x = torch.tensor([s64(local["xor_fold"])], dtype=torch.int64, device=device)
+    xs = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(xs, x, group=group)
+    acc = 0
+    for v in xs:
+        acc ^= int(v.item()) & ((1 << 64) - 1)
+    out["xor_fold"] = acc
+    return out
+
+
+def distributed_join(ex, r_shard, s_shard, flags=0, group=None):
+    """Each rank holds a row shard of R (build) and S (probe) on its GPU.  Returns
+    (local JoinResult for this rank's key range, global checks dict)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        res = ex.join_device(r_shard, s_shard, flags)
+        return res, res.checks()
+    b = owner_bits(world)
+    recv = []
+    for rel in (r_shard, s_shard):
+        parted, off = ex.partition_device(rel, 64 - b, b)
+        rows, _ = exchange_rows(parted, split_counts_from_offsets(off), group)
+        recv.append(rows)
+    res = ex.join_device(recv[0], recv[1], flags)
+    return res, allreduce_checks(res.checks(), r_shard.device, group)

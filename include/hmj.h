@@ -1,0 +1,157 @@
+/*
+ * hmj.h -- C ABI of libhmj_hip.so: the MI355X (gfx950) radix-partitioned hash-join executor.
+ *
+ * This is the drop-in boundary for ONE path of dryman/HashMergeJoin: radix partition ->
+ * bucket-local build -> probe, behind the reference's join operator.  Every entry point cites
+ * the reference interface it replaces (file:line in the reference tree).  Plain pointers and
+ * sizes only; no C++/STL/torch types cross this line; nothing throws.
+ *
+ * Relation layout (reference: hashjoin.h:29-31 KeyValVec, strgen.h:24-25):
+ *   n x { uint64_t key; uint64_t val; }  ==  std::pair<uint64_t,uint64_t>[n], contiguous AoS.
+ * Key hash: std::hash<uint64_t>, the identity (radix_hash.h:353) -- partitions are
+ * taken from the most significant bits of the key, as the reference does (radix_hash.h:369).
+ * R is the build side, S the probe side; a result row is (key, rval, sval) exactly as
+ * HashMergeJoin::iterator::operator* yields it (hashjoin.h:168-173).
+ *
+ * Semantics: relational equi-join.  For relations whose keys are unique within each relation
+ * (the reference generator's invariant, strgen_test.cc:24-33) the result equals what iterating
+ * the reference's HashMergeJoin yields, and with HMJ_ORDERED the order equals its iteration order
+ * (ascending key).  With duplicate keys: cross product per key (or HMJ_FIRST_WINS); the reference
+ * iterator's "staircase"/tail-cut artefact is not reproduced.
+ *
+ * Threading: an hmj_ctx is not thread-safe; use one per calling thread / per GPU.
+ */
+#ifndef HMJ_H
+#define HMJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hmj_ctx hmj_ctx;
+
+/* status codes: 0 ok, negative = error (the reference has none: assert/UB, strgen.cc:60) */
+#define HMJ_OK 0
+#define HMJ_E_ARG (-1)         /* bad argument / size beyond 2^32-1 tuples per call */
+#define HMJ_E_NODEV (-2)       /* no usable HIP device */
+#define HMJ_E_OOM (-3)         /* device or pinned-host allocation failed */
+#define HMJ_E_HIP (-4)         /* HIP runtime error, see hmj_last_error() */
+#define HMJ_E_UNSUPPORTED (-5) /* flag combination not supported for this input (see flags) */
+
+/* flags for hmj_join_* */
+#define HMJ_MATERIALIZE 0x01u /* produce the (key, rval, sval) columns; else count/sums only --   */
+                              /* the reduction hashjoin_bench.cc:131-133 performs                 */
+#define HMJ_ORDERED 0x02u     /* rows sorted by (key, rval, sval): HashMergeJoin iteration order  */
+                              /* (hashjoin.h:104-154); implies HMJ_MATERIALIZE                    */
+#define HMJ_FIRST_WINS 0x04u  /* each probe row pairs with the FIRST build row of its key in      */
+                              /* input order: unordered_map::insert, partitioned_hash.h:166-170   */
+#define HMJ_CHECKSUM 0x08u    /* also fill xor_fold / mix_sum (parity checks)                     */
+#define HMJ_SUM_PROBE 0x10u   /* also fill sum_probe_all (the 'miss inserts 0' sum of             */
+                              /* hashjoin_bench.cc:92-96 is sum_probe_all + sum_r w/ FIRST_WINS)  */
+
+typedef struct {
+  uint64_t n_matches;
+  uint64_t sum_r;         /* sum of rval over result rows, mod 2^64                               */
+  uint64_t sum_s;         /* sum of sval over result rows; sum_r + sum_s == hashjoin_bench.cc:132 */
+  uint64_t xor_fold;      /* XOR over rows of tmix(key,rval,sval)        (HMJ_CHECKSUM)           */
+  uint64_t mix_sum;       /* sum over rows of tmix(key,rval,sval)        (HMJ_CHECKSUM)           */
+  uint64_t sum_probe_all; /* sum of val over ALL probe rows              (HMJ_SUM_PROBE)          */
+  /* Result columns, n_matches entries each, NULL unless HMJ_MATERIALIZE.  Owned by the ctx,
+   * valid until the next hmj_join_* / hmj_release_result / hmj_destroy on it.
+   * hmj_join_u64_device: device pointers.  hmj_join_u64: host pointers (pinned).              */
+  const uint64_t* key;
+  const uint64_t* rval;
+  const uint64_t* sval;
+} hmj_result;
+
+/* Per-phase device time of the last join (HIP events on the ctx stream) and the algorithmic
+ * bytes each phase moves (DESIGN.md "algorithmic bytes").  Valid after hmj_set_profiling(ctx,1). */
+typedef struct {
+  float ms_total;
+  float ms_h2d, ms_d2h;           /* hmj_join_u64 only                                          */
+  float ms_partition_build;       /* all radix passes over R                                    */
+  float ms_partition_probe;       /* all radix passes over S                                    */
+  float ms_hist, ms_scan, ms_scatter; /* the same time split by kernel kind (both relations)    */
+  float ms_offsets;               /* partition boundary search                                  */
+  float ms_probe_count;           /* build+probe kernel, count/sum mode                         */
+  float ms_out_scan;              /* exclusive scan of per-partition match counts               */
+  float ms_probe_write;           /* build+probe kernel, materialising mode                     */
+  float ms_order;                 /* in-partition sort for HMJ_ORDERED                          */
+  int radix_bits;                 /* total partition bits B (2^B partitions)                    */
+  int radix_passes;               /* LSD passes per relation                                    */
+  int n_scatter_launches;         /* scatter kernel launches in this join                       */
+  int reserved;
+  uint64_t bytes_scatter;         /* algorithmic bytes of all scatter launches (32 B/tuple)     */
+  uint64_t bytes_hist;            /* 16 B/tuple per pass                                        */
+  uint64_t bytes_probe_count;     /* 16*(n_build + n_probe)                                     */
+  uint64_t bytes_probe_write;     /* 16*(n_build + n_probe) + 24*n_matches                      */
+} hmj_timing;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+/* Replaces: nothing in the reference (no device); one ctx per GPU. device_id < 0 = current.     */
+int hmj_create(hmj_ctx** out, int device_id);
+void hmj_destroy(hmj_ctx* ctx);
+/* Launch on the caller's HIP stream (hipStream_t passed as void*; NULL = the ctx's own stream). */
+int hmj_set_stream(hmj_ctx* ctx, void* hip_stream);
+/* Pre-allocate workspace for joins up to these sizes (so the timed call allocates nothing).     */
+int hmj_reserve(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, uint64_t max_matches,
+                uint32_t flags);
+/* Override the planner (the reference's optimal_partition heuristic, radix_hash.h:38-57, is tuned
+ * for CPU caches; ours targets LDS capacity).  total_bits < 0 restores automatic planning.       */
+int hmj_set_radix_bits(hmj_ctx* ctx, int total_bits);
+/* The automatic plan for a build side of n_build rows: total bits and per-pass bits (LSD order).*/
+int hmj_plan(uint64_t n_build, int* total_bits, int* n_passes, int pass_bits[4]);
+int hmj_set_profiling(hmj_ctx* ctx, int enabled);
+int hmj_last_timing(hmj_ctx* ctx, hmj_timing* out);
+const char* hmj_strerror(int code);
+const char* hmj_last_error(hmj_ctx* ctx);
+const char* hmj_version(void);
+
+/* ---- the join ---------------------------------------------------------------------------------- */
+/* Replaces HashMergeJoin<RIter,SIter>::HashMergeJoin(r_begin,r_end,s_begin,s_end,num_threads)
+ * (hashjoin.h:56-68) plus the iteration that consumes it (hashjoin.h:183-191, driven as in
+ * hashjoin_bench.cc:126-133), and equally the partition_only + partitioned_hash_table + probe loop
+ * of hashjoin_bench.cc:88-96 (partitioned_hash.h:82-124, :173-215).
+ * Inputs are device-resident, borrowed, read-only, not retained after return.  Blocking: on
+ * return `out` is filled and the result columns are complete on the stream.                      */
+int hmj_join_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_build,
+                        const void* probe_aos_dev, uint64_t n_probe, uint32_t flags,
+                        hmj_result* out);
+/* Same with host-resident relations (what a caller of the reference's ctor holds: pointers into
+ * std::vector<std::pair<uint64_t,uint64_t>>).  Copies in over PCIe, joins, copies results out.   */
+int hmj_join_u64(hmj_ctx* ctx, const void* build_aos_host, uint64_t n_build,
+                 const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out);
+void hmj_release_result(hmj_ctx* ctx);
+
+/* ---- one radix pass ---------------------------------------------------------------------------- */
+/* Replaces pass 1 of radix_int_non_inplace / radix_non_inplace_par: per-worker histogram, exclusive
+ * scan partition-major/worker-minor, STABLE scatter (radix_sort.h:418-449, radix_hash.h:313-345) on
+ * digit = (key >> shift) & (2^bits - 1), 1 <= bits <= 9.  offsets_dev: 2^bits + 1 uint64 bucket
+ * starts (device).  in/out: n x {key,val}, device, must not overlap.  Also the multi-GPU owner
+ * split.                                                                          */
+int hmj_partition_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, int shift, int bits,
+                             void* out_aos_dev, uint64_t* offsets_dev);
+
+/* ---- synthetic relations on device (same integer arithmetic as the oracle) ------- */
+/* key = mix64(i + seed), val = i, i in [start, start+n)                                          */
+int hmj_gen_build_u64_device(hmj_ctx* ctx, void* out_aos_dev, uint64_t n, uint64_t start,
+                             uint64_t seed);
+/* j in [start,start+n): idx = (0x9E3779B1*j + 12345) mod n_build (+ n_build when miss_mod > 0 and
+ * j % miss_mod == 0); key = mix64(idx + seed); val = j ^ 0x9E3779B97F4A7C15                      */
+int hmj_gen_probe_u64_device(hmj_ctx* ctx, void* out_aos_dev, uint64_t n, uint64_t start,
+                             uint64_t n_build, uint64_t seed, uint64_t miss_mod);
+/* rank = lower_bound(thr_dev[0..domain), mix64(i ^ zseed)); key = mix64(rank + seed); val = i     */
+int hmj_gen_from_cdf_u64_device(hmj_ctx* ctx, void* out_aos_dev, uint64_t n, uint64_t start,
+                                const uint64_t* thr_dev, uint64_t domain, uint64_t seed,
+                                uint64_t zseed);
+/* key = mix64((mix64(j ^ zseed) % domain) + seed); val = j ^ 0x9E3779B97F4A7C15                   */
+int hmj_gen_uniform_domain_u64_device(hmj_ctx* ctx, void* out_aos_dev, uint64_t n, uint64_t start,
+                                      uint64_t domain, uint64_t seed, uint64_t zseed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMJ_H */
