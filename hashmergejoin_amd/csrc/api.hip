@@ -40,7 +40,7 @@ struct hmj_ctx {
   int device = 0, num_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
-      out_key, out_rval, out_sval, offs64;
+      out_key, out_rval, out_sval, offs64, irregular;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int force_bits = -1;
   bool profiling = false;
@@ -294,7 +294,20 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   const int grid = hmj::probe_default_grid(c->num_cus);
 
   s = span_begin(c, K_PROBE_COUNT, -1);
-  HIP_TRY(hmj::launch_probe(a, materialize ? 1 : 0, first, extra, grid, c->stream));
+  if (!materialize && !first && !extra && Q == 1 && P >= 2) {
+    // headline path: pipelined count kernel, then the generic kernel over what it set aside
+    if ((rc = ensure_dev(c, c->irregular, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+    u32* n_irr = (u32*)c->irregular.p;
+    u32* irr = n_irr + 1;
+    HIP_TRY(hipMemsetAsync(n_irr, 0, 4, c->stream));
+    HIP_TRY(hmj::launch_probe_count_fast(a, irr, n_irr, c->num_cus * 3 * 4, c->stream));
+    hmj::ProbeArgs a2 = a;
+    a2.item_list = irr;
+    a2.n_item_list = n_irr;
+    HIP_TRY(hmj::launch_probe(a2, 0, false, false, c->num_cus * 2, c->stream));
+  } else {
+    HIP_TRY(hmj::launch_probe(a, materialize ? 1 : 0, first, extra, grid, c->stream));
+  }
   span_end(c, s);
   c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
   if (materialize) {
@@ -394,7 +407,7 @@ void hmj_destroy(hmj_ctx* c) {
   DevBuf* devs[] = {&c->rbuf[0], &c->rbuf[1], &c->sbuf[0], &c->sbuf[1], &c->in_r, &c->in_s,
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
-                    &c->offs64};
+                    &c->offs64, &c->irregular};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);

@@ -82,6 +82,14 @@ __device__ __forceinline__ u64 wave_xor_u64(u64 v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), which would stall every barrier on the global loads a kernel
+// keeps in flight as prefetch and on its fire-and-forget stores.  Use where all cross-thread
+// communication goes through LDS.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Block-wide exclusive scan of one u32 per thread.  scratch: >= THREADS/64 + 1 words of LDS.
 // Returns the exclusive prefix; *total receives the block sum.  Contains two barriers.
 template <int THREADS>
@@ -90,7 +98,7 @@ __device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* scratch, u32* tot
   constexpr int NW = THREADS / kWave;
   u32 incl = wave_incl_scan_u32(v, lane);
   if (lane == 63) scratch[w] = incl;
-  __syncthreads();
+  lds_barrier();
   u32 pre = 0, tot = 0;
 #pragma unroll
   for (int k = 0; k < NW; k++) {
@@ -98,7 +106,7 @@ __device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* scratch, u32* tot
     if (k < w) pre += s;
     tot += s;
   }
-  __syncthreads();
+  lds_barrier();
   *total = tot;
   return pre + incl - v;
 }

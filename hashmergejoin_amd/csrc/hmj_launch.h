@@ -33,11 +33,16 @@ struct ProbeArgs {
   u64* out_rval;
   u64* out_sval;
   u64* accum;              // 8 x u64, see hmj_dev.h ACC_*
+  const u32* item_list;    // optional: process only these items (set aside by the fast kernel)
+  const u32* n_item_list;  //           their count (device)
 };
 // mode: 0 = count/sums only, 1 = count + per-partition counts, 2 = write
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
                         hipStream_t st);
 int probe_default_grid(int num_cus);
+// count-mode fast path (Q == 1, no flags); partitions it cannot take go to irregular[]
+hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
+                                   hipStream_t st);
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
 hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rval, u64* sval, u64* accum,
                         int grid, hipStream_t st);

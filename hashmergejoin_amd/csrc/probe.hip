@@ -46,8 +46,10 @@ __global__ __launch_bounds__(PB_THREADS, 4) void probe_kernel(ProbeArgs a) {
   bool err = false;
   if (MODE == 1 && tid == 0) sm.pcount = 0;
 
-  const u64 items = (u64)a.P * a.Q;
-  for (u64 w = blockIdx.x; w < items; w += gridDim.x) {
+  // either all P*Q items, or (after the fast kernel) just the partitions it set aside
+  const u64 items = a.item_list ? (u64)*a.n_item_list : (u64)a.P * a.Q;
+  for (u64 wi = blockIdx.x; wi < items; wi += gridDim.x) {
+    const u64 w = a.item_list ? (u64)a.item_list[wi] : wi;
     const u32 p = (u32)(w / a.Q), q = (u32)(w % a.Q);
     const u32 rb = a.r_off[p], nb = a.r_off[p + 1] - rb;
     const u32 sb0 = a.s_off[p], np0 = a.s_off[p + 1] - sb0;
@@ -222,6 +224,132 @@ __global__ __launch_bounds__(PB_THREADS, 4) void probe_kernel(ProbeArgs a) {
   if (err && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_FIRST_WINS_OVERFLOW);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path of count mode (the headline: hashjoin_bench.cc:131-133 reduction, no flags).
+// Same build+probe, software-pipelined so HBM latency is never exposed: while partition p is
+// probed, the build rows of the workgroup's NEXT partition are already in flight, and p's probe
+// rows were requested before its table was built.  Chain heads carry a 16-bit epoch, so the table
+// is never cleared between partitions.  3 workgroups/CU (53 KiB LDS each).
+// Partitions that do not fit the register pipeline (more than FP_CAP build or probe rows: skew)
+// are appended to `irregular` and joined afterwards by the generic kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int FP_ROWS = 5;                       // rows per thread per side
+constexpr int FP_CAP = PB_THREADS * FP_ROWS;     // 2560
+constexpr int FP_LOG_NB = 11;
+constexpr u32 FP_NB = 1u << FP_LOG_NB;
+
+struct FastSmem {
+  u64 key[FP_CAP];
+  u64 val[FP_CAP];
+  u32 head[FP_NB];  // epoch << 16 | row
+  u16 next[FP_CAP];
+};
+
+__device__ __forceinline__ u32 fast_hash(u64 k) {
+  u32 x = (u32)k ^ ((u32)(k >> 32) * 0x85EBCA6Bu);
+  x *= 0x9E3779B1u;
+  return x >> (32 - FP_LOG_NB);
+}
+
+__device__ __forceinline__ void fp_load(Tup (&t)[FP_ROWS], const Tup* __restrict__ base, u32 n,
+                                        int tid) {
+  // unpredicated loads (index clamped into the partition) so all five issue back to back
+#pragma unroll
+  for (int k = 0; k < FP_ROWS; k++) {
+    u32 i = k * PB_THREADS + tid;
+    t[k] = base[i < n ? i : n - 1];
+  }
+}
+
+__global__ __launch_bounds__(PB_THREADS, 6) void probe_count_fast_kernel(ProbeArgs a,
+                                                                          u32* __restrict__ irregular,
+                                                                          u32* __restrict__ n_irregular) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  FastSmem& sm = *reinterpret_cast<FastSmem*>(smem_raw);
+  const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
+  const Tup* __restrict__ S = static_cast<const Tup*>(a.S);
+  const u32* __restrict__ r_off = a.r_off;
+  const u32* __restrict__ s_off = a.s_off;
+  const u32 P = a.P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  u64 acc_n = 0, acc_r = 0, acc_s = 0;
+  for (u32 i = tid; i < FP_NB; i += PB_THREADS) sm.head[i] = 0;
+  u32 epoch = 0;
+
+  u32 p = blockIdx.x;
+  u32 rb = 0, nb = 0, sb = 0, np = 0;
+  bool regular = false;
+  Tup br[FP_ROWS], pr[FP_ROWS];
+  if (p < P) {
+    rb = r_off[p]; nb = r_off[p + 1] - rb;
+    sb = s_off[p]; np = s_off[p + 1] - sb;
+    regular = nb && np && nb <= FP_CAP && np <= FP_CAP;
+    if (regular) fp_load(br, R + rb, nb, tid);
+  }
+  while (p < P) {
+    const u32 pn = __builtin_amdgcn_readfirstlane(p + gridDim.x);  // keep the offsets on the scalar path
+    u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
+    bool regular2 = false;
+    if (pn < P) {
+      rb2 = r_off[pn]; nb2 = r_off[pn + 1] - rb2;
+      sb2 = s_off[pn]; np2 = s_off[pn + 1] - sb2;
+      regular2 = nb2 && np2 && nb2 <= FP_CAP && np2 <= FP_CAP;
+    }
+    if (regular) {
+      fp_load(pr, S + sb, np, tid);   // probe rows: in flight while the table is built
+      lds_barrier();                   // everyone is done probing the previous table
+      epoch++;
+      if (epoch == 0x10000u) {         // 16-bit epoch wrapped: clear once
+        for (u32 i = tid; i < FP_NB; i += PB_THREADS) sm.head[i] = 0;
+        epoch = 1;
+        lds_barrier();
+      }
+      const u32 tag = epoch << 16;
+#pragma unroll
+      for (int k = 0; k < FP_ROWS; k++) {
+        const u32 i = k * PB_THREADS + tid;
+        if (i < nb) {
+          sm.key[i] = br[k].key;
+          sm.val[i] = br[k].val;
+          const u32 old = atomicExch(&sm.head[fast_hash(br[k].key)], tag | i);
+          sm.next[i] = ((old >> 16) == epoch) ? (u16)old : (u16)NIL;
+        }
+      }
+      if (regular2) fp_load(br, R + rb2, nb2, tid);  // next partition's build rows
+      lds_barrier();                                  // table complete
+#pragma unroll
+      for (int k = 0; k < FP_ROWS; k++) {
+        const u32 j = k * PB_THREADS + tid;
+        if (j < np) {
+          const u64 key = pr[k].key;
+          const u32 hv = sm.head[fast_hash(key)];
+          u32 i = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
+          while (i != NIL) {
+            if (sm.key[i] == key) {
+              acc_n++;
+              acc_r += sm.val[i];
+              acc_s += pr[k].val;
+            }
+            i = sm.next[i];
+          }
+        }
+      }
+    } else {
+      if (tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
+      if (regular2) fp_load(br, R + rb2, nb2, tid);
+    }
+    p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
+  }
+  acc_n = wave_sum_u64(acc_n);
+  acc_r = wave_sum_u64(acc_r);
+  acc_s = wave_sum_u64(acc_s);
+  if (lane == 0) {
+    if (acc_n) atomicAdd(&a.accum[ACC_N], acc_n);
+    if (acc_r) atomicAdd(&a.accum[ACC_SUM_R], acc_r);
+    if (acc_s) atomicAdd(&a.accum[ACC_SUM_S], acc_s);
+  }
+}
+
 // Exclusive scan of n u64 counts into n+1 offsets (single workgroup; n = partition count).
 __global__ __launch_bounds__(1024) void scan_u64_kernel(const u64* __restrict__ in,
                                                         u64* __restrict__ out, u32 n) {
@@ -348,9 +476,26 @@ static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
+hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
+                                   hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(probe_count_fast_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(FastSmem));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if ((u32)grid > a.P) grid = (int)a.P;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(probe_count_fast_kernel, dim3(grid), dim3(PB_THREADS), sizeof(FastSmem), st, a,
+                     irregular, n_irregular);
+  return hipGetLastError();
+}
+
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
                         hipStream_t st) {
-  if ((u64)grid > (u64)a.P * a.Q) grid = (int)((u64)a.P * a.Q);
+  if (!a.item_list && (u64)grid > (u64)a.P * a.Q) grid = (int)((u64)a.P * a.Q);
   if (grid < 1) grid = 1;
 #define HMJ_DISPATCH(M)                                                          \
   if (first_wins)                                                                \

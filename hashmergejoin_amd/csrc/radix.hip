@@ -19,15 +19,21 @@ namespace hmj {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RP_THREADS) void radix_hist_kernel(const Tup* __restrict__ in, u32 n,
                                                                 int shift, u32 mask,
-                                                                u32 rows_per_block,
+                                                                u32 rows_per_block, u32 n_full,
                                                                 u32* __restrict__ hist, u32 nblk) {
   __shared__ u32 h[RP_MAXD];
   const u32 D = mask + 1;
   for (u32 d = threadIdx.x; d < D; d += RP_THREADS) h[d] = 0;
   __syncthreads();
-  const u64 begin = (u64)blockIdx.x * rows_per_block;
-  u64 end = begin + rows_per_block;
-  if (end > n) end = n;
+  // workers 0..k-1 own whole tiles of [0, n_full); one extra worker owns the ragged tail
+  u64 begin = (u64)blockIdx.x * rows_per_block, end;
+  if (begin < n_full) {
+    end = begin + rows_per_block;
+    if (end > n_full) end = n_full;
+  } else {
+    begin = n_full;
+    end = n;
+  }
   const u64* __restrict__ keys = reinterpret_cast<const u64*>(in);
   for (u64 base = begin; base < end; base += (u64)RP_THREADS * RP_ITEMS) {
     u64 k[RP_ITEMS];
@@ -68,79 +74,119 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(u32* __restrict__ hi
 // ---------------------------------------------------------------------------------------------
 // K3: stable scatter.  Algorithmic traffic: 16 B/row read + 16 B/row written.
 // LDS: 64 KiB tile + 8 KiB per-wave digit counters + 6 KiB per-digit state  -> 2 workgroups/CU.
+//
+// Ranking (the hot part) is wave-synchronous and needs no ballots: every wave owns a table of
+// one 64-bit LANE MASK per digit (aliased onto the tile buffer, which is idle while ranking).
+// A lane ORs its lane bit into mask[digit] (ds_or_b64), reads the word back -- LDS executes one
+// wave's instructions in order, so it now holds exactly the lanes of this round with the same
+// digit -- and the lowest such lane adds the population to the per-wave digit counter and
+// clears the mask.  rank = counter before + matching lanes below me: stable by construction.
 // ---------------------------------------------------------------------------------------------
 struct ScatterSmem {
-  Tup stage[RP_TILE];
+  union {
+    Tup stage[RP_TILE];             // rows of the tile, grouped by digit
+    u64 lanemask[RP_WAVES][RP_MAXD];  // ranking scratch (first 32 KiB), all-zero between uses
+  };
   u16 wcnt[RP_WAVES][RP_MAXD];  // per-wave digit counts, then exclusive prefix across waves
   u32 tile_off[RP_MAXD];        // start of digit d inside the staged tile
   u32 delta[RP_MAXD];           // global cursor of d minus tile_off[d]
   u32 cursor[RP_MAXD];          // next output row of digit d for this worker
   u32 scratch[RP_WAVES + 1];
 };
+static_assert(sizeof(u64) * RP_WAVES * RP_MAXD <= sizeof(Tup) * RP_TILE / 2, "mask table must fit half the tile");
 
+template <bool HI>  // HI: the digit lies entirely in the key's high 32 bits (shift >= 32)
+__device__ __forceinline__ u32 digit_of(u64 key, int shift, u32 mask) {
+  if (HI) return ((u32)(key >> 32) >> (shift - 32)) & mask;
+  return (u32)(key >> shift) & mask;
+}
+
+// Loads this lane's 8 rows of the tile at `src`.  FULL tiles use unpredicated loads so the eight
+// dwordx4 requests issue back to back.
+template <bool FULL>
+__device__ __forceinline__ void load_tile(Tup (&t)[RP_ITEMS], const Tup* __restrict__ src,
+                                          u32 wbase, u32 tile_n) {
+#pragma unroll
+  for (int r = 0; r < RP_ITEMS; r++)
+    if (FULL || wbase + r * 64 < tile_n) t[r] = src[wbase + r * 64];
+}
+
+// FULL = true : workers that own only whole tiles (the bulk; no predication anywhere).
+// FULL = false: the single tail worker (rows [n_full, n), fewer than one tile), launched apart so
+//               its predicated code does not cost the bulk kernel registers.
+template <bool HI, bool FULL>
 __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
-    const Tup* __restrict__ in, Tup* __restrict__ out, u32 n, int shift, int bits,
-    u32 rows_per_block, const u32* __restrict__ hist_scanned, const u32* __restrict__ totals,
-    u32 nblk, u64* __restrict__ offsets_out) {
+    const Tup* __restrict__ in, Tup* __restrict__ out, u32 n, u32 n_full, int shift, int bits,
+    u32 rows_per_block, u32 worker_base, const u32* __restrict__ hist_scanned,
+    const u32* __restrict__ totals, u32 nblk, u64* __restrict__ offsets_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ScatterSmem& sm = *reinterpret_cast<ScatterSmem*>(smem_raw);
   const u32 D = 1u << bits, mask = D - 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 worker = worker_base + blockIdx.x;
 
   // digit bases = exclusive scan of the digit totals (D <= 512 == RP_THREADS: one per thread)
   {
     u32 t = ((u32)tid < D) ? totals[tid] : 0, tot;
     u32 base = block_excl_scan_u32<RP_THREADS>(t, sm.scratch, &tot);
     if ((u32)tid < D) {
-      sm.cursor[tid] = base + hist_scanned[(u64)tid * nblk + blockIdx.x];
-      if (offsets_out && blockIdx.x == 0) {
+      sm.cursor[tid] = base + hist_scanned[(u64)tid * nblk + worker];
+      if (offsets_out && worker == 0) {
         offsets_out[tid] = base;
         if ((u32)tid == D - 1) offsets_out[D] = n;
       }
     }
-    for (int i = tid; i < RP_WAVES * RP_MAXD; i += RP_THREADS) (&sm.wcnt[0][0])[i] = 0;
+    for (int i = tid; i < RP_WAVES * RP_MAXD / 2; i += RP_THREADS)
+      reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
+    for (int i = tid; i < RP_WAVES * RP_MAXD; i += RP_THREADS) (&sm.lanemask[0][0])[i] = 0;
   }
   __syncthreads();
 
-  const u64 begin = (u64)blockIdx.x * rows_per_block;
-  u64 end = begin + rows_per_block;
-  if (end > n) end = n;
-  volatile u16* wc = &sm.wcnt[w][0];
+  u64 begin, end;
+  if (FULL) {
+    begin = (u64)blockIdx.x * rows_per_block;
+    end = begin + rows_per_block;
+    if (end > n_full) end = n_full;
+  } else {
+    begin = n_full;
+    end = n;
+  }
+  if (begin >= end) return;
+
+  // relaxed workgroup-scope atomics: plain LDS instructions, never cached in registers, and --
+  // unlike volatile accesses -- no s_waitcnt vmcnt(0) around them (the prefetch stays in flight)
+  u16* wc = &sm.wcnt[w][0];
+  u64* lm = &sm.lanemask[w][0];
+  const u64 lanebit = 1ull << lane;
+  const u32 wbase = (u32)w * (RP_ITEMS * 64) + lane;  // this lane's row in round 0
+
+  // wave w owns rows [w*512, w*512+512) of a tile, 8 rounds of 64 consecutive rows: lane order
+  // inside a round + round order == row order, which is what makes the rank stable.
+  Tup t[RP_ITEMS];
+  load_tile<FULL>(t, in + begin, wbase, (u32)(end - begin));
 
   for (u64 tile = begin; tile < end; tile += RP_TILE) {
-    const u32 tile_n = (u32)((end - tile < RP_TILE) ? end - tile : RP_TILE);
-    // wave w owns rows [w*512, w*512+512) of the tile, 8 rounds of 64 consecutive rows: lane
-    // order inside a round + round order == row order, which is what makes the rank stable.
-    Tup t[RP_ITEMS];
-    u32 dg[RP_ITEMS];
-    u32 rk[RP_ITEMS];
+    const u32 tile_n = FULL ? (u32)RP_TILE : (u32)(end - tile);
+    u32 dr[RP_ITEMS];  // digit << 16 | rank inside this wave's 512 rows
 #pragma unroll
     for (int r = 0; r < RP_ITEMS; r++) {
-      u32 li = (u32)w * (RP_ITEMS * 64) + r * 64 + lane;
-      if (li < tile_n) t[r] = in[tile + li];
-    }
-#pragma unroll
-    for (int r = 0; r < RP_ITEMS; r++) {
-      u32 li = (u32)w * (RP_ITEMS * 64) + r * 64 + lane;
-      bool valid = li < tile_n;
-      u32 d = valid ? ((u32)(t[r].key >> shift) & mask) : 0;
-      // lanes holding the same digit (wave match-any by bit ballots)
-      u64 m = __ballot(valid);
-      for (int b = 0; b < bits; b++) {
-        bool bit = (d >> b) & 1;
-        u64 bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+      u32 d = 0, rank = 0;
+      if (FULL || wbase + r * 64 < tile_n) {
+        d = digit_of<HI>(t[r].key, shift, mask);
+        __hip_atomic_fetch_or(&lm[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u64 m = __hip_atomic_load(&lm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 old = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 below = popc_below(m);
+        if (below == 0) {
+          __hip_atomic_store(&lm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&wc[d], (u16)(old + (u32)__popcll(m)), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        rank = old + below;
       }
-      u32 below = popc_below(m);
-      u32 old = 0;
-      if (valid) {
-        old = wc[d];
-        if (below == 0) wc[d] = (u16)(old + (u32)__popcll(m));
-      }
-      dg[r] = d;
-      rk[r] = old + below;
+      dr[r] = (d << 16) | rank;
     }
-    __syncthreads();
+    lds_barrier();
 
     // per digit: exclusive prefix over the 8 waves, tile totals, tile offsets, global delta
     {
@@ -162,31 +208,51 @@ __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
         sm.cursor[tid] = cur + cnt;
       }
     }
-    __syncthreads();
+    lds_barrier();
 
 #pragma unroll
     for (int r = 0; r < RP_ITEMS; r++) {
-      u32 li = (u32)w * (RP_ITEMS * 64) + r * 64 + lane;
-      if (li < tile_n) {
-        u32 pos = sm.tile_off[dg[r]] + sm.wcnt[w][dg[r]] + rk[r];
+      if (FULL || wbase + r * 64 < tile_n) {
+        const u32 d = dr[r] >> 16;
+        const u32 pos = sm.tile_off[d] + sm.wcnt[w][d] + (dr[r] & 0xFFFFu);
         sm.stage[pos] = t[r];
       }
     }
-    __syncthreads();
+    // the rows now live in LDS: start fetching the next tile while this one is written out
+    if (FULL && tile + RP_TILE < end) load_tile<true>(t, in + tile + RP_TILE, wbase, RP_TILE);
+    lds_barrier();
 
-    // copy out: consecutive lanes -> consecutive rows of one digit run -> contiguous 16-B stores
+    // copy out: consecutive lanes -> consecutive rows of one digit run -> contiguous 16-B stores;
+    // the first half of the tile buffer is handed back to the ranking masks as zeros
 #pragma unroll
-    for (int r = 0; r < RP_ITEMS; r++) {
-      u32 i = r * RP_THREADS + tid;
-      if (i < tile_n) {
-        Tup v = sm.stage[i];
-        u32 d = (u32)(v.key >> shift) & mask;
-        out[sm.delta[d] + i] = v;
+    for (int h = 0; h < 2; h++) {
+      Tup v[RP_ITEMS / 2];
+#pragma unroll
+      for (int r = 0; r < RP_ITEMS / 2; r++) {
+        const u32 i = (h * (RP_ITEMS / 2) + r) * RP_THREADS + tid;
+        if (FULL || i < tile_n) v[r] = sm.stage[i];
+      }
+      if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < RP_ITEMS / 2; r++) {
+          Tup z;
+          z.key = 0;
+          z.val = 0;
+          sm.stage[r * RP_THREADS + tid] = z;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RP_ITEMS / 2; r++) {
+        const u32 i = (h * (RP_ITEMS / 2) + r) * RP_THREADS + tid;
+        if (FULL || i < tile_n) {
+          const u32 d = digit_of<HI>(v[r].key, shift, mask);
+          out[sm.delta[d] + i] = v[r];
+        }
       }
     }
     for (int i = tid; i < RP_WAVES * RP_MAXD / 2; i += RP_THREADS)
       reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -218,11 +284,15 @@ __global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int bits,
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+// Workers: k = ceil(full_tiles / tiles_per_worker) workers own whole tiles; if n is not a multiple
+// of the tile, one more worker owns the ragged tail.  *nblk counts all of them.
 void radix_pass_geometry(u32 n, u32* nblk, u32* rows_per_block) {
-  u64 tiles = ((u64)n + RP_TILE - 1) / RP_TILE;
-  if (tiles == 0) tiles = 1;
-  u64 tpb = (tiles + RP_MAX_BLOCKS - 1) / RP_MAX_BLOCKS;
-  *nblk = (u32)((tiles + tpb - 1) / tpb);
+  u64 full_tiles = (u64)n / RP_TILE;
+  u64 tpb = (full_tiles + RP_MAX_BLOCKS - 1) / RP_MAX_BLOCKS;
+  if (tpb == 0) tpb = 1;
+  u64 k = (full_tiles + tpb - 1) / tpb;
+  *nblk = (u32)(k + ((u64)n % RP_TILE ? 1 : 0));
+  if (*nblk == 0) *nblk = 1;
   *rows_per_block = (u32)(tpb * RP_TILE);
 }
 
@@ -230,9 +300,10 @@ size_t radix_scatter_smem_bytes() { return sizeof(ScatterSmem); }
 
 hipError_t launch_radix_hist(const void* in, u32 n, int shift, int bits, u32* hist, u32 nblk,
                              u32 rows_per_block, hipStream_t st) {
+  const u32 n_full = (n / RP_TILE) * RP_TILE;
   hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(RP_THREADS), 0, st,
-                     static_cast<const Tup*>(in), n, shift, (1u << bits) - 1, rows_per_block, hist,
-                     nblk);
+                     static_cast<const Tup*>(in), n, shift, (1u << bits) - 1, rows_per_block, n_full,
+                     hist, nblk);
   return hipGetLastError();
 }
 
@@ -241,21 +312,49 @@ hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipS
   return hipGetLastError();
 }
 
-hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int shift, int bits,
-                                const u32* hist_scanned, const u32* totals, u32 nblk,
-                                u32 rows_per_block, u64* offsets_out, hipStream_t st) {
+template <bool HI, bool FULL>
+static hipError_t launch_radix_scatter_t(const void* in, void* out, u32 n, u32 n_full, int shift,
+                                         int bits, u32 rows_per_block, u32 worker_base, u32 grid,
+                                         const u32* hist_scanned, const u32* totals, u32 nblk,
+                                         u64* offsets_out, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(radix_scatter_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(ScatterSmem));
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(radix_scatter_kernel<HI, FULL>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterSmem));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(RP_THREADS), sizeof(ScatterSmem), st,
-                     static_cast<const Tup*>(in), static_cast<Tup*>(out), n, shift, bits,
-                     rows_per_block, hist_scanned, totals, nblk, offsets_out);
+  hipLaunchKernelGGL((radix_scatter_kernel<HI, FULL>), dim3(grid), dim3(RP_THREADS),
+                     sizeof(ScatterSmem), st, static_cast<const Tup*>(in), static_cast<Tup*>(out), n,
+                     n_full, shift, bits, rows_per_block, worker_base, hist_scanned, totals, nblk,
+                     offsets_out);
   return hipGetLastError();
+}
+
+hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int shift, int bits,
+                                const u32* hist_scanned, const u32* totals, u32 nblk,
+                                u32 rows_per_block, u64* offsets_out, hipStream_t st) {
+  const u32 n_full = (n / RP_TILE) * RP_TILE;
+  const bool tail = n_full != n;
+  const u32 k = nblk - (tail ? 1 : 0);  // workers owning whole tiles
+  const bool hi = shift >= 32;
+  hipError_t e = hipSuccess;
+  if (n_full) {
+    e = hi ? launch_radix_scatter_t<true, true>(in, out, n, n_full, shift, bits, rows_per_block, 0, k,
+                                                hist_scanned, totals, nblk, offsets_out, st)
+           : launch_radix_scatter_t<false, true>(in, out, n, n_full, shift, bits, rows_per_block, 0,
+                                                 k, hist_scanned, totals, nblk, offsets_out, st);
+    if (e != hipSuccess) return e;
+  }
+  if (tail) {
+    const u32 wb = n_full ? k : 0;
+    e = hi ? launch_radix_scatter_t<true, false>(in, out, n, n_full, shift, bits, rows_per_block, wb,
+                                                 1, hist_scanned, totals, nblk, offsets_out, st)
+           : launch_radix_scatter_t<false, false>(in, out, n, n_full, shift, bits, rows_per_block,
+                                                  wb, 1, hist_scanned, totals, nblk, offsets_out, st);
+  }
+  return e;
 }
 
 hipError_t launch_part_offsets(const void* a, u32 n, int bits, u32* off, hipStream_t st) {
