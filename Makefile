@@ -7,7 +7,7 @@ CSRC     := hashmergejoin_amd/csrc
 OBJS     := $(CSRC)/radix.o $(CSRC)/probe.o $(CSRC)/gen.o $(CSRC)/api.o
 LIB      := hashmergejoin_amd/libhmj_hip.so
 
-all: $(LIB) oracle
+all: $(LIB) oracle cpptest
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/hmj_dev.h $(CSRC)/hmj_launch.h include/hmj.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -18,11 +18,14 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle all
 
-examples: $(LIB)
-	$(MAKE) -C examples
+# C++ drop-in test: host-only g++ against the C ABI (+ the oracle as checker)
+cpptest: tests/cpp/test_dropin
+tests/cpp/test_dropin: tests/cpp/test_dropin.cc include/hashmergejoin_hip.hpp include/hmj.h $(LIB) oracle
+	g++ -std=c++11 -O2 -Wall -Iinclude -Ioracle $< -o $@ -Lhashmergejoin_amd -lhmj_hip -Loracle -lhmj_oracle \
+	  -Wl,-rpath,'$$ORIGIN/../../hashmergejoin_amd' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,/opt/rocm/lib -pthread
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) tests/cpp/test_dropin
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle examples clean
+.PHONY: all oracle cpptest clean

@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=28, help="rows per relation PER GPU (log2)")
     ap.add_argument("--materialize", action="store_true", help="also write the (key,rval,sval) columns")
-    ap.add_argument("--cpu-log2n", type=int, default=23)
+    ap.add_argument("--cpu-log2n", type=int, default=24)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--bits", type=int, default=-1, help="force total radix bits")
     a = ap.parse_args()
@@ -191,7 +191,12 @@ def main():
         }
         if world == 1 and not a.no_cpu:
             try:
-                line["cpu_baseline"] = cpu_baseline(a.cpu_log2n, os.cpu_count() or 1)
+                try:
+                    cores = len(os.sched_getaffinity(0))
+                except Exception:
+                    cores = os.cpu_count() or 1
+                cores = min(cores, int(os.environ.get("HMJ_CPU_THREADS", "16")))  # the box's CPU share for one GPU
+                line["cpu_baseline"] = cpu_baseline(a.cpu_log2n, cores)
             except Exception as e:  # the baseline is reporting only; never fail the bench on it
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,6 +44,7 @@ struct hmj_ctx {
       out_key, out_rval, out_sval, offs64, irregular;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int force_bits = -1;
+  int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;
   std::vector<hipEvent_t> events;
   std::vector<Span> spans;
@@ -188,18 +190,20 @@ void plan_bits(u64 n_build, int force, int* total, int* passes, int pass_bits[4]
 int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bits, int rel,
                u64* offsets_out) {
   u32 nblk, rpb;
-  hmj::radix_pass_geometry(n, &nblk, &rpb);
+  const int variant = c->scatter_variant;
+  const int tile = hmj::radix_tile_rows(bits, variant);
+  hmj::radix_pass_geometry(n, tile, &nblk, &rpb);
   int rc;
   if ((rc = ensure_dev(c, c->hist, (size_t)(1u << bits) * nblk * sizeof(u32))) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->totals, (size_t)hmj::RP_MAXD * sizeof(u32))) != HMJ_OK) return rc;
   int s = span_begin(c, K_HIST, rel);
-  HIP_TRY(hmj::launch_radix_hist(src, n, shift, bits, (u32*)c->hist.p, nblk, rpb, c->stream));
+  HIP_TRY(hmj::launch_radix_hist(src, n, tile, shift, bits, (u32*)c->hist.p, nblk, rpb, c->stream));
   span_end(c, s);
   s = span_begin(c, K_SCAN, rel);
   HIP_TRY(hmj::launch_radix_rowscan((u32*)c->hist.p, nblk, bits, (u32*)c->totals.p, c->stream));
   span_end(c, s);
   s = span_begin(c, K_SCATTER, rel);
-  HIP_TRY(hmj::launch_radix_scatter(src, dst, n, shift, bits, (const u32*)c->hist.p,
+  HIP_TRY(hmj::launch_radix_scatter(src, dst, n, variant, shift, bits, (const u32*)c->hist.p,
                                     (const u32*)c->totals.p, nblk, rpb, offsets_out, c->stream));
   span_end(c, s);
   c->timing.bytes_hist += 16ull * n;
@@ -382,6 +386,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return HMJ_E_NODEV;
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
+  if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -419,7 +424,7 @@ void hmj_destroy(hmj_ctx* c) {
 
 int hmj_set_stream(hmj_ctx* c, void* hip_stream) {
   if (!c) return HMJ_E_ARG;
-  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  c->stream = (hip_stream == HMJ_STREAM_OWN) ? c->own_stream : (hipStream_t)hip_stream;
   return HMJ_OK;
 }
 

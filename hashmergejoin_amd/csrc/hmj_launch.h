@@ -9,12 +9,14 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 // radix.hip
-void radix_pass_geometry(u32 n, u32* nblk, u32* rows_per_block);
+// variant: 0 = plain staged scatter (4096-row tile), 1 = write-combining scatter (WC_X / WC_Y)
+int radix_tile_rows(int bits, int variant);
+void radix_pass_geometry(u32 n, int tile, u32* nblk, u32* rows_per_block);
 size_t radix_scatter_smem_bytes();
-hipError_t launch_radix_hist(const void* in, u32 n, int shift, int bits, u32* hist, u32 nblk,
-                             u32 rows_per_block, hipStream_t st);
+hipError_t launch_radix_hist(const void* in, u32 n, int tile, int shift, int bits, u32* hist,
+                             u32 nblk, u32 rows_per_block, hipStream_t st);
 hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipStream_t st);
-hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int shift, int bits,
+hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, int shift, int bits,
                                 const u32* hist_scanned, const u32* totals, u32 nblk,
                                 u32 rows_per_block, u64* offsets_out, hipStream_t st);
 hipError_t launch_part_offsets(const void* a, u32 n, int bits, u32* off, hipStream_t st);

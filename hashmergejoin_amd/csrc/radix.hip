@@ -257,6 +257,228 @@ __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3': stable scatter with software write-combining.  Same ranking and staging as K3, but the
+// output of every digit is only ever stored in WHOLE 128-byte lines (8 rows): the rows of a
+// digit's trailing partial line wait in an LDS carry buffer (carry[digit][8]) until a later tile
+// of the same worker completes the line.  Measured motivation (tools/exp_align.py, 2^28 rows,
+// 9-bit fan-out): line-aligned runs 1.70 ms (5.1 TB/s) vs unaligned runs 2.90 ms (2.9 TB/s) --
+// partial lines, not run length, are what the plain scatter pays for.
+//   WC_X: 512 threads, 2048-row tile, fan-out <= 256  -> 74 KiB LDS, 2 workgroups/CU
+//   WC_Y: 1024 threads, 4096-row tile, fan-out <= 512 -> 156 KiB LDS, 1 workgroup/CU
+// Worker-boundary lines (first/last line of a worker's digit segment) are still partial:
+// 2 per (worker, digit).
+// ---------------------------------------------------------------------------------------------
+constexpr int WC_ITEMS = 4;
+constexpr int WC_LINE = 8;  // rows per 128-byte line
+
+template <int THREADS, int MAXD>
+struct WcSmem {
+  static constexpr int TILE = THREADS * WC_ITEMS;
+  static constexpr int WAVES = THREADS / kWave;
+  static constexpr int ZROWS = WAVES * MAXD * 8 / 16;  // tile rows aliased by the lane masks
+  static constexpr int MAXLINES = TILE / WC_LINE + 2 * MAXD;
+  static_assert(ZROWS <= TILE && ZROWS % THREADS == 0, "lane masks must alias whole row slabs");
+  static_assert(MAXD <= THREADS && MAXD * WC_LINE == TILE, "one digit per thread; carry == tile slots");
+  union {
+    Tup stage[TILE];
+    u64 lanemask[WAVES][MAXD];
+  };
+  Tup carry[MAXD][WC_LINE];
+  u16 wcnt[WAVES][MAXD];
+  u32 tile_off[MAXD];  // start of digit d's new rows inside the staged tile
+  u32 cflush[MAXD];    // global row where digit d's next unflushed row belongs
+  u32 cf_tile[MAXD];   // cflush at the start of this tile
+  u32 plan[MAXD];      // rows to flush this tile << 8 | rows pending from earlier tiles
+  u32 pend[MAXD];      // rows waiting in carry[d]
+  u32 line_off[MAXD];  // first entry of digit d in line_tab
+  u16 line_tab[MAXLINES];  // digit of every 128-byte line this tile completes
+  u32 total_lines;
+  u32 scratch[WAVES + 1];
+};
+
+template <int THREADS, int MAXD, bool HI, bool FULL>
+__global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_scatter_wc_kernel(
+    const Tup* __restrict__ in, Tup* __restrict__ out, u32 n, u32 n_full, int shift, int bits,
+    u32 rows_per_block, u32 worker_base, const u32* __restrict__ hist_scanned,
+    const u32* __restrict__ totals, u32 nblk, u64* __restrict__ offsets_out) {
+  typedef WcSmem<THREADS, MAXD> Smem;
+  constexpr int TILE = Smem::TILE, WAVES = Smem::WAVES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
+  const u32 D = 1u << bits, mask = D - 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 worker = worker_base + blockIdx.x;
+
+  {
+    u32 t = ((u32)tid < D) ? totals[tid] : 0, tot;
+    u32 base = block_excl_scan_u32<THREADS>(t, sm.scratch, &tot);
+    if ((u32)tid < D) {
+      sm.cflush[tid] = base + hist_scanned[(u64)tid * nblk + worker];
+      sm.pend[tid] = 0;
+      if (offsets_out && worker == 0) {
+        offsets_out[tid] = base;
+        if ((u32)tid == D - 1) offsets_out[D] = n;
+      }
+    }
+    for (int i = tid; i < WAVES * MAXD / 2; i += THREADS) reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
+    for (int i = tid; i < WAVES * MAXD; i += THREADS) (&sm.lanemask[0][0])[i] = 0;
+  }
+  __syncthreads();
+
+  u64 begin, end;
+  if (FULL) {
+    begin = (u64)blockIdx.x * rows_per_block;
+    end = begin + rows_per_block;
+    if (end > n_full) end = n_full;
+  } else {
+    begin = n_full;
+    end = n;
+  }
+  if (begin >= end) return;
+
+  u16* wc = &sm.wcnt[w][0];
+  u64* lm = &sm.lanemask[w][0];
+  const u64 lanebit = 1ull << lane;
+  const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
+
+  Tup t[WC_ITEMS];
+#pragma unroll
+  for (int r = 0; r < WC_ITEMS; r++)
+    if (FULL || begin + wbase + r * 64 < end) t[r] = in[begin + wbase + r * 64];
+
+  for (u64 tile = begin; tile < end; tile += TILE) {
+    const u32 tile_n = FULL ? (u32)TILE : (u32)(end - tile);
+    u32 dr[WC_ITEMS];
+#pragma unroll
+    for (int r = 0; r < WC_ITEMS; r++) {
+      u32 d = 0, rank = 0;
+      if (FULL || wbase + r * 64 < tile_n) {
+        d = digit_of<HI>(t[r].key, shift, mask);
+        __hip_atomic_fetch_or(&lm[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u64 m = __hip_atomic_load(&lm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 old = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 below = popc_below(m);
+        if (below == 0) {
+          __hip_atomic_store(&lm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&wc[d], (u16)(old + (u32)__popcll(m)), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        rank = old + below;
+      }
+      dr[r] = (d << 16) | rank;
+    }
+    lds_barrier();
+
+    // per digit: prefix over waves, tile offsets, this tile's flush plan and its 128-byte lines
+    {
+      u32 cnt = 0, nl = 0, pd = 0, cf = 0, fl = 0;
+      if ((u32)tid < D) {
+#pragma unroll
+        for (int k = 0; k < WAVES; k++) {
+          u32 c = sm.wcnt[k][tid];
+          sm.wcnt[k][tid] = (u16)cnt;
+          cnt += c;
+        }
+        pd = sm.pend[tid];
+        cf = sm.cflush[tid];
+        const u32 avail = pd + cnt;
+        const u32 tail = (cf + avail) & (WC_LINE - 1);  // rows past the last whole line
+        fl = (tail >= avail) ? 0u : avail - tail;
+        nl = fl ? (((cf & (WC_LINE - 1)) + fl + WC_LINE - 1) >> 3) : 0u;
+        sm.pend[tid] = avail - fl;
+        sm.cflush[tid] = cf + fl;
+      }
+      u32 tot;
+      const u32 sc = block_excl_scan_u32<THREADS>((nl << 16) | cnt, sm.scratch, &tot);
+      if ((u32)tid < D) {
+        const u32 loff = sc >> 16;
+        sm.tile_off[tid] = sc & 0xFFFFu;
+        sm.cf_tile[tid] = cf;
+        sm.plan[tid] = (fl << 8) | pd;
+        sm.line_off[tid] = loff;
+        for (u32 l = 0; l < nl; l++) sm.line_tab[loff + l] = (u16)tid;
+      }
+      if (tid == 0) sm.total_lines = tot >> 16;
+    }
+    lds_barrier();
+
+#pragma unroll
+    for (int r = 0; r < WC_ITEMS; r++) {
+      if (FULL || wbase + r * 64 < tile_n) {
+        const u32 d = dr[r] >> 16;
+        sm.stage[sm.tile_off[d] + sm.wcnt[w][d] + (dr[r] & 0xFFFFu)] = t[r];
+      }
+    }
+    if (FULL && tile + TILE < end) {
+      const Tup* src = in + tile + TILE;
+#pragma unroll
+      for (int r = 0; r < WC_ITEMS; r++) t[r] = src[wbase + r * 64];
+    }
+    lds_barrier();
+
+    // copy out WHOLE LINES: 8 consecutive lanes own one 128-byte line (carried rows first, then
+    // this tile's rows), so every line leaves in a single store instruction
+    {
+      const u32 TL = sm.total_lines, k = (u32)tid & (WC_LINE - 1);
+      for (u32 L = (u32)tid >> 3; L < TL; L += THREADS / WC_LINE) {
+        const u32 d = sm.line_tab[L];
+        const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu, cfd = sm.cf_tile[d];
+        const u32 grow = (cfd & ~(u32)(WC_LINE - 1)) + (L - sm.line_off[d]) * WC_LINE + k;
+        const u32 j = grow - cfd;  // wraps (huge) for the slots before an unaligned segment start
+        if (j < fl) out[grow] = (j < pd) ? sm.carry[d][j] : sm.stage[sm.tile_off[d] + j - pd];
+      }
+    }
+    // rows that stay behind (each digit's new partial line): stage -> registers
+    u64 keep_k[WC_ITEMS], keep_v[WC_ITEMS];
+    u32 has = 0;
+#pragma unroll
+    for (int q = 0; q < WC_ITEMS; q++) {
+      const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
+      u32 idx = 0;
+      if (d < D && k < sm.pend[d]) {
+        const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu;
+        if (fl != 0 || k >= pd) {
+          idx = sm.tile_off[d] + (fl ? fl - pd + k : k - pd);
+          has |= 1u << q;
+        }
+      }
+      const Tup kv = sm.stage[idx];  // unconditional read (row 0 when nothing stays)
+      keep_k[q] = kv.key;
+      keep_v[q] = kv.val;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < WC_ITEMS; q++) {
+      const u32 s = q * THREADS + tid;
+      if (has & (1u << q)) {
+        Tup kv;
+        kv.key = keep_k[q];
+        kv.val = keep_v[q];
+        sm.carry[s >> 3][s & (WC_LINE - 1)] = kv;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < WC_ITEMS; r++) {
+      if (r * THREADS < Smem::ZROWS) {  // hand the slab back to the lane masks as zeros
+        Tup z;
+        z.key = 0;
+        z.val = 0;
+        sm.stage[r * THREADS + tid] = z;
+      }
+    }
+    for (int i = tid; i < WAVES * MAXD / 2; i += THREADS) reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
+    lds_barrier();
+  }
+
+  // worker done: whatever still waits in the carry buffers ends this worker's digit segments
+#pragma unroll
+  for (int q = 0; q < WC_ITEMS; q++) {
+    const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
+    if (d < D && k < sm.pend[d]) out[sm.cflush[d] + k] = sm.carry[d][k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Partition boundaries of an array sorted by its top `bits` key bits: off[p] = first row whose
 // top bits >= p (binary search; P+1 entries).  bits == 0 -> {0, n}.
 // ---------------------------------------------------------------------------------------------
@@ -286,7 +508,19 @@ __global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int bits,
 // ---------------------------------------------------------------------------------------------
 // Workers: k = ceil(full_tiles / tiles_per_worker) workers own whole tiles; if n is not a multiple
 // of the tile, one more worker owns the ragged tail.  *nblk counts all of them.
-void radix_pass_geometry(u32 n, u32* nblk, u32* rows_per_block) {
+// Kernel choice per pass.  Fan-out <= 16: runs are >= 4 KiB anyway, the plain staged scatter is
+// fastest.  Otherwise the write-combining kernels (WC_X up to 8 bits, WC_Y for 9).
+static inline int scatter_kind(int bits, int variant) {
+  if (variant != 1 || bits <= 4) return 0;
+  return bits <= 8 ? 1 : 2;
+}
+int radix_tile_rows(int bits, int variant) {
+  const int k = scatter_kind(bits, variant);
+  return k == 1 ? 2048 : (k == 2 ? 4096 : RP_TILE);
+}
+
+void radix_pass_geometry(u32 n, int tile, u32* nblk, u32* rows_per_block) {
+  const u64 RP_TILE = (u64)tile;
   u64 full_tiles = (u64)n / RP_TILE;
   u64 tpb = (full_tiles + RP_MAX_BLOCKS - 1) / RP_MAX_BLOCKS;
   if (tpb == 0) tpb = 1;
@@ -298,9 +532,9 @@ void radix_pass_geometry(u32 n, u32* nblk, u32* rows_per_block) {
 
 size_t radix_scatter_smem_bytes() { return sizeof(ScatterSmem); }
 
-hipError_t launch_radix_hist(const void* in, u32 n, int shift, int bits, u32* hist, u32 nblk,
-                             u32 rows_per_block, hipStream_t st) {
-  const u32 n_full = (n / RP_TILE) * RP_TILE;
+hipError_t launch_radix_hist(const void* in, u32 n, int tile, int shift, int bits, u32* hist,
+                             u32 nblk, u32 rows_per_block, hipStream_t st) {
+  const u32 n_full = (n / (u32)tile) * (u32)tile;
   hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(RP_THREADS), 0, st,
                      static_cast<const Tup*>(in), n, shift, (1u << bits) - 1, rows_per_block, n_full,
                      hist, nblk);
@@ -332,9 +566,60 @@ static hipError_t launch_radix_scatter_t(const void* in, void* out, u32 n, u32 n
   return hipGetLastError();
 }
 
-hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int shift, int bits,
+template <int THREADS, int MAXD, bool HI, bool FULL>
+static hipError_t launch_wc_t(const void* in, void* out, u32 n, u32 n_full, int shift, int bits,
+                              u32 rows_per_block, u32 worker_base, u32 grid, const u32* hist_scanned,
+                              const u32* totals, u32 nblk, u64* offsets_out, hipStream_t st) {
+  typedef WcSmem<THREADS, MAXD> Smem;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(radix_scatter_wc_kernel<THREADS, MAXD, HI, FULL>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((radix_scatter_wc_kernel<THREADS, MAXD, HI, FULL>), dim3(grid), dim3(THREADS),
+                     sizeof(Smem), st, static_cast<const Tup*>(in), static_cast<Tup*>(out), n, n_full,
+                     shift, bits, rows_per_block, worker_base, hist_scanned, totals, nblk, offsets_out);
+  return hipGetLastError();
+}
+
+template <int THREADS, int MAXD>
+static hipError_t launch_wc(const void* in, void* out, u32 n, int shift, int bits,
+                            const u32* hist_scanned, const u32* totals, u32 nblk, u32 rows_per_block,
+                            u64* offsets_out, hipStream_t st) {
+  const u32 tile = THREADS * WC_ITEMS, n_full = (n / tile) * tile;
+  const bool tail = n_full != n, hi = shift >= 32;
+  const u32 k = nblk - (tail ? 1 : 0);
+  hipError_t e = hipSuccess;
+  if (n_full) {
+    e = hi ? launch_wc_t<THREADS, MAXD, true, true>(in, out, n, n_full, shift, bits, rows_per_block, 0,
+                                                    k, hist_scanned, totals, nblk, offsets_out, st)
+           : launch_wc_t<THREADS, MAXD, false, true>(in, out, n, n_full, shift, bits, rows_per_block,
+                                                     0, k, hist_scanned, totals, nblk, offsets_out, st);
+    if (e != hipSuccess) return e;
+  }
+  if (tail) {
+    const u32 wb = n_full ? k : 0;
+    e = hi ? launch_wc_t<THREADS, MAXD, true, false>(in, out, n, n_full, shift, bits, rows_per_block,
+                                                     wb, 1, hist_scanned, totals, nblk, offsets_out, st)
+           : launch_wc_t<THREADS, MAXD, false, false>(in, out, n, n_full, shift, bits, rows_per_block,
+                                                      wb, 1, hist_scanned, totals, nblk, offsets_out, st);
+  }
+  return e;
+}
+
+hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, int shift, int bits,
                                 const u32* hist_scanned, const u32* totals, u32 nblk,
                                 u32 rows_per_block, u64* offsets_out, hipStream_t st) {
+  const int kind = scatter_kind(bits, variant);
+  if (kind == 1)
+    return launch_wc<512, 256>(in, out, n, shift, bits, hist_scanned, totals, nblk, rows_per_block,
+                               offsets_out, st);
+  if (kind == 2)
+    return launch_wc<1024, 512>(in, out, n, shift, bits, hist_scanned, totals, nblk, rows_per_block,
+                                offsets_out, st);
   const u32 n_full = (n / RP_TILE) * RP_TILE;
   const bool tail = n_full != n;
   const u32 k = nblk - (tail ? 1 : 0);  // workers owning whole tiles

@@ -72,6 +72,8 @@ class Executor:
             raise HmjError(rc, "%s (%s)" % (self.L.hmj_strerror(rc).decode(), self.L.hmj_last_error(self.h).decode()))
 
     def _sync_stream(self):
+        # run on torch's current stream so the join is ordered after whatever produced its inputs
+        # (handle 0 = the HIP default stream, which hmj_set_stream takes as such)
         if self.use_torch_stream:
             s = self._torch.cuda.current_stream(self.device).cuda_stream
             self._check(self.L.hmj_set_stream(self.h, C.c_void_p(s)))

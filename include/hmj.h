@@ -94,7 +94,11 @@ typedef struct {
 /* Replaces: nothing in the reference (no device); one ctx per GPU. device_id < 0 = current.     */
 int hmj_create(hmj_ctx** out, int device_id);
 void hmj_destroy(hmj_ctx* ctx);
-/* Launch on the caller's HIP stream (hipStream_t passed as void*; NULL = the ctx's own stream). */
+/* Launch on the caller's HIP stream (hipStream_t passed as void*).  NULL is the HIP default (null)
+ * stream, exactly as in the HIP API; HMJ_STREAM_OWN selects the ctx's private non-blocking stream
+ * (the initial setting).  Device inputs must be complete on, or ordered before, the chosen stream:
+ * the private stream does NOT synchronise with work queued on other streams.                      */
+#define HMJ_STREAM_OWN ((void*)(intptr_t)-1)
 int hmj_set_stream(hmj_ctx* ctx, void* hip_stream);
 /* Pre-allocate workspace for joins up to these sizes (so the timed call allocates nothing).     */
 int hmj_reserve(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, uint64_t max_matches,

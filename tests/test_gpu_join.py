@@ -267,3 +267,31 @@ def test_full_size_closed_form(ex, H, log2n):
         assert int(rv.sum().item()) & M64 == (n * (n - 1) // 2) & M64
         assert int(rv.min().item()) == 0 and int(rv.max().item()) == n - 1
     ex.release_result()
+
+
+def test_cpp_dropin_operator():
+    # the C++ HashMergeJoin<RIter,SIter> drop-in (include/hashmergejoin_hip.hpp), built host-only
+    # with g++ against the C ABI, driven exactly like hashjoin_bench.cc:109-143
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "test_dropin")
+    assert os.path.exists(exe), "run `make cpptest`"
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    txt = out.stdout.decode()
+    assert out.returncode == 0 and "all drop-in cases passed" in txt, txt
+
+
+def test_inputs_written_on_the_torch_stream_are_ordered(ex, oracle):
+    # regression: the executor must run on torch's CURRENT stream (handle 0 = HIP default stream);
+    # a private non-blocking stream raced with the kernel that was still writing the relation.
+    import torch
+
+    n, bits = 1 << 22, 9
+    for _ in range(3):
+        i = torch.arange(n, dtype=torch.int64, device="cuda")
+        g = (i // 16) % 256
+        dig = torch.where(i % 16 < 7, 2 * g, 2 * g + 1)
+        R = torch.stack([dig << (64 - bits), i], 1).contiguous()
+        out, off = ex.partition_device(R, 64 - bits, bits)
+        eo, eoff = oracle.stable_partition(R.cpu().numpy().view(np.uint64), 64 - bits, bits)
+        assert np.array_equal(to_np(off), eoff) and np.array_equal(to_np(out), eo)
