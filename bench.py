@@ -89,15 +89,21 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("HMJ_DIST_BACKEND", "nccl")  # "gloo": rehearse N ranks on one GPU
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = 1 << a.log2n           # rows per relation on this GPU
     n_total = n * world        # |R| = |S| of the whole job
-    ex = H.Executor(local_rank)
+    ex = H.Executor(local_dev)
     if a.bits >= 0:
         ex.set_radix_bits(a.bits)
     # synthetic relations generated on device: this rank's row shard [rank*n, (rank+1)*n)
@@ -105,6 +111,8 @@ def main():
     S = ex.gen_probe(n, n_total, start=rank * n)
     flags = H.HMJ_MATERIALIZE if a.materialize else 0
     ex.set_profiling(True)
+    if world > 1:
+        ex.set_key_prefix_bits(hdist.owner_bits(world))  # received rows share their top owner bits
 
     def step():
         if world == 1:
@@ -116,7 +124,7 @@ def main():
             parted, off = ex.partition_device(rel, 64 - b, b)
             rows, _ = hdist.exchange_rows(parted, hdist.split_counts_from_offsets(off))
             recv.append(rows)
-        res = ex.join_device(recv[0], recv[1], flags)
+        res = ex.join_device(recv[0], recv[1], flags)  # ex.set_key_prefix_bits(b) was set below
         return res, ex.last_timing()
 
     for _ in range(a.warmup):
@@ -138,10 +146,11 @@ def main():
     dt = time.perf_counter() - t0
     n_local = int(res.n_matches)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rdev = dev if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        m = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        m = torch.tensor([n_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(m)
         n_matches = int(m.item())
     else:

@@ -71,6 +71,8 @@ def load_library():
     L.hmj_reserve.argtypes = [vp, u, u, u, C.c_uint32]
     L.hmj_set_radix_bits.restype = i
     L.hmj_set_radix_bits.argtypes = [vp, i]
+    L.hmj_set_key_prefix_bits.restype = i
+    L.hmj_set_key_prefix_bits.argtypes = [vp, i]
     L.hmj_plan.restype = i
     L.hmj_plan.argtypes = [u, C.POINTER(i), C.POINTER(i), C.POINTER(i * 4)]
     L.hmj_set_profiling.restype = i

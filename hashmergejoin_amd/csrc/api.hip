@@ -44,6 +44,7 @@ struct hmj_ctx {
       out_key, out_rval, out_sval, offs64, irregular;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int force_bits = -1;
+  int prefix_bits = 0;  // top key bits known to be constant (consumed by an outer split)
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;
   std::vector<hipEvent_t> events;
@@ -212,7 +213,7 @@ int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bit
 }
 
 // all passes of one relation; *result = where the partitioned rows ended up
-int partition_relation(hmj_ctx* c, const void* in, u32 n, DevBuf buf[2], int B, int passes,
+int partition_relation(hmj_ctx* c, const void* in, u32 n, DevBuf buf[2], int top, int passes,
                        const int pass_bits[4], int rel, const void** result) {
   *result = in;
   if (passes == 0 || n == 0) return HMJ_OK;
@@ -220,7 +221,7 @@ int partition_relation(hmj_ctx* c, const void* in, u32 n, DevBuf buf[2], int B, 
   if ((rc = ensure_dev(c, buf[0], (size_t)n * 16)) != HMJ_OK) return rc;
   if (passes > 1 && (rc = ensure_dev(c, buf[1], (size_t)n * 16)) != HMJ_OK) return rc;
   const void* src = in;
-  int shift = 64 - B;
+  int shift = top;  // lowest of the partition bits
   for (int i = 0; i < passes; i++) {
     void* dst = buf[i & 1].p;
     if ((rc = radix_pass(c, src, dst, n, shift, pass_bits[i], rel, nullptr)) != HMJ_OK) return rc;
@@ -277,11 +278,14 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
 
   HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
   const void *Rp, *Sp;
-  if ((rc = partition_relation(c, R, nb, c->rbuf, B, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
-  if ((rc = partition_relation(c, S, np, c->sbuf, B, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
+  int prefix = c->prefix_bits;
+  if (prefix + B > 64) prefix = 64 - B;
+  const int low = 64 - prefix - B;  // partition id = (key >> low) & (P - 1)
+  if ((rc = partition_relation(c, R, nb, c->rbuf, low, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
+  if ((rc = partition_relation(c, S, np, c->sbuf, low, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
   int s = span_begin(c, K_OFFSETS, -1);
-  HIP_TRY(hmj::launch_part_offsets(Rp, nb, B, (u32*)c->r_off.p, c->stream));
-  HIP_TRY(hmj::launch_part_offsets(Sp, np, B, (u32*)c->s_off.p, c->stream));
+  HIP_TRY(hmj::launch_part_offsets(Rp, nb, low, B, (u32*)c->r_off.p, c->stream));
+  HIP_TRY(hmj::launch_part_offsets(Sp, np, low, B, (u32*)c->s_off.p, c->stream));
   span_end(c, s);
 
   hmj::ProbeArgs a;
@@ -304,11 +308,12 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
     u32* n_irr = (u32*)c->irregular.p;
     u32* irr = n_irr + 1;
     HIP_TRY(hipMemsetAsync(n_irr, 0, 4, c->stream));
-    HIP_TRY(hmj::launch_probe_count_fast(a, irr, n_irr, c->num_cus * 3 * 4, c->stream));
+    const bool big = ((u64)nb >> B) > 2300;  // average build partition beyond the 2560-row pipeline
+    HIP_TRY(hmj::launch_probe_count_fast(a, irr, n_irr, big, c->num_cus, c->stream));
     hmj::ProbeArgs a2 = a;
     a2.item_list = irr;
     a2.n_item_list = n_irr;
-    HIP_TRY(hmj::launch_probe(a2, 0, false, false, c->num_cus * 2, c->stream));
+    HIP_TRY(hmj::launch_probe(a2, 0, false, false, c->num_cus, c->stream));
   } else {
     HIP_TRY(hmj::launch_probe(a, materialize ? 1 : 0, first, extra, grid, c->stream));
   }
@@ -431,6 +436,12 @@ int hmj_set_stream(hmj_ctx* c, void* hip_stream) {
 int hmj_set_radix_bits(hmj_ctx* c, int total_bits) {
   if (!c || total_bits > 27) return HMJ_E_ARG;
   c->force_bits = total_bits < 0 ? -1 : total_bits;
+  return HMJ_OK;
+}
+
+int hmj_set_key_prefix_bits(hmj_ctx* c, int bits) {
+  if (!c || bits < 0 || bits > 32) return HMJ_E_ARG;
+  c->prefix_bits = bits;
   return HMJ_OK;
 }
 

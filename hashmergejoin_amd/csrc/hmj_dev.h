@@ -27,10 +27,13 @@ constexpr int RP_MAXD = 1 << RP_MAX_BITS;
 constexpr int RP_MAX_BLOCKS = 2048;              // "workers" (reference: threads) per pass
 
 // ---- build+probe geometry (probe.hip) ------------------------------------------------------
-constexpr int PB_THREADS = 512;
-constexpr int PB_CAP = 3072;          // build rows resident in LDS per chunk
-constexpr int PB_LOG_NB = 12;         // 4096 chain heads
-constexpr int PB_TARGET_AVG = 2048;   // planner: average build rows per partition
+constexpr int PB_THREADS = 1024;       // generic kernel: 106 KiB LDS -> one 16-wave workgroup per CU
+constexpr int PB_CAP = 5120;           // build rows resident in LDS per chunk
+constexpr int PB_LOG_NB = 12;          // 4096 chain heads
+constexpr int PB_TARGET_AVG = 4096;    // planner: average build rows per partition
+// Measured at |R|=|S|=2^28 (tools/exp_bits.py): 16 bits (avg 4096 rows/partition, two 8-bit
+// write-combining passes) 12.45 ms per join vs 17 bits (avg 2048, 9+8) 13.02 ms, 18 bits 13.9 ms,
+// 15 bits 14.6 ms: fewer, larger partitions win as long as one still fits the LDS table.
 constexpr int OR_CAP = 4096;          // rows per partition the ordered epilogue sorts in LDS
 
 // accumulator slots (global u64[8])

@@ -19,7 +19,7 @@ hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipS
 hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, int shift, int bits,
                                 const u32* hist_scanned, const u32* totals, u32 nblk,
                                 u32 rows_per_block, u64* offsets_out, hipStream_t st);
-hipError_t launch_part_offsets(const void* a, u32 n, int bits, u32* off, hipStream_t st);
+hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st);
 
 // probe.hip
 struct ProbeArgs {
@@ -43,8 +43,8 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
                         hipStream_t st);
 int probe_default_grid(int num_cus);
 // count-mode fast path (Q == 1, no flags); partitions it cannot take go to irregular[]
-hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
-                                   hipStream_t st);
+hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
+                                   int num_cus, hipStream_t st);
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
 hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rval, u64* sval, u64* accum,
                         int grid, hipStream_t st);

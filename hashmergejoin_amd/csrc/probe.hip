@@ -35,7 +35,7 @@ __device__ __forceinline__ u32 tab_hash(u64 k) {
 // MODE 0: count + sums.  MODE 1: also per-partition match counts.  MODE 2: write result columns.
 // FIRST: HMJ_FIRST_WINS.  EXTRA: HMJ_CHECKSUM / HMJ_SUM_PROBE accumulators.
 template <int MODE, bool FIRST, bool EXTRA>
-__global__ __launch_bounds__(PB_THREADS, 4) void probe_kernel(ProbeArgs a) {
+__global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ProbeSmem& sm = *reinterpret_cast<ProbeSmem*>(smem_raw);
   const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
@@ -233,39 +233,44 @@ __global__ __launch_bounds__(PB_THREADS, 4) void probe_kernel(ProbeArgs a) {
 // Partitions that do not fit the register pipeline (more than FP_CAP build or probe rows: skew)
 // are appended to `irregular` and joined afterwards by the generic kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int FP_ROWS = 5;                       // rows per thread per side
-constexpr int FP_CAP = PB_THREADS * FP_ROWS;     // 2560
-constexpr int FP_LOG_NB = 11;
-constexpr u32 FP_NB = 1u << FP_LOG_NB;
+constexpr int FP_ROWS = 5;  // rows per thread per side
 
+template <int THREADS, int LOG_NB>
 struct FastSmem {
-  u64 key[FP_CAP];
-  u64 val[FP_CAP];
-  u32 head[FP_NB];  // epoch << 16 | row
-  u16 next[FP_CAP];
+  static constexpr int CAP = THREADS * FP_ROWS;
+  u64 key[CAP];
+  u64 val[CAP];
+  u32 head[1u << LOG_NB];  // epoch << 16 | row
+  u16 next[CAP];
 };
 
+template <int LOG_NB>
 __device__ __forceinline__ u32 fast_hash(u64 k) {
   u32 x = (u32)k ^ ((u32)(k >> 32) * 0x85EBCA6Bu);
   x *= 0x9E3779B1u;
-  return x >> (32 - FP_LOG_NB);
+  return x >> (32 - LOG_NB);
 }
 
+template <int THREADS>
 __device__ __forceinline__ void fp_load(Tup (&t)[FP_ROWS], const Tup* __restrict__ base, u32 n,
                                         int tid) {
   // unpredicated loads (index clamped into the partition) so all five issue back to back
 #pragma unroll
   for (int k = 0; k < FP_ROWS; k++) {
-    u32 i = k * PB_THREADS + tid;
+    u32 i = k * THREADS + tid;
     t[k] = base[i < n ? i : n - 1];
   }
 }
 
-__global__ __launch_bounds__(PB_THREADS, 6) void probe_count_fast_kernel(ProbeArgs a,
-                                                                          u32* __restrict__ irregular,
-                                                                          u32* __restrict__ n_irregular) {
+// <512, 11>: partitions up to 2560 rows, 53 KiB LDS, 3 workgroups/CU (the planner's default size)
+// <1024, 12>: partitions up to 5120 rows, 106 KiB LDS, 1 workgroup/CU
+template <int THREADS, int LOG_NB>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_fast_kernel(
+    ProbeArgs a, u32* __restrict__ irregular, u32* __restrict__ n_irregular) {
+  typedef FastSmem<THREADS, LOG_NB> Smem;
+  constexpr u32 CAP = Smem::CAP, NB = 1u << LOG_NB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  FastSmem& sm = *reinterpret_cast<FastSmem*>(smem_raw);
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
   const Tup* __restrict__ S = static_cast<const Tup*>(a.S);
   const u32* __restrict__ r_off = a.r_off;
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(PB_THREADS, 6) void probe_count_fast_kernel(ProbeAr
   const u32 P = a.P;
   const int tid = threadIdx.x, lane = tid & 63;
   u64 acc_n = 0, acc_r = 0, acc_s = 0;
-  for (u32 i = tid; i < FP_NB; i += PB_THREADS) sm.head[i] = 0;
+  for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
   u32 epoch = 0;
 
   u32 p = blockIdx.x;
@@ -283,8 +288,8 @@ __global__ __launch_bounds__(PB_THREADS, 6) void probe_count_fast_kernel(ProbeAr
   if (p < P) {
     rb = r_off[p]; nb = r_off[p + 1] - rb;
     sb = s_off[p]; np = s_off[p + 1] - sb;
-    regular = nb && np && nb <= FP_CAP && np <= FP_CAP;
-    if (regular) fp_load(br, R + rb, nb, tid);
+    regular = nb && np && nb <= CAP && np <= CAP;
+    if (regular) fp_load<THREADS>(br, R + rb, nb, tid);
   }
   while (p < P) {
     const u32 pn = __builtin_amdgcn_readfirstlane(p + gridDim.x);  // keep the offsets on the scalar path
@@ -293,36 +298,36 @@ __global__ __launch_bounds__(PB_THREADS, 6) void probe_count_fast_kernel(ProbeAr
     if (pn < P) {
       rb2 = r_off[pn]; nb2 = r_off[pn + 1] - rb2;
       sb2 = s_off[pn]; np2 = s_off[pn + 1] - sb2;
-      regular2 = nb2 && np2 && nb2 <= FP_CAP && np2 <= FP_CAP;
+      regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
     }
     if (regular) {
-      fp_load(pr, S + sb, np, tid);   // probe rows: in flight while the table is built
+      fp_load<THREADS>(pr, S + sb, np, tid);   // probe rows: in flight while the table is built
       lds_barrier();                   // everyone is done probing the previous table
       epoch++;
       if (epoch == 0x10000u) {         // 16-bit epoch wrapped: clear once
-        for (u32 i = tid; i < FP_NB; i += PB_THREADS) sm.head[i] = 0;
+        for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
         epoch = 1;
         lds_barrier();
       }
       const u32 tag = epoch << 16;
 #pragma unroll
       for (int k = 0; k < FP_ROWS; k++) {
-        const u32 i = k * PB_THREADS + tid;
+        const u32 i = k * THREADS + tid;
         if (i < nb) {
           sm.key[i] = br[k].key;
           sm.val[i] = br[k].val;
-          const u32 old = atomicExch(&sm.head[fast_hash(br[k].key)], tag | i);
+          const u32 old = atomicExch(&sm.head[fast_hash<LOG_NB>(br[k].key)], tag | i);
           sm.next[i] = ((old >> 16) == epoch) ? (u16)old : (u16)NIL;
         }
       }
-      if (regular2) fp_load(br, R + rb2, nb2, tid);  // next partition's build rows
+      if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);  // next partition's build rows
       lds_barrier();                                  // table complete
 #pragma unroll
       for (int k = 0; k < FP_ROWS; k++) {
-        const u32 j = k * PB_THREADS + tid;
+        const u32 j = k * THREADS + tid;
         if (j < np) {
           const u64 key = pr[k].key;
-          const u32 hv = sm.head[fast_hash(key)];
+          const u32 hv = sm.head[fast_hash<LOG_NB>(key)];
           u32 i = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
           while (i != NIL) {
             if (sm.key[i] == key) {
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(PB_THREADS, 6) void probe_count_fast_kernel(ProbeAr
       }
     } else {
       if (tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
-      if (regular2) fp_load(br, R + rb2, nb2, tid);
+      if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);
     }
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
   }
@@ -476,21 +481,30 @@ static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
-                                   hipStream_t st) {
+template <int THREADS, int LOG_NB>
+static hipError_t launch_fast_t(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
+                                hipStream_t st) {
+  typedef FastSmem<THREADS, LOG_NB> Smem;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(probe_count_fast_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(FastSmem));
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(probe_count_fast_kernel, dim3(grid), dim3(PB_THREADS), sizeof(FastSmem), st, a,
-                     irregular, n_irregular);
+  hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB>), dim3(grid), dim3(THREADS),
+                     sizeof(Smem), st, a, irregular, n_irregular);
   return hipGetLastError();
+}
+
+// big == false: partitions of <= 2560 rows (3 workgroups/CU); big == true: <= 5120 rows (1/CU)
+hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
+                                   int num_cus, hipStream_t st) {
+  if (big) return launch_fast_t<1024, 12>(a, irregular, n_irregular, num_cus * 1 * 4, st);
+  return launch_fast_t<512, 11>(a, irregular, n_irregular, num_cus * 3 * 4, st);
 }
 
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
@@ -515,7 +529,7 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
 #undef HMJ_DISPATCH
 }
 
-int probe_default_grid(int num_cus) { return num_cus * 2 * 4; }
+int probe_default_grid(int num_cus) { return num_cus * 4; }
 
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st) {
   hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, in, out_excl, n);

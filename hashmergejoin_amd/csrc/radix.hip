@@ -479,10 +479,10 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 }
 
 // ---------------------------------------------------------------------------------------------
-// Partition boundaries of an array sorted by its top `bits` key bits: off[p] = first row whose
-// top bits >= p (binary search; P+1 entries).  bits == 0 -> {0, n}.
+// Partition boundaries of an array sorted by partition id = (key >> low) & (2^bits - 1):
+// off[p] = first row whose id >= p (binary search; P+1 entries).  bits == 0 -> {0, n}.
 // ---------------------------------------------------------------------------------------------
-__global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int bits,
+__global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int low, int bits,
                                     u32* __restrict__ off, u32 P) {
   u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > P) return;
@@ -491,11 +491,10 @@ __global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int bits,
     return;
   }
   const u64* keys = reinterpret_cast<const u64*>(a);
-  const int sh = 64 - bits;
   u32 lo = 0, hi = n;
   while (lo < hi) {
     u32 mid = lo + ((hi - lo) >> 1);
-    if ((u32)(keys[2 * (u64)mid] >> sh) < p)
+    if (((u32)(keys[2 * (u64)mid] >> low) & (P - 1)) < p)
       lo = mid + 1;
     else
       hi = mid;
@@ -642,10 +641,10 @@ hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, i
   return e;
 }
 
-hipError_t launch_part_offsets(const void* a, u32 n, int bits, u32* off, hipStream_t st) {
+hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st) {
   u32 P = 1u << bits;
   hipLaunchKernelGGL(part_offsets_kernel, dim3((P + 1 + 255) / 256), dim3(256), 0, st,
-                     static_cast<const Tup*>(a), n, bits, off, P);
+                     static_cast<const Tup*>(a), n, low, bits, off, P);
   return hipGetLastError();
 }
 

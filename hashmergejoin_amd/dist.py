@@ -31,6 +31,11 @@ def exchange_rows(parted, send_counts, group=None):
     tensors (RCCL)."""
     world = dist.get_world_size(group)
     assert len(send_counts) == world and sum(send_counts) == parted.shape[0]
+    if parted.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices):
+        # stage through host memory.  The production path is RCCL on device tensors, below.
+        rows, rc = exchange_rows(parted.cpu(), send_counts, group)
+        return rows.to(parted.device), rc
     sc = torch.tensor(send_counts, dtype=torch.int64, device=parted.device)
     rc = torch.empty(world, dtype=torch.int64, device=parted.device)
     dist.all_to_all_single(rc, sc, group=group)
@@ -56,6 +61,8 @@ def allreduce_checks(local, device, group=None):
     for k in keys:
         v = local[k] & ((1 << 64) - 1)
         halves += [v & 0xFFFFFFFF, v >> 32]
+    if dist.get_backend(group) == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor(halves, dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     h = t.tolist()
@@ -85,5 +92,9 @@ def distributed_join(ex, r_shard, s_shard, flags=0, group=None):
         parted, off = ex.partition_device(rel, 64 - b, b)
         rows, _ = exchange_rows(parted, split_counts_from_offsets(off), group)
         recv.append(rows)
-    res = ex.join_device(recv[0], recv[1], flags)
+    ex.set_key_prefix_bits(b)  # every row received here carries this rank's owner bits on top
+    try:
+        res = ex.join_device(recv[0], recv[1], flags)
+    finally:
+        ex.set_key_prefix_bits(0)
     return res, allreduce_checks(res.checks(), r_shard.device, group)

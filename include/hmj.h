@@ -106,6 +106,10 @@ int hmj_reserve(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, uint64_t max_m
 /* Override the planner (the reference's optimal_partition heuristic, radix_hash.h:38-57, is tuned
  * for CPU caches; ours targets LDS capacity).  total_bits < 0 restores automatic planning.       */
 int hmj_set_radix_bits(hmj_ctx* ctx, int total_bits);
+/* Tell the executor that the top `bits` key bits are equal in all rows of both relations (an outer
+ * radix split already consumed them, e.g. the multi-GPU owner split): partitioning then starts
+ * below them, as the reference's recursion masks off consumed bits (radix_hash.h:219-220).       */
+int hmj_set_key_prefix_bits(hmj_ctx* ctx, int bits);
 /* The automatic plan for a build side of n_build rows: total bits and per-pass bits (LSD order).*/
 int hmj_plan(uint64_t n_build, int* total_bits, int* n_passes, int pass_bits[4]);
 int hmj_set_profiling(hmj_ctx* ctx, int enabled);

@@ -44,15 +44,15 @@ def test_no_gpu_means_loud_failure_not_fallback():
 def test_planner():
     import hashmergejoin_amd as H
 
-    # average build partition <= 2048 rows (LDS table of probe.hip), <= 9 bits per LSD pass
+    # average build partition <= 4096 rows (LDS table of probe.hip), <= 9 bits per LSD pass
     assert H.plan(0) == (0, [])
-    assert H.plan(2048) == (0, [])
-    assert H.plan(2049) == (1, [1])
-    assert H.plan(10 ** 6) == (9, [9])
-    assert H.plan(1 << 26) == (15, [8, 7])
-    assert H.plan(1 << 28) == (17, [9, 8])
+    assert H.plan(4096) == (0, [])
+    assert H.plan(4097) == (1, [1])
+    assert H.plan(10 ** 6) == (8, [8])
+    assert H.plan(1 << 26) == (14, [7, 7])
+    assert H.plan(1 << 28) == (16, [8, 8])
     tb, pb = H.plan(1 << 31)
-    assert tb == 20 and sum(pb) == 20 and max(pb) <= 9
+    assert tb == 19 and sum(pb) == 19 and max(pb) <= 9
 
 
 def test_product_never_imports_the_oracle():

@@ -295,3 +295,28 @@ def test_inputs_written_on_the_torch_stream_are_ordered(ex, oracle):
         out, off = ex.partition_device(R, 64 - bits, bits)
         eo, eoff = oracle.stable_partition(R.cpu().numpy().view(np.uint64), 64 - bits, bits)
         assert np.array_equal(to_np(off), eoff) and np.array_equal(to_np(out), eo)
+
+
+def test_key_prefix_bits_after_an_outer_split(ex, H, oracle):
+    # after the multi-GPU owner split every row on a rank shares its top log2(G) key bits; the local
+    # join must partition BELOW them (else 2^b x too few effective partitions -> chunked slow path)
+    nb, npb, b = 300000, 250000, 3
+    B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=5)
+    top = np.uint64(5) << np.uint64(61)
+    low = np.uint64((1 << 61) - 1)
+    B[:, 0] = (B[:, 0] & low) | top
+    P[:, 0] = (P[:, 0] & low) | top
+    ck, rows = oracle.equijoin(B, P)
+    ex.set_key_prefix_bits(b)
+    try:
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+        assert r.checks() == ck and np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), 0)
+        assert int(r.n_matches) == ck["n_matches"]
+    finally:
+        ex.set_key_prefix_bits(0)
+        ex.set_profiling(False)
+    # without the hint the result is still right (partitioning is any function of the key)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
+    assert r.checks() == ck
