@@ -44,7 +44,8 @@ class Timing(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhmj_hip.so")
+    # HMJ_LIB: developer override to A/B an alternative build of the same library
+    return os.environ.get("HMJ_LIB") or os.path.join(_HERE, "libhmj_hip.so")
 
 
 _LIB = None

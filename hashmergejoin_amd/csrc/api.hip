@@ -297,6 +297,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   a.P = P;
   a.Q = Q;
   a.accum = (u64*)c->accum.p;
+  if (const char* e = getenv("HMJ_DEBUG_ABLATE")) a.debug = (u32)atoi(e);
   a.part_count = (u64*)c->part_count.p;
   a.part_out_off = (const u64*)c->part_out_off.p;
   const int grid = hmj::probe_default_grid(c->num_cus);

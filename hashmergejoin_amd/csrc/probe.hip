@@ -234,6 +234,9 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
 // are appended to `irregular` and joined afterwards by the generic kernel.
 // ---------------------------------------------------------------------------------------------
 constexpr int FP_ROWS = 5;  // rows per thread per side
+#ifndef BIG_LOG_NB
+#define BIG_LOG_NB 13
+#endif
 
 template <int THREADS, int LOG_NB>
 struct FastSmem {
@@ -281,15 +284,21 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
   for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
   u32 epoch = 0;
 
+  // Pipeline (per workgroup, partitions p, p+G, p+2G, ...): when partition p is processed its build
+  // rows (br) AND probe rows (pr) are already in registers; the probe rows of the next partition
+  // (pq) are requested before p's table is built, its build rows right after p's rows went to LDS.
   u32 p = blockIdx.x;
   u32 rb = 0, nb = 0, sb = 0, np = 0;
   bool regular = false;
-  Tup br[FP_ROWS], pr[FP_ROWS];
+  Tup br[FP_ROWS], pr[FP_ROWS], pq[FP_ROWS];
   if (p < P) {
     rb = r_off[p]; nb = r_off[p + 1] - rb;
     sb = s_off[p]; np = s_off[p + 1] - sb;
     regular = nb && np && nb <= CAP && np <= CAP;
-    if (regular) fp_load<THREADS>(br, R + rb, nb, tid);
+    if (regular) {
+      fp_load<THREADS>(br, R + rb, nb, tid);
+      fp_load<THREADS>(pr, S + sb, np, tid);
+    }
   }
   while (p < P) {
     const u32 pn = __builtin_amdgcn_readfirstlane(p + gridDim.x);  // keep the offsets on the scalar path
@@ -300,8 +309,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
       sb2 = s_off[pn]; np2 = s_off[pn + 1] - sb2;
       regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
     }
+    if (regular2) fp_load<THREADS>(pq, S + sb2, np2, tid);  // next partition's probe rows
     if (regular) {
-      fp_load<THREADS>(pr, S + sb, np, tid);   // probe rows: in flight while the table is built
       lds_barrier();                   // everyone is done probing the previous table
       epoch++;
       if (epoch == 0x10000u) {         // 16-bit epoch wrapped: clear once
@@ -310,39 +319,71 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
         lds_barrier();
       }
       const u32 tag = epoch << 16;
+      if (!(a.debug & 1u)) {
+        // build: the five exchanges are independent -> issue them together, then link
+        u32 old[FP_ROWS];
 #pragma unroll
-      for (int k = 0; k < FP_ROWS; k++) {
-        const u32 i = k * THREADS + tid;
-        if (i < nb) {
-          sm.key[i] = br[k].key;
-          sm.val[i] = br[k].val;
-          const u32 old = atomicExch(&sm.head[fast_hash<LOG_NB>(br[k].key)], tag | i);
-          sm.next[i] = ((old >> 16) == epoch) ? (u16)old : (u16)NIL;
-        }
-      }
-      if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);  // next partition's build rows
-      lds_barrier();                                  // table complete
-#pragma unroll
-      for (int k = 0; k < FP_ROWS; k++) {
-        const u32 j = k * THREADS + tid;
-        if (j < np) {
-          const u64 key = pr[k].key;
-          const u32 hv = sm.head[fast_hash<LOG_NB>(key)];
-          u32 i = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
-          while (i != NIL) {
-            if (sm.key[i] == key) {
-              acc_n++;
-              acc_r += sm.val[i];
-              acc_s += pr[k].val;
-            }
-            i = sm.next[i];
+        for (int k = 0; k < FP_ROWS; k++) {
+          const u32 i = k * THREADS + tid;
+          old[k] = tag | NIL;
+          if (i < nb) {
+            sm.key[i] = br[k].key;
+            sm.val[i] = br[k].val;
+            old[k] = atomicExch(&sm.head[fast_hash<LOG_NB>(br[k].key)], tag | i);
           }
         }
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          const u32 i = k * THREADS + tid;
+          if (i < nb) sm.next[i] = ((old[k] >> 16) == epoch) ? (u16)old[k] : (u16)NIL;
+        }
+      } else {  // dev-only ablation (HMJ_DEBUG_ABLATE=1): stream the rows, no LDS work
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) acc_r += br[k].key;
+      }
+      if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);  // next partition's build rows
+      lds_barrier();                                          // table complete
+      if (!(a.debug & 1u)) {
+        // probe: walk the five chains in lockstep so their LDS latencies overlap
+        u32 cur[FP_ROWS];
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          const u32 j = k * THREADS + tid;
+          cur[k] = NIL;
+          if (j < np) {
+            const u32 hv = sm.head[fast_hash<LOG_NB>(pr[k].key)];
+            cur[k] = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
+          }
+        }
+        for (; !(a.debug & 2u);) {
+          bool any = false;
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) any |= (cur[k] != NIL);
+          if (!__any(any)) break;
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            if (cur[k] != NIL) {
+              const u32 i = cur[k];
+              const u64 kk = sm.key[i], vv = sm.val[i];  // val read unconditionally: one LDS
+              cur[k] = sm.next[i];                       // round trip per chain step, not two
+              if (kk == pr[k].key) {
+                acc_n++;
+                acc_r += vv;
+                acc_s += pr[k].val;
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) acc_r += pr[k].key;
       }
     } else {
       if (tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
       if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);
     }
+#pragma unroll
+    for (int k = 0; k < FP_ROWS; k++) pr[k] = pq[k];
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
   }
   acc_n = wave_sum_u64(acc_n);
@@ -503,7 +544,7 @@ static hipError_t launch_fast_t(const ProbeArgs& a, u32* irregular, u32* n_irreg
 // big == false: partitions of <= 2560 rows (3 workgroups/CU); big == true: <= 5120 rows (1/CU)
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
                                    int num_cus, hipStream_t st) {
-  if (big) return launch_fast_t<1024, 12>(a, irregular, n_irregular, num_cus * 1 * 4, st);
+  if (big) return launch_fast_t<1024, BIG_LOG_NB>(a, irregular, n_irregular, num_cus * 1 * 4, st);
   return launch_fast_t<512, 11>(a, irregular, n_irregular, num_cus * 3 * 4, st);
 }
 

@@ -13,7 +13,7 @@ for bits in [int(x) for x in sys.argv[2:]] or [16, 17, 18]:
     best = None
     for _ in range(4):
         r = ex.join_device(R, S, 0)
-        assert int(r.n_matches) == n
+        assert int(r.n_matches) == n or os.environ.get('HMJ_DEBUG_ABLATE')
         t = ex.last_timing()
         if best is None or t["ms_total"] < best["ms_total"]:
             best = t
