@@ -84,6 +84,7 @@ def main():
     from hashmergejoin_amd import dist as hdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    force_dist = os.environ.get("HMJ_FORCE_DIST") == "1"  # dev: run the exchange path with 1 rank
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
@@ -94,8 +95,11 @@ def main():
     local_dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -115,13 +119,15 @@ def main():
         ex.set_key_prefix_bits(hdist.owner_bits(world))  # received rows share their top owner bits
 
     def step():
-        if world == 1:
+        if world == 1 and not force_dist:
             res = ex.join_device(R, S, flags)
             return res, ex.last_timing()
-        b = hdist.owner_bits(world)
+        b = max(hdist.owner_bits(world), 1 if force_dist else 0)
         recv = []
         for rel in (R, S):
             parted, off = ex.partition_device(rel, 64 - b, b)
+            if force_dist:  # one rank: everything is sent to self, as one message
+                off = off[[0, -1]]
             rows, _ = hdist.exchange_rows(parted, hdist.split_counts_from_offsets(off))
             recv.append(rows)
         res = ex.join_device(recv[0], recv[1], flags)  # ex.set_key_prefix_bits(b) was set below
@@ -193,7 +199,7 @@ def main():
                        "rows_per_relation_per_gpu": n, "rows_per_relation_total": n_total,
                        "parallelism": "radix-sharded x%d" % world},
             "roofline": dict(roof(sc_bytes, sc_ms, traffic), kernel="radix_scatter_kernel",
-                             launches_per_step=launches // K),
+                             launches_per_step=launches // K, kernel_name="radix_scatter_wc_kernel (write-combining stable scatter)"),
             "roofline_probe": dict(roof(pr_bytes, pr_ms), kernel="probe_kernel<count>",
                                    probe_tuples_per_s=round(n / (pr_ms * 1e-3)) if pr_ms > 0 else None),
             "phases_ms_per_step": {k[3:]: round(v / K, 4) for k, v in agg.items() if k.startswith("ms_")},

@@ -24,6 +24,7 @@ struct ProbeSmem {
   u16 next[PB_CAP];
   u32 scratch[PB_THREADS / kWave + 1];
   u64 pcount;
+  u64 red[8];
 };
 
 __device__ __forceinline__ u32 tab_hash(u64 k) {
@@ -202,24 +203,11 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
   }
 
   if (MODE != 2) {
-    acc_n = wave_sum_u64(acc_n);
-    acc_r = wave_sum_u64(acc_r);
-    acc_s = wave_sum_u64(acc_s);
-    if (EXTRA) {
-      acc_x = wave_xor_u64(acc_x);
-      acc_m = wave_sum_u64(acc_m);
-      acc_p = wave_sum_u64(acc_p);
-    }
-    if (lane == 0) {
-      if (acc_n) atomicAdd(&a.accum[ACC_N], acc_n);
-      if (acc_r) atomicAdd(&a.accum[ACC_SUM_R], acc_r);
-      if (acc_s) atomicAdd(&a.accum[ACC_SUM_S], acc_s);
-      if (EXTRA) {
-        if (acc_x) atomicXor(&a.accum[ACC_XOR], acc_x);
-        if (acc_m) atomicAdd(&a.accum[ACC_MIX], acc_m);
-        if (acc_p) atomicAdd(&a.accum[ACC_SUM_P], acc_p);
-      }
-    }
+    __syncthreads();
+    if (tid < 8) sm.red[tid] = 0;
+    __syncthreads();
+    const u64 v[6] = {acc_n, acc_r, acc_s, acc_x, acc_m, acc_p};  // ACC_N .. ACC_SUM_P order
+    block_accumulate(sm.red, a.accum, v, 1u << ACC_XOR);
   }
   if (err && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_FIRST_WINS_OVERFLOW);
 }
@@ -245,6 +233,7 @@ struct FastSmem {
   u64 val[CAP];
   u32 head[1u << LOG_NB];  // epoch << 16 | row
   u16 next[CAP];
+  u64 red[8];
 };
 
 template <int LOG_NB>
@@ -279,7 +268,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
   const u32* __restrict__ r_off = a.r_off;
   const u32* __restrict__ s_off = a.s_off;
   const u32 P = a.P;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   u64 acc_n = 0, acc_r = 0, acc_s = 0;
   for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
   u32 epoch = 0;
@@ -386,14 +375,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
     for (int k = 0; k < FP_ROWS; k++) pr[k] = pq[k];
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
   }
-  acc_n = wave_sum_u64(acc_n);
-  acc_r = wave_sum_u64(acc_r);
-  acc_s = wave_sum_u64(acc_s);
-  if (lane == 0) {
-    if (acc_n) atomicAdd(&a.accum[ACC_N], acc_n);
-    if (acc_r) atomicAdd(&a.accum[ACC_SUM_R], acc_r);
-    if (acc_s) atomicAdd(&a.accum[ACC_SUM_S], acc_s);
-  }
+  lds_barrier();
+  if (tid < 8) sm.red[tid] = 0;
+  lds_barrier();
+  const u64 v[6] = {acc_n, acc_r, acc_s, 0, 0, 0};
+  block_accumulate(sm.red, a.accum, v, 0u);
 }
 
 // Exclusive scan of n u64 counts into n+1 offsets (single workgroup; n = partition count).
