@@ -303,18 +303,19 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   const int grid = hmj::probe_default_grid(c->num_cus);
 
   s = span_begin(c, K_PROBE_COUNT, -1);
-  if (!materialize && !first && !extra && Q == 1 && P >= 2) {
-    // headline path: pipelined count kernel, then the generic kernel over what it set aside
+  if (!first && !extra && Q == 1 && P >= 2) {
+    // pipelined count kernel (with per-partition counts when materialising), then the generic
+    // kernel over the partitions it set aside
     if ((rc = ensure_dev(c, c->irregular, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
     u32* n_irr = (u32*)c->irregular.p;
     u32* irr = n_irr + 1;
     HIP_TRY(hipMemsetAsync(n_irr, 0, 4, c->stream));
     const bool big = ((u64)nb >> B) > 2300;  // average build partition beyond the 2560-row pipeline
-    HIP_TRY(hmj::launch_probe_count_fast(a, irr, n_irr, big, c->num_cus, c->stream));
+    HIP_TRY(hmj::launch_probe_count_fast(a, irr, n_irr, big, materialize, c->num_cus, c->stream));
     hmj::ProbeArgs a2 = a;
     a2.item_list = irr;
     a2.n_item_list = n_irr;
-    HIP_TRY(hmj::launch_probe(a2, 0, false, false, c->num_cus, c->stream));
+    HIP_TRY(hmj::launch_probe(a2, materialize ? 1 : 0, false, false, c->num_cus, c->stream));
   } else {
     HIP_TRY(hmj::launch_probe(a, materialize ? 1 : 0, first, extra, grid, c->stream));
   }

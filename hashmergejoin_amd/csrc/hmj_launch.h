@@ -45,7 +45,7 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
 int probe_default_grid(int num_cus);
 // count-mode fast path (Q == 1, no flags); partitions it cannot take go to irregular[]
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
-                                   int num_cus, hipStream_t st);
+                                   bool per_partition_counts, int num_cus, hipStream_t st);
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
 hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rval, u64* sval, u64* accum,
                         int grid, hipStream_t st);

@@ -234,6 +234,7 @@ struct FastSmem {
   u32 head[1u << LOG_NB];  // epoch << 16 | row
   u16 next[CAP];
   u64 red[8];
+  u32 itemcnt[2];  // per-partition match count, double-buffered by partition parity
 };
 
 template <int LOG_NB>
@@ -256,7 +257,8 @@ __device__ __forceinline__ void fp_load(Tup (&t)[FP_ROWS], const Tup* __restrict
 
 // <512, 11>: partitions up to 2560 rows, 53 KiB LDS, 3 workgroups/CU (the planner's default size)
 // <1024, 12>: partitions up to 5120 rows, 106 KiB LDS, 1 workgroup/CU
-template <int THREADS, int LOG_NB>
+// PCOUNT: also store each partition's match count in a.part_count[p] (first pass of materialising).
+template <int THREADS, int LOG_NB, bool PCOUNT>
 __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_fast_kernel(
     ProbeArgs a, u32* __restrict__ irregular, u32* __restrict__ n_irregular) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
@@ -271,7 +273,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
   const int tid = threadIdx.x;
   u64 acc_n = 0, acc_r = 0, acc_s = 0;
   for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
+  if (tid < 2) sm.itemcnt[tid] = 0;
   u32 epoch = 0;
+  u32 prev_p = 0xFFFFFFFFu, parity = 0;  // PCOUNT: partition whose count still sits in itemcnt[parity^1]
 
   // Pipeline (per workgroup, partitions p, p+G, p+2G, ...): when partition p is processed its build
   // rows (br) AND probe rows (pr) are already in registers; the probe rows of the next partition
@@ -301,6 +305,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
     if (regular2) fp_load<THREADS>(pq, S + sb2, np2, tid);  // next partition's probe rows
     if (regular) {
       lds_barrier();                   // everyone is done probing the previous table
+      if (PCOUNT && prev_p != 0xFFFFFFFFu && tid == 0) {  // its count is complete now
+        a.part_count[prev_p] = sm.itemcnt[parity ^ 1];
+        sm.itemcnt[parity ^ 1] = 0;
+      }
+      if (PCOUNT) prev_p = 0xFFFFFFFFu;
       epoch++;
       if (epoch == 0x10000u) {         // 16-bit epoch wrapped: clear once
         for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
       }
       if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);  // next partition's build rows
       lds_barrier();                                          // table complete
+      const u64 n_before = acc_n;
       if (!(a.debug & 1u)) {
         // probe: walk the five chains in lockstep so their LDS latencies overlap
         u32 cur[FP_ROWS];
@@ -367,7 +377,15 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) acc_r += pr[k].key;
       }
+      if (PCOUNT) {
+        const u32 mine = (u32)(acc_n - n_before);
+        const u32 ws = (u32)wave_sum_u64(mine);
+        if ((tid & 63) == 0 && ws) atomicAdd(&sm.itemcnt[parity], ws);
+        prev_p = p;
+        parity ^= 1;
+      }
     } else {
+      if (PCOUNT && tid == 0 && !(nb && np)) a.part_count[p] = 0;  // empty side: no rows
       if (tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
       if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);
     }
@@ -376,6 +394,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
   }
   lds_barrier();
+  if (PCOUNT && prev_p != 0xFFFFFFFFu && tid == 0) a.part_count[prev_p] = sm.itemcnt[parity ^ 1];
   if (tid < 8) sm.red[tid] = 0;
   lds_barrier();
   const u64 v[6] = {acc_n, acc_r, acc_s, 0, 0, 0};
@@ -508,30 +527,34 @@ static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int THREADS, int LOG_NB>
+template <int THREADS, int LOG_NB, bool PCOUNT>
 static hipError_t launch_fast_t(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
                                 hipStream_t st) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB>),
+        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB>), dim3(grid), dim3(THREADS),
+  hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT>), dim3(grid), dim3(THREADS),
                      sizeof(Smem), st, a, irregular, n_irregular);
   return hipGetLastError();
 }
 
 // big == false: partitions of <= 2560 rows (3 workgroups/CU); big == true: <= 5120 rows (1/CU)
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
-                                   int num_cus, hipStream_t st) {
-  if (big) return launch_fast_t<1024, BIG_LOG_NB>(a, irregular, n_irregular, num_cus * 1 * 4, st);
-  return launch_fast_t<512, 11>(a, irregular, n_irregular, num_cus * 3 * 4, st);
+                                   bool per_partition_counts, int num_cus, hipStream_t st) {
+  if (per_partition_counts) {
+    if (big) return launch_fast_t<1024, BIG_LOG_NB, true>(a, irregular, n_irregular, num_cus * 4, st);
+    return launch_fast_t<512, 11, true>(a, irregular, n_irregular, num_cus * 3 * 4, st);
+  }
+  if (big) return launch_fast_t<1024, BIG_LOG_NB, false>(a, irregular, n_irregular, num_cus * 4, st);
+  return launch_fast_t<512, 11, false>(a, irregular, n_irregular, num_cus * 3 * 4, st);
 }
 
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
