@@ -41,7 +41,7 @@ struct hmj_ctx {
   int device = 0, num_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
-      out_key, out_rval, out_sval, offs64, irregular;
+      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int force_bits = -1;
   int prefix_bits = 0;  // top key bits known to be constant (consumed by an outer split)
@@ -352,11 +352,18 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
     HIP_TRY(hmj::launch_probe(a, 2, first, false, grid, c->stream));
     span_end(c, s);
     c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
-    if (flags & HMJ_ORDERED) {
+    if (flags & HMJ_ORDERED) {  // out of place: unsorted columns -> sorted columns
+      if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
       s = span_begin(c, K_ORDER, -1);
-      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, P, Q, a.out_key, a.out_rval,
-                                a.out_sval, a.accum, c->num_cus * 2, c->stream));
+      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, P, Q, low, a.out_key, a.out_rval,
+                                a.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
+                                (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
       span_end(c, s);
+      a.out_key = (u64*)c->ord_key.p;
+      a.out_rval = (u64*)c->ord_rval.p;
+      a.out_sval = (u64*)c->ord_sval.p;
     }
     if (to_host) {
       if ((rc = ensure_host(c, c->h_key, bytes)) != HMJ_OK) return rc;
@@ -419,7 +426,7 @@ void hmj_destroy(hmj_ctx* c) {
   DevBuf* devs[] = {&c->rbuf[0], &c->rbuf[1], &c->sbuf[0], &c->sbuf[1], &c->in_r, &c->in_s,
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
-                    &c->offs64, &c->irregular};
+                    &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);
@@ -563,6 +570,9 @@ void hmj_release_result(hmj_ctx* c) {
   free_dev(c->out_key);
   free_dev(c->out_rval);
   free_dev(c->out_sval);
+  free_dev(c->ord_key);
+  free_dev(c->ord_rval);
+  free_dev(c->ord_sval);
   free_host(c->h_key);
   free_host(c->h_rval);
   free_host(c->h_sval);

@@ -34,7 +34,6 @@ constexpr int PB_TARGET_AVG = 4096;    // planner: average build rows per partit
 // Measured at |R|=|S|=2^28 (tools/exp_bits.py): 16 bits (avg 4096 rows/partition, two 8-bit
 // write-combining passes) 12.45 ms per join vs 17 bits (avg 2048, 9+8) 13.02 ms, 18 bits 13.9 ms,
 // 15 bits 14.6 ms: fewer, larger partitions win as long as one still fits the LDS table.
-constexpr int OR_CAP = 4096;          // rows per partition the ordered epilogue sorts in LDS
 
 // accumulator slots (global u64[8])
 enum { ACC_N = 0, ACC_SUM_R, ACC_SUM_S, ACC_XOR, ACC_MIX, ACC_SUM_P, ACC_ERR, ACC_PAD };

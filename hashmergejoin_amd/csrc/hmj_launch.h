@@ -47,7 +47,8 @@ int probe_default_grid(int num_cus);
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
                                    bool per_partition_counts, int num_cus, hipStream_t st);
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
-hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rval, u64* sval, u64* accum,
+hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, int low, const u64* akey,
+                        const u64* arval, const u64* asval, u64* bkey, u64* brval, u64* bsval,
                         int grid, hipStream_t st);
 
 // gen.hip

@@ -434,28 +434,37 @@ __global__ __launch_bounds__(1024) void scan_u64_kernel(const u64* __restrict__ 
   if (tid == 0) out[n] = carry_s;
 }
 
-// HMJ_ORDERED epilogue: sort each partition's result rows by (key, rval, sval) with a bitonic
-// network.  Partitions are key ranges in ascending order (partitioning uses the most significant
-// key bits, radix_hash.h:369), so sorted partitions concatenate to the ascending-key order
-// HashMergeJoin iteration has (hashjoin.h:86-101).
-// The network is the "all ascending" form (first stage of each merge pairs mirrored positions), so
-// rows beyond the segment behave as +infinity and a pair reaching past the end is skipped: no
-// padding.  Segments up to OR_CAP rows are sorted in LDS; longer ones (probe side much larger than
-// the build side, or duplicate-heavy keys) run the same network on the global columns.
+// HMJ_ORDERED epilogue: sort each partition's result rows by (key, rval, sval).  Partitions are
+// key ranges in ascending order (partitioning uses the most significant key bits, radix_hash.h:369),
+// so sorted partitions concatenate to the ascending-key order HashMergeJoin iteration has
+// (hashjoin.h:86-101).
+//
+// Fast path (segments of <= OS_CAP rows): one bucket pass on the 12 key bits just below the
+// partition bits (4096 buckets for ~4096 rows: about one row per bucket for the uniform keys the
+// planner assumes), then every row ranks itself inside its bucket by comparing with the few rows
+// that share it; rows are staged through LDS column by column and leave as coalesced stores into
+// the second set of result columns.  Out of place: A (unsorted) -> B (sorted).
+// Slow path (longer segments, or a bucket with more than OS_MAXBUCKET rows: duplicate-heavy keys):
+// copy A -> B, then a bitonic network on the global columns ("all ascending" form, no padding).
+constexpr int OS_THREADS = 1024, OS_ROWS = 5, OS_CAP = OS_THREADS * OS_ROWS, OS_LOGB = 12;
+constexpr int OS_NB = 1 << OS_LOGB, OS_MAXBUCKET = 48;
+
 struct OrderSmem {
-  u64 k[OR_CAP];
-  u64 r[OR_CAP];
-  u64 s[OR_CAP];
+  u64 stage[OS_CAP];  // keys while ranking, then one column at a time while copying out
+  u16 sidx[OS_CAP];   // row indices grouped by bucket
+  u32 bstart[OS_NB + 1];
+  u32 bcur[OS_NB];
+  u32 scratch[OS_THREADS / kWave + 1];
+  u32 fallback;
 };
 
-template <typename A>
-__device__ __forceinline__ void order_network(A k, A r, A s, u32 L, int tid) {
+__device__ __forceinline__ void order_network_global(u64* k, u64* r, u64* s, u32 L, int tid) {
   u32 n2 = 2;
   while (n2 < L) n2 <<= 1;
   for (u32 size = 2; size <= n2; size <<= 1) {
     for (u32 j = size >> 1; j > 0; j >>= 1) {
       const bool mirror = (j == (size >> 1));
-      for (u32 t = tid; t < (n2 >> 1); t += 512) {
+      for (u32 t = tid; t < (n2 >> 1); t += OS_THREADS) {
         u32 i, l;
         if (mirror) {
           u32 blk = t / j, idx = t % j;
@@ -480,33 +489,122 @@ __device__ __forceinline__ void order_network(A k, A r, A s, u32 L, int tid) {
   }
 }
 
-__global__ __launch_bounds__(512, 2) void order_kernel(const u64* __restrict__ off, u32 P, u32 Q,
-                                                       u64* key, u64* rval, u64* sval) {
+__global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
+    const u64* __restrict__ off, u32 P, u32 Q, int low, const u64* __restrict__ akey,
+    const u64* __restrict__ arval, const u64* __restrict__ asval, u64* __restrict__ bkey,
+    u64* __restrict__ brval, u64* __restrict__ bsval) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   OrderSmem& sm = *reinterpret_cast<OrderSmem*>(smem_raw);
   const int tid = threadIdx.x;
+  const int bsh = low - OS_LOGB;  // bucket = key bits [low-12, low)
   for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
     const u64 b = off[(u64)p * Q], L64 = off[((u64)p + 1) * Q] - b;
-    if (L64 < 2) continue;
-    if (L64 > OR_CAP) {
-      if (L64 > 0x7FFFFFFFull) continue;  // cannot happen: n_matches per partition < 2^31 rows
+    if (L64 == 0) continue;
+    bool slow = (L64 > OS_CAP) || (bsh < 0);
+    const u32 L = slow ? 0u : (u32)L64;
+    u64 key[OS_ROWS], rv[OS_ROWS], sv[OS_ROWS];
+    u32 bk[OS_ROWS], dest[OS_ROWS];
+    if (!slow) {
       __syncthreads();
-      order_network<u64*>(key + b, rval + b, sval + b, (u32)L64, tid);
+      for (u32 i = tid; i <= (u32)OS_NB; i += OS_THREADS) sm.bstart[i] = 0;
+      if (tid == 0) sm.fallback = 0;
+#pragma unroll
+      for (int k = 0; k < OS_ROWS; k++) {
+        const u32 i = k * OS_THREADS + tid;
+        if (i < L) {
+          key[k] = akey[b + i];
+          rv[k] = arval[b + i];
+          sv[k] = asval[b + i];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < OS_ROWS; k++) {
+        const u32 i = k * OS_THREADS + tid;
+        if (i < L) {
+          bk[k] = (u32)(key[k] >> bsh) & (OS_NB - 1);
+          sm.stage[i] = key[k];
+          atomicAdd(&sm.bstart[bk[k]], 1u);
+        }
+      }
+      __syncthreads();
+      {  // exclusive scan of the 4096 bucket counts, 4 per thread
+        u32 c[4], sum = 0, mx = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          c[q] = sm.bstart[tid * 4 + q];
+          sum += c[q];
+          mx = c[q] > mx ? c[q] : mx;
+        }
+        if (mx > OS_MAXBUCKET) sm.fallback = 1;
+        u32 tot;
+        u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          sm.bstart[tid * 4 + q] = ex;
+          sm.bcur[tid * 4 + q] = ex;
+          ex += c[q];
+        }
+        if (tid == 0) sm.bstart[OS_NB] = L;
+      }
+      __syncthreads();
+      slow = sm.fallback != 0;
+    }
+    if (slow) {  // uniform for the workgroup
+      const u64 n = L64;
+      for (u64 i = tid; i < n; i += OS_THREADS) {
+        bkey[b + i] = akey[b + i];
+        brval[b + i] = arval[b + i];
+        bsval[b + i] = asval[b + i];
+      }
+      __syncthreads();
+      if (n >= 2 && n <= 0x7FFFFFFFull) order_network_global(bkey + b, brval + b, bsval + b, (u32)n, tid);
       continue;
     }
-    const u32 L = (u32)L64;
-    __syncthreads();
-    for (u32 i = tid; i < L; i += 512) {
-      sm.k[i] = key[b + i];
-      sm.r[i] = rval[b + i];
-      sm.s[i] = sval[b + i];
+#pragma unroll
+    for (int k = 0; k < OS_ROWS; k++) {
+      const u32 i = k * OS_THREADS + tid;
+      if (i < L) sm.sidx[atomicAdd(&sm.bcur[bk[k]], 1u)] = (u16)i;
     }
     __syncthreads();
-    order_network<u64*>(sm.k, sm.r, sm.s, L, tid);
-    for (u32 i = tid; i < L; i += 512) {
-      key[b + i] = sm.k[i];
-      rval[b + i] = sm.r[i];
-      sval[b + i] = sm.s[i];
+#pragma unroll
+    for (int k = 0; k < OS_ROWS; k++) {
+      const u32 i = k * OS_THREADS + tid;
+      dest[k] = 0;
+      if (i < L) {
+        const u32 s0 = sm.bstart[bk[k]], e0 = sm.bstart[bk[k] + 1];
+        u32 rank = 0;
+        for (u32 j = s0; j < e0; j++) {
+          const u32 o = sm.sidx[j];
+          if (o == i) continue;
+          const u64 ok = sm.stage[o];
+          bool less = ok < key[k];
+          if (ok == key[k]) {  // duplicate key: order by (rval, sval), then by position
+            const u64 orv = arval[b + o], osv = asval[b + o];
+            less = (orv != rv[k]) ? (orv < rv[k]) : (osv != sv[k]) ? (osv < sv[k]) : (o < i);
+          }
+          rank += less ? 1u : 0u;
+        }
+        dest[k] = s0 + rank;
+      }
+    }
+    __syncthreads();
+    // stage each column in sorted order, copy out coalesced
+#pragma unroll
+    for (int col = 0; col < 3; col++) {
+#pragma unroll
+      for (int k = 0; k < OS_ROWS; k++) {
+        const u32 i = k * OS_THREADS + tid;
+        if (i < L) sm.stage[dest[k]] = (col == 0) ? key[k] : (col == 1) ? rv[k] : sv[k];
+      }
+      __syncthreads();
+      u64* outc = (col == 0) ? bkey : (col == 1) ? brval : bsval;
+#pragma unroll
+      for (int k = 0; k < OS_ROWS; k++) {
+        const u32 i = k * OS_THREADS + tid;
+        if (i < L) outc[b + i] = sm.stage[i];
+      }
+      __syncthreads();
     }
   }
 }
@@ -586,7 +684,8 @@ hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st) 
   return hipGetLastError();
 }
 
-hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rval, u64* sval, u64* accum,
+hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, int low, const u64* akey,
+                        const u64* arval, const u64* asval, u64* bkey, u64* brval, u64* bsval,
                         int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -598,8 +697,8 @@ hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, u64* key, u64* rv
   }
   if ((u32)grid > P) grid = (int)P;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(512), sizeof(OrderSmem), st, part_out_off, P, Q,
-                     key, rval, sval);
+  hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off,
+                     P, Q, low, akey, arval, asval, bkey, brval, bsval);
   return hipGetLastError();
 }
 
