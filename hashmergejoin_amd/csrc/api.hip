@@ -41,7 +41,7 @@ struct hmj_ctx {
   int device = 0, num_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
-      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular;
+      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int force_bits = -1;
   int prefix_bits = 0;  // top key bits known to be constant (consumed by an outer split)
@@ -301,6 +301,12 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   a.part_count = (u64*)c->part_count.p;
   a.part_out_off = (const u64*)c->part_out_off.p;
   const int grid = hmj::probe_default_grid(c->num_cus);
+  const size_t matched_bytes = ((size_t)np / 32 + 1) * 4;
+  if (first) {  // bitmap of probe rows already paired (used when a build partition needs chunks)
+    if ((rc = ensure_dev(c, c->matched, matched_bytes)) != HMJ_OK) return rc;
+    a.matched = (u32*)c->matched.p;
+    HIP_TRY(hipMemsetAsync(c->matched.p, 0, matched_bytes, c->stream));
+  }
 
   s = span_begin(c, K_PROBE_COUNT, -1);
   if (!first && !extra && Q == 1 && P >= 2) {
@@ -330,9 +336,6 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   u64* h = (u64*)c->h_accum.p;
   HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (h[hmj::ACC_ERR] & hmj::ERR_FIRST_WINS_OVERFLOW)
-    return fail(c, HMJ_E_UNSUPPORTED,
-                "HMJ_FIRST_WINS: a build partition exceeds the LDS table (skewed build side)");
   out->n_matches = h[hmj::ACC_N];
   out->sum_r = h[hmj::ACC_SUM_R];
   out->sum_s = h[hmj::ACC_SUM_S];
@@ -348,6 +351,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
     a.out_key = (u64*)c->out_key.p;
     a.out_rval = (u64*)c->out_rval.p;
     a.out_sval = (u64*)c->out_sval.p;
+    if (first) HIP_TRY(hipMemsetAsync(c->matched.p, 0, matched_bytes, c->stream));
     s = span_begin(c, K_PROBE_WRITE, -1);
     HIP_TRY(hmj::launch_probe(a, 2, first, false, grid, c->stream));
     span_end(c, s);
@@ -426,7 +430,7 @@ void hmj_destroy(hmj_ctx* c) {
   DevBuf* devs[] = {&c->rbuf[0], &c->rbuf[1], &c->sbuf[0], &c->sbuf[1], &c->in_r, &c->in_s,
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
-                    &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval};
+                    &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);

@@ -37,6 +37,7 @@ struct ProbeArgs {
   u64* accum;              // 8 x u64, see hmj_dev.h ACC_*
   const u32* item_list;    // optional: process only these items (set aside by the fast kernel)
   const u32* n_item_list;  //           their count (device)
+  u32* matched;            // HMJ_FIRST_WINS + chunked build: one bit per probe row already paired
   u32 debug;               // dev-only ablation bits (HMJ_DEBUG_ABLATE env): 1 = loads only, 2 = no probe walk
 };
 // mode: 0 = count/sums only, 1 = count + per-partition counts, 2 = write

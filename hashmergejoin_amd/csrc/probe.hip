@@ -33,6 +33,19 @@ __device__ __forceinline__ u32 tab_hash(u64 k) {
   return x >> (32 - PB_LOG_NB);
 }
 
+// HMJ_FIRST_WINS when the build partition is processed in several chunks: chunks follow input order,
+// so the first chunk that holds a probe row's key holds its first build row; the row is then marked
+// in a bitmap (one bit per probe row) and skipped in later chunks.  Only the thread that owns the
+// row ever tests or sets its bit; the load bypasses L1 because the earlier atomic went to L2.
+__device__ __forceinline__ bool first_claim(u32* matched, bool multi, u32 row) {
+  if (!multi) return true;
+  u32* w = matched + (row >> 5);
+  const u32 bit = 1u << (row & 31);
+  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) return false;
+  atomicOr(w, bit);
+  return true;
+}
+
 // MODE 0: count + sums.  MODE 1: also per-partition match counts.  MODE 2: write result columns.
 // FIRST: HMJ_FIRST_WINS.  EXTRA: HMJ_CHECKSUM / HMJ_SUM_PROBE accumulators.
 template <int MODE, bool FIRST, bool EXTRA>
@@ -44,7 +57,6 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
   const int tid = threadIdx.x, lane = tid & 63;
 
   u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
-  bool err = false;
   if (MODE == 1 && tid == 0) sm.pcount = 0;
 
   // either all P*Q items, or (after the fast kernel) just the partitions it set aside
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
       if (MODE == 1 && tid == 0) a.part_count[w] = 0;
       continue;
     }
-    if (FIRST && nb > PB_CAP) err = true;
+    const bool multi = FIRST && nb > PB_CAP;  // first-wins across chunks: remember paired probe rows
     u64 pc = 0;                                   // this thread's matches in partition p
     u64 run = (MODE == 2) ? a.part_out_off[w] : 0;  // next output row of this item
 
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
                 }
                 i = sm.next[i];
               }
-              if (FIRST && best != NIL) {
+              if (FIRST && best != NIL && first_claim(a.matched, multi, sb + j)) {
                 const u64 rval = sm.val[best];
                 pc++;
                 acc_r += rval;
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
               }
               i = sm.next[i];
             }
-            if (FIRST) m = (first != NIL) ? 1u : 0u;
+            if (FIRST) m = (first != NIL && first_claim(a.matched, multi, sb + j)) ? 1u : 0u;
           }
           u32 tot;
           const u32 off = block_excl_scan_u32<PB_THREADS>(m, sm.scratch, &tot);
@@ -209,7 +221,6 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
     const u64 v[6] = {acc_n, acc_r, acc_s, acc_x, acc_m, acc_p};  // ACC_N .. ACC_SUM_P order
     block_accumulate(sm.red, a.accum, v, 1u << ACC_XOR);
   }
-  if (err && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_FIRST_WINS_OVERFLOW);
 }
 
 // ---------------------------------------------------------------------------------------------

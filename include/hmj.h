@@ -39,7 +39,7 @@ typedef struct hmj_ctx hmj_ctx;
 #define HMJ_E_NODEV (-2)       /* no usable HIP device */
 #define HMJ_E_OOM (-3)         /* device or pinned-host allocation failed */
 #define HMJ_E_HIP (-4)         /* HIP runtime error, see hmj_last_error() */
-#define HMJ_E_UNSUPPORTED (-5) /* flag combination not supported for this input (see flags) */
+#define HMJ_E_UNSUPPORTED (-5) /* reserved: flag combination not supported for this input      */
 
 /* flags for hmj_join_* */
 #define HMJ_MATERIALIZE 0x01u /* produce the (key, rval, sval) columns; else count/sums only --   */

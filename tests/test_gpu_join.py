@@ -214,6 +214,18 @@ def test_skewed_build_side(ex, H, oracle):
     assert int(r.n_matches) == ck["n_matches"]
     got = ex.columns_to_numpy(r, host=False)
     assert oracle.checks_of_triples(got) == ck
+    # first insert wins across LDS-sized build chunks (bitmap of already-paired probe rows)
+    ckf, rowsf = oracle.equijoin(B, P, first_wins=True)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_FIRST_WINS | H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    assert r.checks() == ckf and np.array_equal(ex.columns_to_numpy(r, host=False), rowsf)
+    ex.set_radix_bits(2)  # force every build partition through many chunks
+    try:
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM)
+        assert r.checks() == ckf
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_FIRST_WINS | H.HMJ_MATERIALIZE)
+        assert np.array_equal(sorted_rows(ex.columns_to_numpy(r, host=False)), rowsf)
+    finally:
+        ex.set_radix_bits(None)
 
 
 def test_python_operator_mirror(ex, H, oracle):
@@ -320,3 +332,49 @@ def test_key_prefix_bits_after_an_outer_split(ex, H, oracle):
     # without the hint the result is still right (partitioning is any function of the key)
     r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
     assert r.checks() == ck
+
+
+def _zipf_thresholds(domain, theta=0.9):
+    w = 1.0 / np.arange(1, domain + 1, dtype=np.float64) ** theta
+    cdf = np.cumsum(w) / w.sum()
+    thr = np.empty(domain, np.uint64)
+    big = cdf >= 1.0 - 2.0 ** -53
+    thr[~big] = (cdf[~big] * 2.0 ** 64).astype(np.uint64)
+    thr[big] = np.uint64(M64)
+    thr[-1] = np.uint64(M64)
+    return thr
+
+
+@pytest.mark.parametrize("log2b,log2p,log2dom", [(18, 22, 18), (24, 30, 24)])
+def test_skewed_build_side_config5(ex, H, oracle, log2b, log2p, log2dom):
+    # BASELINE configs[4]: Zipf(0.9) build side (heavy duplicate keys -> build partitions far beyond
+    # the LDS table -> chunked chained path), uniform probe over the same domain.  The small case is
+    # checked against the CPU oracle; both cases through the symmetry of the relational join:
+    # |R join S| == |S join R| with the payload sums swapped -- the swapped run puts the skew on the
+    # PROBE side and the 64-fold duplicates on the build side, i.e. different kernels and paths.
+    import torch
+
+    nb, npb, dom = 1 << log2b, 1 << log2p, 1 << log2dom
+    thr = _zipf_thresholds(dom)
+    thr_d = torch.from_numpy(thr.view(np.int64).copy()).cuda()
+    R = ex.gen_from_cdf(nb, thr_d)
+    S = ex.gen_uniform_domain(npb, dom)
+    a = ex.join_device(R, S, 0)
+    b = ex.join_device(S, R, 0)
+    assert int(a.n_matches) == int(b.n_matches) > 0
+    assert (int(a.sum_r), int(a.sum_s)) == (int(b.sum_s), int(b.sum_r))
+    fw = ex.join_device(R, S, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE) if log2b <= 20 else None
+    if log2b <= 20:
+        Rn, Sn = to_np(R), to_np(S)
+        assert np.array_equal(Rn, oracle.gen_from_cdf(nb, thr)) and np.array_equal(Sn, oracle.gen_uniform_domain(npb, dom))
+        ck, _ = oracle.equijoin(Rn, Sn, cap=0)
+        assert (int(a.n_matches), int(a.sum_r), int(a.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"])
+        ckf, _ = oracle.equijoin(Rn, Sn, first_wins=True, cap=0)
+        assert (int(fw.n_matches), int(fw.sum_r), int(fw.sum_s)) == (ckf["n_matches"], ckf["sum_r"], ckf["sum_s"])
+        # hashjoin_bench.cc:92-96 sum (first insert wins, miss -> 0) from the restated reference loop
+        psum, found = oracle.partitioned_join_sum(Sn, Rn, 10)
+        # (`found` is not comparable here: operator[] inserts a 0 on a miss, so a repeated missing probe
+        #  key is 'found' from its second lookup on; the sum is unaffected)
+        assert (int(fw.sum_probe_all) + int(fw.sum_r)) & M64 == psum and found >= int(fw.n_matches)
+    ex.release_result()
+    del R, S
