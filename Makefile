@@ -7,7 +7,7 @@ CSRC     := hashmergejoin_amd/csrc
 OBJS     := $(CSRC)/radix.o $(CSRC)/probe.o $(CSRC)/gen.o $(CSRC)/api.o
 LIB      := hashmergejoin_amd/libhmj_hip.so
 
-all: $(LIB) oracle cpptest
+all: $(LIB) oracle cpptest examples/hashjoin_bench_hip
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/hmj_dev.h $(CSRC)/hmj_launch.h include/hmj.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -23,6 +23,10 @@ cpptest: tests/cpp/test_dropin
 tests/cpp/test_dropin: tests/cpp/test_dropin.cc include/hashmergejoin_hip.hpp include/hmj.h $(LIB) oracle
 	g++ -std=c++11 -O2 -Wall -Iinclude -Ioracle $< -o $@ -Lhashmergejoin_amd -lhmj_hip -Loracle -lhmj_oracle \
 	  -Wl,-rpath,'$$ORIGIN/../../hashmergejoin_amd' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,/opt/rocm/lib -pthread
+
+examples/hashjoin_bench_hip: examples/hashjoin_bench_hip.cc include/hashmergejoin_hip.hpp include/hmj.h $(LIB)
+	g++ -std=c++11 -O2 -Wall -Iinclude $< -o $@ -Lhashmergejoin_amd -lhmj_hip \
+	  -Wl,-rpath,'$$ORIGIN/../hashmergejoin_amd' -Wl,-rpath,/opt/rocm/lib -pthread
 
 clean:
 	rm -f $(OBJS) $(LIB) tests/cpp/test_dropin

@@ -90,6 +90,12 @@ def load_library():
     L.hmj_join_u64_device.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult)]
     L.hmj_join_u64.restype = i
     L.hmj_join_u64.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult)]
+    L.hmj_join_u64_rows.restype = i
+    L.hmj_join_u64_rows.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult), C.POINTER(vp)]
+    L.hmj_rows_free.restype = None
+    L.hmj_rows_free.argtypes = [vp]
+    L.hmj_set_host_threads.restype = i
+    L.hmj_set_host_threads.argtypes = [vp, i]
     L.hmj_release_result.restype = None
     L.hmj_release_result.argtypes = [vp]
     L.hmj_partition_u64_device.restype = i

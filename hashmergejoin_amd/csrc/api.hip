@@ -5,8 +5,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hmj.h"
@@ -43,6 +46,10 @@ struct hmj_ctx {
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
       out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched;
   HostBuf h_accum, h_key, h_rval, h_sval;
+  int host_threads = 0;  // staging threads for pageable input (0 = default)
+  std::vector<hipStream_t> up_streams;
+  std::vector<hipEvent_t> up_events;  // 2 per staging thread
+  std::vector<HostBuf> up_slots;      // 2 per staging thread
   int force_bits = -1;
   int prefix_bits = 0;  // top key bits known to be constant (consumed by an outer split)
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
@@ -94,13 +101,36 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
   return HMJ_OK;
 }
 
+// Pinned host memory is expensive to create (page pinning), so released buffers go to a process-wide
+// pool and are handed out again (smallest fit within 2x).
+std::mutex g_pool_mu;
+std::vector<HostBuf> g_pool;
+
+void pool_give(HostBuf& b) {
+  if (!b.p) return;
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  g_pool.push_back(b);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+bool pool_take(size_t bytes, HostBuf* out) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  int best = -1;
+  for (int i = 0; i < (int)g_pool.size(); i++)
+    if (g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + (1u << 20) &&
+        (best < 0 || g_pool[i].cap < g_pool[best].cap))
+      best = i;
+  if (best < 0) return false;
+  *out = g_pool[best];
+  g_pool.erase(g_pool.begin() + best);
+  return true;
+}
+
 int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes) {
   if (bytes <= b.cap) return HMJ_OK;
-  if (b.p) {
-    (void)hipHostFree(b.p);
-    b.p = nullptr;
-    b.cap = 0;
-  }
+  pool_give(b);
+  if (pool_take(bytes, &b)) return HMJ_OK;
   size_t want = bytes + (bytes >> 4) + 256;
   hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -117,11 +147,7 @@ void free_dev(DevBuf& b) {
   b.p = nullptr;
   b.cap = 0;
 }
-void free_host(HostBuf& b) {
-  if (b.p) (void)hipHostFree(b.p);
-  b.p = nullptr;
-  b.cap = 0;
-}
+void free_host(HostBuf& b) { pool_give(b); }
 
 // ---- profiling spans ---------------------------------------------------------------------------
 int span_begin(hmj_ctx* c, int kind, int rel) {
@@ -229,6 +255,63 @@ int partition_relation(hmj_ctx* c, const void* in, u32 n, DevBuf buf[2], int top
     src = dst;
   }
   *result = src;
+  return HMJ_OK;
+}
+
+// Pageable host memory -> device.  hipMemcpy from pageable memory is staged by the runtime through
+// one thread; here T host threads each copy their chunks into their own pinned double buffer and
+// push them over PCIe on their own stream, so the copy is PCIe-bound instead of memcpy-bound.
+constexpr size_t kUpChunk = 8u << 20;
+
+int upload_host(hmj_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
+  if (bytes == 0) return HMJ_OK;
+  int T = c->host_threads > 0 ? c->host_threads : (int)std::thread::hardware_concurrency();
+  if (c->host_threads <= 0 && T > 8) T = 8;
+  const size_t nchunks = (bytes + kUpChunk - 1) / kUpChunk;
+  if (T > (int)nchunks) T = (int)nchunks;
+  if (T <= 1 || bytes < 4 * kUpChunk) {
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    return HMJ_OK;
+  }
+  while ((int)c->up_streams.size() < T) {
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->up_streams.push_back(st);
+    for (int k = 0; k < 2; k++) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      c->up_events.push_back(ev);
+      HostBuf hb;
+      int rc = ensure_host(c, hb, kUpChunk);
+      if (rc != HMJ_OK) return rc;
+      c->up_slots.push_back(hb);
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));  // dst may still be read by earlier work on the ctx stream
+  std::vector<int> status(T, 0);
+  std::vector<std::thread> th;
+  const int dev = c->device;
+  for (int t = 0; t < T; t++) {
+    th.emplace_back([=, &status]() {
+      if (hipSetDevice(dev) != hipSuccess) { status[t] = 1; return; }
+      hipStream_t st = c->up_streams[t];
+      size_t it = 0;
+      for (size_t ci = t; ci < nchunks; ci += T, it++) {
+        const int slot = (int)(it & 1);
+        hipEvent_t ev = c->up_events[2 * t + slot];
+        char* pin = static_cast<char*>(c->up_slots[2 * t + slot].p);
+        if (it >= 2 && hipEventSynchronize(ev) != hipSuccess) { status[t] = 1; return; }
+        const size_t off = ci * kUpChunk, len = (bytes - off < kUpChunk) ? bytes - off : kUpChunk;
+        std::memcpy(pin, static_cast<const char*>(src_host) + off, len);
+        if (hipMemcpyAsync(static_cast<char*>(dst_dev) + off, pin, len, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipEventRecord(ev, st) != hipSuccess) { status[t] = 1; return; }
+      }
+      if (hipStreamSynchronize(st) != hipSuccess) status[t] = 1;
+    });
+  }
+  for (auto& x : th) x.join();
+  for (int t = 0; t < T; t++)
+    if (status[t]) return fail(c, HMJ_E_HIP, "staged host-to-device copy failed");
   return HMJ_OK;
 }
 
@@ -436,6 +519,9 @@ void hmj_destroy(hmj_ctx* c) {
   for (HostBuf* b : hosts) free_host(*b);
   for (auto& e : c->events)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->up_events) (void)hipEventDestroy(e);
+  for (auto& st : c->up_streams) (void)hipStreamDestroy(st);
+  for (auto& b : c->up_slots) free_host(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -540,8 +626,9 @@ int hmj_join_u64_device(hmj_ctx* c, const void* build_aos_dev, uint64_t n_build,
   return rc;
 }
 
-int hmj_join_u64(hmj_ctx* c, const void* build_aos_host, uint64_t n_build,
-                 const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out) {
+static int join_host_impl(hmj_ctx* c, const void* build_aos_host, uint64_t n_build,
+                          const void* probe_aos_host, uint64_t n_probe, uint32_t flags,
+                          hmj_result* out) {
   if (!c) return HMJ_E_ARG;
   if (n_build > 0xFFFFFFFFull || n_probe > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "too many rows");
   if ((n_build && !build_aos_host) || (n_probe && !probe_aos_host))
@@ -551,20 +638,64 @@ int hmj_join_u64(hmj_ctx* c, const void* build_aos_host, uint64_t n_build,
   int rc;
   if ((rc = ensure_dev(c, c->in_r, n_build * 16 + 16)) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->in_s, n_probe * 16 + 16)) != HMJ_OK) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  if ((rc = upload_host(c, c->in_r.p, build_aos_host, n_build * 16)) != HMJ_OK) return rc;
+  if ((rc = upload_host(c, c->in_s.p, probe_aos_host, n_probe * 16)) != HMJ_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const float ms_h2d = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   int st = span_begin(c, K_TOTAL, -1);
-  int s = span_begin(c, K_H2D, -1);
-  if (n_build)
-    HIP_TRY(hipMemcpyAsync(c->in_r.p, build_aos_host, n_build * 16, hipMemcpyHostToDevice, c->stream));
-  if (n_probe)
-    HIP_TRY(hipMemcpyAsync(c->in_s.p, probe_aos_host, n_probe * 16, hipMemcpyHostToDevice, c->stream));
-  span_end(c, s);
   rc = join_device(c, c->in_r.p, n_build, c->in_s.p, n_probe, flags, out, true);
   span_end(c, st);
   if (c->profiling) {
     (void)hipStreamSynchronize(c->stream);
     spans_collect(c);
+    c->timing.ms_h2d = ms_h2d;  // wall clock: staging threads + PCIe
+    c->timing.ms_total += ms_h2d;
   }
   return rc;
+}
+
+int hmj_join_u64(hmj_ctx* c, const void* build_aos_host, uint64_t n_build,
+                 const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out) {
+  return join_host_impl(c, build_aos_host, n_build, probe_aos_host, n_probe, flags, out);
+}
+
+struct hmj_rows {
+  HostBuf key, rval, sval;
+};
+
+int hmj_join_u64_rows(hmj_ctx* c, const void* build_aos_host, uint64_t n_build,
+                      const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out,
+                      hmj_rows** rows) {
+  if (!rows) return c ? fail(c, HMJ_E_ARG, "rows is NULL") : HMJ_E_ARG;
+  *rows = nullptr;
+  int rc = join_host_impl(c, build_aos_host, n_build, probe_aos_host, n_probe, flags | HMJ_MATERIALIZE, out);
+  if (rc != HMJ_OK) return rc;
+  hmj_rows* r = new hmj_rows();
+  if (out->n_matches) {  // hand the pinned columns over; the ctx will take fresh ones from the pool
+    r->key = c->h_key;
+    r->rval = c->h_rval;
+    r->sval = c->h_sval;
+    c->h_key = HostBuf();
+    c->h_rval = HostBuf();
+    c->h_sval = HostBuf();
+  }
+  *rows = r;
+  return HMJ_OK;
+}
+
+void hmj_rows_free(hmj_rows* r) {
+  if (!r) return;
+  pool_give(r->key);
+  pool_give(r->rval);
+  pool_give(r->sval);
+  delete r;
+}
+
+int hmj_set_host_threads(hmj_ctx* c, int n) {
+  if (!c || n < 0 || n > 64) return HMJ_E_ARG;
+  c->host_threads = n;
+  return HMJ_OK;
 }
 
 void hmj_release_result(hmj_ctx* c) {

@@ -93,9 +93,9 @@ class HashMergeJoin {
 
  public:
   HashMergeJoin() = default;
-  // num_threads is accepted for source compatibility (hashjoin.h:58); the work runs on the GPU.
+  // num_threads (hashjoin.h:58) sets the number of host threads that stage the relations for the
+  // PCIe copy; the join itself runs on the GPU.
   HashMergeJoin(RIter r_begin, RIter r_end, SIter s_begin, SIter s_end, unsigned int num_threads = 1) {
-    (void)num_threads;
     const distance_type r_size = std::distance(r_begin, r_end), s_size = std::distance(s_begin, s_end);
     const void* r_ptr = r_size ? static_cast<const void*>(std::addressof(*r_begin)) : nullptr;
     const void* s_ptr = s_size ? static_cast<const void*>(std::addressof(*s_begin)) : nullptr;
@@ -105,18 +105,16 @@ class HashMergeJoin {
         throw std::runtime_error("HashMergeJoin: unexpected std::pair layout");
     }
     hmj_ctx* c = hmj_detail::thread_ctx();
+    hmj_set_host_threads(c, num_threads > 16 ? 16 : (int)num_threads);
     hmj_result res;
-    hmj_detail::check(c, hmj_join_u64(c, r_ptr, (uint64_t)r_size, s_ptr, (uint64_t)s_size,
-                                      HMJ_MATERIALIZE | HMJ_ORDERED, &res), "hmj_join_u64");
-    const std::size_t n = (std::size_t)res.n_matches;
-    _key.resize(n);
-    _rval.resize(n);
-    _sval.resize(n);
-    if (n) {
-      std::memcpy(_key.data(), res.key, n * 8);
-      std::memcpy(static_cast<void*>(_rval.data()), res.rval, n * 8);
-      std::memcpy(static_cast<void*>(_sval.data()), res.sval, n * 8);
-    }
+    hmj_rows* rows = nullptr;
+    hmj_detail::check(c, hmj_join_u64_rows(c, r_ptr, (uint64_t)r_size, s_ptr, (uint64_t)s_size,
+                                           HMJ_MATERIALIZE | HMJ_ORDERED, &res, &rows), "hmj_join_u64_rows");
+    _rows = std::shared_ptr<hmj_rows>(rows, hmj_rows_free);  // the result columns (pinned host memory)
+    _n = (std::size_t)res.n_matches;
+    _key = const_cast<Key*>(res.key);
+    _rval = reinterpret_cast<RValue*>(const_cast<uint64_t*>(res.rval));
+    _sval = reinterpret_cast<SValue*>(const_cast<uint64_t*>(res.sval));
   }
 
   class iterator : public std::iterator<std::input_iterator_tag, std::tuple<Key*, RValue*, SValue*>> {
@@ -134,7 +132,7 @@ class HashMergeJoin {
     bool operator==(iterator other) const { return _pos == other._pos; }
     bool operator!=(iterator other) const { return _pos != other._pos; }
     std::tuple<Key*, RValue*, SValue*>& operator*() {
-      tmp_val = std::make_tuple(&_owner->_key[_pos], &_owner->_rval[_pos], &_owner->_sval[_pos]);
+      tmp_val = std::make_tuple(_owner->_key + _pos, _owner->_rval + _pos, _owner->_sval + _pos);
       return tmp_val;
     }
 
@@ -145,19 +143,25 @@ class HashMergeJoin {
   };
 
   iterator begin() { return iterator(this, 0); }
-  iterator end() { return iterator(this, _key.size()); }
+  iterator end() { return iterator(this, _n); }
   void clear() {
-    _key.clear();
-    _rval.clear();
-    _sval.clear();
+    _rows.reset();
+    _n = 0;
+    _key = nullptr;
+    _rval = nullptr;
+    _sval = nullptr;
   }
   // not in the reference: number of result rows
-  std::size_t size() const { return _key.size(); }
+  std::size_t size() const { return _n; }
 
  protected:
-  std::vector<Key> _key;
-  std::vector<RValue> _rval;
-  std::vector<SValue> _sval;
+  // Result columns live in pinned host memory owned by _rows (shared by copies of this object, as
+  // the reference's copies share nothing but are equally valid while they live).
+  std::shared_ptr<hmj_rows> _rows;
+  std::size_t _n = 0;
+  Key* _key = nullptr;
+  RValue* _rval = nullptr;
+  SValue* _sval = nullptr;
 };
 
 // Convenience spelled the way BASELINE.json's north_star names the entry point.
