@@ -100,6 +100,8 @@ def load_library():
     L.hmj_release_result.argtypes = [vp]
     L.hmj_partition_u64_device.restype = i
     L.hmj_partition_u64_device.argtypes = [vp, vp, u, i, i, vp, vp]
+    L.hmj_sort_u64_device.restype = i
+    L.hmj_sort_u64_device.argtypes = [vp, vp, u, vp]
     L.hmj_gen_build_u64_device.restype = i
     L.hmj_gen_build_u64_device.argtypes = [vp, vp, u, u, u]
     L.hmj_gen_probe_u64_device.restype = i

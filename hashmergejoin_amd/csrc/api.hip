@@ -735,6 +735,26 @@ int hmj_partition_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, int
   return HMJ_OK;
 }
 
+int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* out_aos_dev) {
+  if (!c) return HMJ_E_ARG;
+  int rc;
+  if ((rc = check_rel(c, in_aos_dev, n, "in_aos is NULL")) != HMJ_OK) return rc;
+  if ((rc = check_rel(c, out_aos_dev, n, "out_aos is NULL")) != HMJ_OK) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  spans_reset(c);
+  if (n == 0) return HMJ_OK;
+  if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
+  const void* src = in_aos_dev;
+  for (int pass = 0; pass < 8; pass++) {  // LSD: bits [8*pass, 8*pass+8); even passes land in tmp
+    void* dst = (pass & 1) ? out_aos_dev : c->rbuf[0].p;
+    if ((rc = radix_pass(c, src, dst, (u32)n, 8 * pass, 8, -1, nullptr)) != HMJ_OK) return rc;
+    src = dst;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->profiling) spans_collect(c);
+  return HMJ_OK;
+}
+
 #define GEN_PROLOGUE                                                        \
   if (!c) return HMJ_E_ARG;                                                 \
   if (n && !out_aos_dev) return fail(c, HMJ_E_ARG, "out_aos is NULL");      \

@@ -149,6 +149,15 @@ class Executor:
                                                     C.c_void_p(off.data_ptr())))
         return out, off
 
+    def sort_device(self, rel):
+        """Full ascending-key sort of a device relation (hmj_sort_u64_device); returns a new tensor."""
+        torch = self._torch
+        self._sync_stream()
+        ptr, n = _dev_ptr(rel)
+        out = torch.empty_like(rel)
+        self._check(self.L.hmj_sort_u64_device(self.h, C.c_void_p(ptr), n, C.c_void_p(out.data_ptr())))
+        return out
+
     # ---- generators ----------------------------------------------------------------------------
     def _alloc(self, n):
         torch = self._torch

@@ -158,6 +158,15 @@ int hmj_set_host_threads(hmj_ctx* ctx, int n);
 int hmj_partition_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, int shift, int bits,
                              void* out_aos_dev, uint64_t* offsets_dev);
 
+/* ---- full radix sort ------------------------------------------------------------ */
+/* Replaces radix_int_non_inplace<uint64_t,uint64_t>(begin, end, dst, num_threads)
+ * (radix_sort.h:452-522) -- the call radix_bench_par.cc:126-127 times: rows sorted by key, ascending,
+ * out of place.  Eight stable 8-bit LSD passes of the write-combining scatter; equal keys keep their
+ * input order (the reference is stable in pass 1 only, so on duplicate keys its payload order may
+ * differ; the key column and the multiset of rows are identical).  in/out: n x {key,val}, device,
+ * must not overlap.                                                                               */
+int hmj_sort_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, void* out_aos_dev);
+
 /* ---- synthetic relations on device (same integer arithmetic as the oracle) ------- */
 /* key = mix64(i + seed), val = i, i in [start, start+n)                                          */
 int hmj_gen_build_u64_device(hmj_ctx* ctx, void* out_aos_dev, uint64_t n, uint64_t start,

@@ -378,3 +378,34 @@ def test_skewed_build_side_config5(ex, H, oracle, log2b, log2p, log2dom):
         assert (int(fw.sum_probe_all) + int(fw.sum_r)) & M64 == psum and found >= int(fw.n_matches)
     ex.release_result()
     del R, S
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 4095, 12345, 1 << 16, (1 << 20) + 3])
+def test_full_radix_sort_matches_reference_sort(ex, oracle, n):
+    # hmj_sort_u64_device vs the restated radix_int_non_inplace (radix_sort.h:452-522; the call
+    # radix_bench_par.cc:126-127 times), same shapes as radix_sort_test.cc:48-68
+    rng = np.random.default_rng(n + 5)
+    keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    a = np.stack([keys, np.arange(n, dtype=np.uint64)], 1)
+    got = to_np(ex.sort_device(to_dev(a))) if n else a
+    assert np.array_equal(got, oracle.radix_int_non_inplace(a, 8, -1))  # unique keys: identical rows
+    # duplicate keys (and keys differing only in low / only in high bits): stable LSD order
+    k2 = (keys % np.uint64(97)) << np.uint64(40) | (keys % np.uint64(5))
+    a2 = np.stack([k2, np.arange(n, dtype=np.uint64)], 1)
+    got2 = to_np(ex.sort_device(to_dev(a2))) if n else a2
+    order = np.argsort(k2, kind="stable")
+    assert np.array_equal(got2, a2[order])
+    ref2 = oracle.radix_int_non_inplace(a2, 3, -1)
+    assert np.array_equal(got2[:, 0], ref2[:, 0])  # key column equals the reference's
+
+
+def test_full_radix_sort_golden(ex, G, golden_dir):
+    # radix_sort_test.cc:48-68 shape with the committed random input; expected FNV from the
+    # compiled reference (unique 64-bit keys -> one possible output)
+    c = G["radix_int_random"]
+    a = np.load(os.path.join(golden_dir, c["input"]))
+    got = to_np(ex.sort_device(to_dev(a)))
+    h = 0xCBF29CE484222325
+    for byte in np.ascontiguousarray(got).tobytes():
+        h = ((h ^ byte) * 0x100000001B3) & M64
+    assert h == c["non_inplace_T8"]
