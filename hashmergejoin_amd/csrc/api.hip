@@ -51,7 +51,7 @@ struct hmj_ctx {
   std::vector<hipEvent_t> up_events;  // 2 per staging thread
   std::vector<HostBuf> up_slots;      // 2 per staging thread
   int force_bits = -1;
-  int prefix_bits = 0;  // top key bits known to be constant (consumed by an outer split)
+  int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;
   std::vector<hipEvent_t> events;
@@ -322,8 +322,10 @@ int check_rel(hmj_ctx* c, const void* p, uint64_t n, const char* name) {
   return HMJ_OK;
 }
 
-int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
-                uint32_t flags, hmj_result* out, bool to_host) {
+constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-planned without the sampled prefix
+
+int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
+                     uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix) {
   int rc;
   if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
   std::memset(out, 0, sizeof(*out));
@@ -361,7 +363,20 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
 
   HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
   const void *Rp, *Sp;
-  int prefix = c->prefix_bits;
+  int prefix = c->prefix_bits < 0 ? 0 : c->prefix_bits;
+  bool sampled = false;
+  u64 pfx_ref = 0;
+  if (c->prefix_bits < 0 && allow_auto_prefix && B > 0 && (u64)nb + np > 0) {
+    // dense / small-integer keys: skip the top bits every (sampled) key shares
+    u64* hs = (u64*)c->h_accum.p;
+    if ((rc = ensure_dev(c, c->offs64, 2 * sizeof(u64))) != HMJ_OK) return rc;
+    HIP_TRY(hmj::launch_key_sample(R, nb, S, np, (u64*)c->offs64.p, c->stream));
+    HIP_TRY(hipMemcpyAsync(hs, c->offs64.p, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prefix = hs[0] ? __builtin_clzll(hs[0]) : 64;
+    pfx_ref = hs[1];
+    sampled = prefix > 0;
+  }
   if (prefix + B > 64) prefix = 64 - B;
   const int low = 64 - prefix - B;  // partition id = (key >> low) & (P - 1)
   if ((rc = partition_relation(c, R, nb, c->rbuf, low, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
@@ -380,6 +395,10 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   a.P = P;
   a.Q = Q;
   a.accum = (u64*)c->accum.p;
+  if (sampled && prefix > 0 && (flags & HMJ_ORDERED)) {  // ordered output relies on the prefix: verify it
+    a.pfx_shift = (u32)(64 - prefix);
+    a.pfx_val = pfx_ref >> (64 - prefix);
+  }
   if (const char* e = getenv("HMJ_DEBUG_ABLATE")) a.debug = (u32)atoi(e);
   a.part_count = (u64*)c->part_count.p;
   a.part_out_off = (const u64*)c->part_out_off.p;
@@ -419,6 +438,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   u64* h = (u64*)c->h_accum.p;
   HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h[hmj::ACC_ERR] & hmj::ERR_PREFIX) return kRetryNoPrefix;
   out->n_matches = h[hmj::ACC_N];
   out->sum_r = h[hmj::ACC_SUM_R];
   out->sum_s = h[hmj::ACC_SUM_S];
@@ -468,6 +488,13 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
     out->sval = to_host ? (const uint64_t*)c->h_sval.p : (const uint64_t*)a.out_sval;
   }
   return HMJ_OK;
+}
+
+int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
+                uint32_t flags, hmj_result* out, bool to_host) {
+  int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, true);
+  if (rc == kRetryNoPrefix) rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, false);
+  return rc;
 }
 
 }  // namespace
@@ -539,7 +566,7 @@ int hmj_set_radix_bits(hmj_ctx* c, int total_bits) {
 }
 
 int hmj_set_key_prefix_bits(hmj_ctx* c, int bits) {
-  if (!c || bits < 0 || bits > 32) return HMJ_E_ARG;
+  if (!c || bits < -1 || bits > 48) return HMJ_E_ARG;
   c->prefix_bits = bits;
   return HMJ_OK;
 }

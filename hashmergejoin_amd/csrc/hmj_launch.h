@@ -19,6 +19,7 @@ hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipS
 hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, int shift, int bits,
                                 const u32* hist_scanned, const u32* totals, u32 nblk,
                                 u32 rows_per_block, u64* offsets_out, hipStream_t st);
+hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st);
 hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st);
 
 // probe.hip
@@ -37,6 +38,8 @@ struct ProbeArgs {
   u64* accum;              // 8 x u64, see hmj_dev.h ACC_*
   const u32* item_list;    // optional: process only these items (set aside by the fast kernel)
   const u32* n_item_list;  //           their count (device)
+  u32 pfx_shift;           // ordered mode: verify (key >> pfx_shift) == pfx_val for every row (0 = off)
+  u64 pfx_val;
   u32* matched;            // HMJ_FIRST_WINS + chunked build: one bit per probe row already paired
   u32 debug;               // dev-only ablation bits (HMJ_DEBUG_ABLATE env): 1 = loads only, 2 = no probe walk
 };

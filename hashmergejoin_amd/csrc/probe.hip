@@ -57,6 +57,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
   const int tid = threadIdx.x, lane = tid & 63;
 
   u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
+  bool pfx_bad = false;
   if (MODE == 1 && tid == 0) sm.pcount = 0;
 
   // either all P*Q items, or (after the fast kernel) just the partitions it set aside
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
         for (int k = 0; k < 2; k++) {
           u32 i = i0 + k * PB_THREADS + tid;
           if (i < cn) {
+            if (a.pfx_shift && (t[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             sm.key[i] = t[k].key;
             sm.val[i] = t[k].val;
             u32 old = atomicExch(&sm.head[tab_hash(t[k].key)], i);
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
             u32 j = j0 + k * PB_THREADS + tid;
             if (j < np) {
               const u64 key = t[k].key, sval = t[k].val;
+              if (a.pfx_shift && (key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
               if (EXTRA && c0 == 0) acc_p += sval;
               u32 i = sm.head[tab_hash(key)];
               u32 best = NIL;
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
     }
   }
 
+  if (MODE != 2 && __any(pfx_bad) && (tid & 63) == 0) atomicOr(&a.accum[ACC_ERR], ERR_PREFIX);
   if (MODE != 2) {
     __syncthreads();
     if (tid < 8) sm.red[tid] = 0;
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
   const u32 P = a.P;
   const int tid = threadIdx.x;
   u64 acc_n = 0, acc_r = 0, acc_s = 0;
+  bool pfx_bad = false;
   for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
   if (tid < 2) sm.itemcnt[tid] = 0;
   u32 epoch = 0;
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
           const u32 i = k * THREADS + tid;
           old[k] = tag | NIL;
           if (i < nb) {
+            if (a.pfx_shift && (br[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             sm.key[i] = br[k].key;
             sm.val[i] = br[k].val;
             old[k] = atomicExch(&sm.head[fast_hash<LOG_NB>(br[k].key)], tag | i);
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
           const u32 j = k * THREADS + tid;
           cur[k] = NIL;
           if (j < np) {
+            if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             const u32 hv = sm.head[fast_hash<LOG_NB>(pr[k].key)];
             cur[k] = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
           }
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
     for (int k = 0; k < FP_ROWS; k++) pr[k] = pq[k];
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
   }
+  if (__any(pfx_bad) && (tid & 63) == 0) atomicOr(&a.accum[ACC_ERR], ERR_PREFIX);
   lds_barrier();
   if (PCOUNT && prev_p != 0xFFFFFFFFu && tid == 0) a.part_count[prev_p] = sm.itemcnt[parity ^ 1];
   if (tid < 8) sm.red[tid] = 0;

@@ -503,6 +503,50 @@ __global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int low, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Key-range probe for the planner: OR of (key ^ reference key) over a strided sample of both
+// relations.  Its leading zeros are the top key bits all sampled keys share (dense integer keys:
+// the zero high bits), which carry no information for partitioning; the reference's MSD recursion
+// reaches the informative bits by recursing (radix_hash.h:277-289), the GPU plan skips to them.
+// out[0] = OR, out[1] = reference key.  A sample can miss outliers: the join stays correct for any
+// prefix (the partition id is a function of the key); ordered output additionally verifies it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict__ R, u32 nb,
+                                                          const Tup* __restrict__ S, u32 np,
+                                                          u64* __restrict__ out) {
+  __shared__ u64 acc;
+  const int tid = threadIdx.x;
+  const u64* rk = reinterpret_cast<const u64*>(R);
+  const u64* sk = reinterpret_cast<const u64*>(S);
+  const u64 ref = nb ? rk[0] : (np ? sk[0] : 0);
+  if (tid == 0) acc = 0;
+  __syncthreads();
+  u64 x = 0;
+  const u32 sr = nb / 8192 + 1, ss = np / 8192 + 1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const u64 i = (u64)(tid + k * 1024) * sr, j = (u64)(tid + k * 1024) * ss;
+    if (i < nb) x |= rk[2 * i] ^ ref;
+    if (j < np) x |= sk[2 * j] ^ ref;
+  }
+  if (nb) x |= rk[2 * (u64)(nb - 1)] ^ ref;
+  if (np) x |= sk[2 * (u64)(np - 1)] ^ ref;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) x |= __shfl_xor(x, o, kWave);
+  if ((tid & 63) == 0 && x) atomicOr(&acc, x);
+  __syncthreads();
+  if (tid == 0) {
+    out[0] = acc;
+    out[1] = ref;
+  }
+}
+
+hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st) {
+  hipLaunchKernelGGL(key_sample_kernel, dim3(1), dim3(1024), 0, st, static_cast<const Tup*>(R), nb,
+                     static_cast<const Tup*>(S), np, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 // Workers: k = ceil(full_tiles / tiles_per_worker) workers own whole tiles; if n is not a multiple

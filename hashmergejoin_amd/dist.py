@@ -96,5 +96,5 @@ def distributed_join(ex, r_shard, s_shard, flags=0, group=None):
     try:
         res = ex.join_device(recv[0], recv[1], flags)
     finally:
-        ex.set_key_prefix_bits(0)
+        ex.set_key_prefix_bits(-1)
     return res, allreduce_checks(res.checks(), r_shard.device, group)

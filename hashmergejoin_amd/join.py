@@ -86,7 +86,7 @@ class Executor:
         self._check(self.L.hmj_set_radix_bits(self.h, -1 if bits is None else bits))
 
     def set_key_prefix_bits(self, bits):
-        """Top `bits` key bits are constant in both relations (consumed by an outer split)."""
+        """Top `bits` key bits are constant in both relations (consumed by an outer split); -1 = sample."""
         self._check(self.L.hmj_set_key_prefix_bits(self.h, bits))
 
     def set_profiling(self, on=True):

@@ -108,7 +108,11 @@ int hmj_reserve(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, uint64_t max_m
 int hmj_set_radix_bits(hmj_ctx* ctx, int total_bits);
 /* Tell the executor that the top `bits` key bits are equal in all rows of both relations (an outer
  * radix split already consumed them, e.g. the multi-GPU owner split): partitioning then starts
- * below them, as the reference's recursion masks off consumed bits (radix_hash.h:219-220).       */
+ * below them, as the reference's recursion masks off consumed bits (radix_hash.h:219-220).
+ * bits = -1 (the default): the executor samples both relations and skips the top bits all sampled
+ * keys share (dense / small-integer keys would otherwise all fall into partition 0).
+ * Any value is safe for the result; ordered output additionally verifies a sampled prefix on every
+ * row and re-plans without it if a row disagrees.                                                */
 int hmj_set_key_prefix_bits(hmj_ctx* ctx, int bits);
 /* The automatic plan for a build side of n_build rows: total bits and per-pass bits (LSD order).*/
 int hmj_plan(uint64_t n_build, int* total_bits, int* n_passes, int pass_bits[4]);

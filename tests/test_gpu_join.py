@@ -327,7 +327,7 @@ def test_key_prefix_bits_after_an_outer_split(ex, H, oracle):
         r = ex.join_device(to_dev(B), to_dev(P), 0)
         assert int(r.n_matches) == ck["n_matches"]
     finally:
-        ex.set_key_prefix_bits(0)
+        ex.set_key_prefix_bits(-1)
         ex.set_profiling(False)
     # without the hint the result is still right (partitioning is any function of the key)
     r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
@@ -409,3 +409,40 @@ def test_full_radix_sort_golden(ex, G, golden_dir):
     for byte in np.ascontiguousarray(got).tobytes():
         h = ((h ^ byte) * 0x100000001B3) & M64
     assert h == c["non_inplace_T8"]
+
+
+def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
+    # dense keys 0..N-1 all share their top bits (the reference sends them all to
+    # partition 0 in pass 1 and reaches the low bits by recursing).  The executor samples the
+    # relations and partitions below the shared prefix; ordered output must still be exact.
+    n = 1 << 20
+    rng = np.random.default_rng(11)
+    kb = rng.permutation(n).astype(np.uint64)
+    kp = rng.permutation(n + n // 4)[:n].astype(np.uint64)  # 80 % of the probe keys exist
+    B = np.stack([kb, np.arange(n, dtype=np.uint64) * np.uint64(7)], 1)
+    P = np.stack([kp, np.arange(n, dtype=np.uint64) + np.uint64(5)], 1)
+    ck, rows = oracle.equijoin(B, P)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
+    assert r.checks() == ck
+    assert ex.last_timing()["ms_probe_count"] < 5.0  # not the one-giant-partition path
+    ex.set_profiling(False)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    assert r.checks() == ck and np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+    # an outlier the sample does not see (top bit set, at an unsampled row): the ordered join
+    # notices the broken prefix and re-plans; the result stays exact
+    B2, P2 = B.copy(), P.copy()
+    B2[12345, 0] = np.uint64((1 << 63) | 77)
+    P2[54321, 0] = np.uint64((1 << 63) | 77)
+    ck2, rows2 = oracle.equijoin(B2, P2)
+    r = ex.join_device(to_dev(B2), to_dev(P2), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    assert r.checks() == ck2 and np.array_equal(ex.columns_to_numpy(r, host=False), rows2)
+    r = ex.join_device(to_dev(B2), to_dev(P2), H.HMJ_CHECKSUM)
+    assert r.checks() == ck2
+    # reference known-answer shape: radix_hash_test.cc:82-93 keys 12345..1 (descending ints)
+    k = np.arange(12345, 0, -1, dtype=np.uint64)
+    D = np.stack([k, k], 1)
+    nref, smref, tref = oracle.hashmergejoin(D, D[::-1].copy(), 2)
+    r = ex.join_host(D, D[::-1].copy(), H.HMJ_ORDERED)
+    got = ex.columns_to_numpy(r, host=True)
+    assert int(r.n_matches) == nref == 12345 and np.array_equal(got, tref)
