@@ -44,7 +44,8 @@ struct hmj_ctx {
   int device = 0, num_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
-      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched;
+      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched,
+      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int host_threads = 0;  // staging threads for pageable input (0 = default)
   std::vector<hipStream_t> up_streams;
@@ -52,6 +53,8 @@ struct hmj_ctx {
   std::vector<HostBuf> up_slots;      // 2 per staging thread
   int force_bits = -1;
   int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
+  int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
+  int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;
   std::vector<hipEvent_t> events;
@@ -322,10 +325,12 @@ int check_rel(hmj_ctx* c, const void* p, uint64_t n, const char* name) {
   return HMJ_OK;
 }
 
+constexpr int kRetryNoSlab = 1001;    // internal: the slab path gave up (skew) -> exact path
 constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-planned without the sampled prefix
 
 int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
-                     uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix) {
+                     uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix,
+                     bool allow_slab) {
   int rc;
   if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
   std::memset(out, 0, sizeof(*out));
@@ -379,6 +384,64 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   }
   if (prefix + B > 64) prefix = 64 - B;
   const int low = 64 - prefix - B;  // partition id = (key >> low) & (P - 1)
+  // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
+  if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;
+  hmj::SlabGeom gr, gs;
+  if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && !materialize && !first && !extra && Q == 1 &&
+      passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && nb >= (1u << 22) && np >= (1u << 22) &&
+      hmj::slab_geometry(nb, pass_bits[0], pass_bits[1], &gr) &&
+      hmj::slab_geometry(np, pass_bits[0], pass_bits[1], &gs)) {
+    const int ba = pass_bits[0], bb = pass_bits[1];
+    const u64 rows_a = gr.rows_a > gs.rows_a ? gr.rows_a : gs.rows_a;
+    const u32 wa = gr.WA > gs.WA ? gr.WA : gs.WA;
+    if ((rc = ensure_dev(c, c->slab_a, rows_a * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_a, ((size_t)wa << ba) * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->slab_br, gr.rows_b * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->slab_bs, gs.rows_b * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_br, (size_t)P * 4 * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * 4 * 4)) != HMJ_OK) return rc;
+    u64* acc = (u64*)c->accum.p;
+    struct { const void* in; u32 n; const hmj::SlabGeom* g; void* sb; u32* cb; int rel; } side[2] = {
+        {R, nb, &gr, c->slab_br.p, (u32*)c->cnt_br.p, 0}, {S, np, &gs, c->slab_bs.p, (u32*)c->cnt_bs.p, 1}};
+    for (auto& sd : side) {
+      int sp = span_begin(c, K_SCATTER, sd.rel);
+      HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
+      span_end(c, sp);
+      sp = span_begin(c, K_SCATTER, sd.rel);
+      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, *sd.g, sd.sb, sd.cb,
+                                 acc, c->stream));
+      span_end(c, sp);
+      c->timing.bytes_scatter += 2 * 32ull * sd.n;
+    }
+    hmj::ProbeArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.R = c->slab_br.p;
+    sa.S = c->slab_bs.p;
+    sa.r_cnt = (const u32*)c->cnt_br.p;
+    sa.s_cnt = (const u32*)c->cnt_bs.p;
+    sa.r_cap = gr.CB;
+    sa.s_cap = gs.CB;
+    sa.P = P;
+    sa.Q = 1;
+    sa.accum = acc;
+    if (const char* e = getenv("HMJ_DEBUG_ABLATE")) sa.debug = (u32)atoi(e);
+    int sp = span_begin(c, K_PROBE_COUNT, -1);
+    HIP_TRY(hmj::launch_probe_count_slab(sa, c->num_cus, c->stream));
+    span_end(c, sp);
+    c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
+    u64* hh = (u64*)c->h_accum.p;
+    HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // skewed digits: remember, and take the exact path
+      c->slab_cooldown = 8;
+      return kRetryNoSlab;
+    }
+    out->n_matches = hh[hmj::ACC_N];
+    out->sum_r = hh[hmj::ACC_SUM_R];
+    out->sum_s = hh[hmj::ACC_SUM_S];
+    return HMJ_OK;
+  }
+
   if ((rc = partition_relation(c, R, nb, c->rbuf, low, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
   if ((rc = partition_relation(c, S, np, c->sbuf, low, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
   int s = span_begin(c, K_OFFSETS, -1);
@@ -492,9 +555,22 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
 
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
-  int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, true);
-  if (rc == kRetryNoPrefix) rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, false);
-  return rc;
+  bool auto_prefix = true, slab = true;
+  for (int attempt = 0; attempt < 3; attempt++) {
+    int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab);
+    if (rc == kRetryNoSlab || rc == kRetryNoPrefix) {
+      // forget the abandoned attempt's phase spans (the enclosing total / h2d spans stay)
+      std::vector<Span> keep;
+      for (const Span& sp : c->spans)
+        if (sp.kind == K_TOTAL || sp.kind == K_H2D) keep.push_back(sp);
+      c->spans.swap(keep);
+      std::memset(&c->timing, 0, sizeof(c->timing));
+      if (rc == kRetryNoSlab) slab = false; else auto_prefix = false;
+      continue;
+    }
+    return rc;
+  }
+  return fail(c, HMJ_E_HIP, "join could not be planned");
 }
 
 }  // namespace
@@ -514,6 +590,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return HMJ_E_NODEV;
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
+  if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
   if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
@@ -540,7 +617,8 @@ void hmj_destroy(hmj_ctx* c) {
   DevBuf* devs[] = {&c->rbuf[0], &c->rbuf[1], &c->sbuf[0], &c->sbuf[1], &c->in_r, &c->in_s,
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
-                    &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched};
+                    &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched,
+                    &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);

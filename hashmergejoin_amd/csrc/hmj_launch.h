@@ -19,6 +19,16 @@ hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipS
 hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, int shift, int bits,
                                 const u32* hist_scanned, const u32* totals, u32 nblk,
                                 u32 rows_per_block, u64* offsets_out, hipStream_t st);
+// slab (histogram-free) partitioning, radix.hip
+struct SlabGeom {
+  u32 WA, rpw, CA, CB, KB;
+  u64 rows_a, rows_b;
+};
+bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g);
+hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a,
+                         u32* cnt_a, u64* accum, hipStream_t st);
+hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
+                         const SlabGeom& g, void* slab_b, u32* cnt_b, u64* accum, hipStream_t st);
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st);
 hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st);
 
@@ -38,6 +48,11 @@ struct ProbeArgs {
   u64* accum;              // 8 x u64, see hmj_dev.h ACC_*
   const u32* item_list;    // optional: process only these items (set aside by the fast kernel)
   const u32* n_item_list;  //           their count (device)
+  // slab layout (probe_count_slab_kernel): partition p = 4 pieces, piece j = rows
+  // [(p*4 + j) * cap, + cnt[p*4 + j]) of R / S
+  const u32* r_cnt;
+  const u32* s_cnt;
+  u32 r_cap, s_cap;
   u32 pfx_shift;           // ordered mode: verify (key >> pfx_shift) == pfx_val for every row (0 = off)
   u64 pfx_val;
   u32* matched;            // HMJ_FIRST_WINS + chunked build: one bit per probe row already paired
@@ -47,6 +62,7 @@ struct ProbeArgs {
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
                         hipStream_t st);
 int probe_default_grid(int num_cus);
+hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st);
 // count-mode fast path (Q == 1, no flags); partitions it cannot take go to irregular[]
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
                                    bool per_partition_counts, int num_cus, hipStream_t st);

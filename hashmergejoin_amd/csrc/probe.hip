@@ -272,8 +272,25 @@ __device__ __forceinline__ void fp_load(Tup (&t)[FP_ROWS], const Tup* __restrict
 
 // <512, 11>: partitions up to 2560 rows, 53 KiB LDS, 3 workgroups/CU (the planner's default size)
 // <1024, 12>: partitions up to 5120 rows, 106 KiB LDS, 1 workgroup/CU
+// Slab layout loader: the partition is 4 pieces of up to `cap` rows; p1..p3 = prefix sums of the
+// first three piece counts (wave-uniform).
+template <int THREADS>
+__device__ __forceinline__ void fp_load_slab(Tup (&t)[FP_ROWS], const Tup* __restrict__ base, u32 cap,
+                                             u32 p1, u32 p2, u32 p3, u32 n, int tid) {
+#pragma unroll
+  for (int k = 0; k < FP_ROWS; k++) {
+    u32 i = k * THREADS + tid;
+    i = i < n ? i : n - 1;
+    const u32 j = (i >= p1) + (i >= p2) + (i >= p3);
+    const u32 pre = j == 0 ? 0u : (j == 1 ? p1 : (j == 2 ? p2 : p3));
+    t[k] = base[(u64)j * cap + (i - pre)];
+  }
+}
+
 // PCOUNT: also store each partition's match count in a.part_count[p] (first pass of materialising).
-template <int THREADS, int LOG_NB, bool PCOUNT>
+// SLAB: the partitioned relations are in the histogram-free slab layout (radix.hip, slab kernels);
+//       a partition that does not fit the pipeline raises ERR_SLAB (the caller re-runs the exact path).
+template <int THREADS, int LOG_NB, bool PCOUNT, bool SLAB>
 __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_fast_kernel(
     ProbeArgs a, u32* __restrict__ irregular, u32* __restrict__ n_irregular) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
@@ -300,13 +317,29 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
   u32 rb = 0, nb = 0, sb = 0, np = 0;
   bool regular = false;
   Tup br[FP_ROWS], pr[FP_ROWS], pq[FP_ROWS];
+  // slab layout: piece prefix sums of the current (r1..3, s1..3) and next (…n) partition
+  u32 r1 = 0, r2 = 0, r3 = 0, s1 = 0, s2 = 0, s3 = 0, r1n = 0, r2n = 0, r3n = 0, s1n = 0, s2n = 0, s3n = 0;
+  bool slab_bad = false;
   if (p < P) {
-    rb = r_off[p]; nb = r_off[p + 1] - rb;
-    sb = s_off[p]; np = s_off[p + 1] - sb;
+    if (SLAB) {
+      const u32* rc = a.r_cnt + (u64)p * 4;
+      const u32* sc = a.s_cnt + (u64)p * 4;
+      r1 = rc[0]; r2 = r1 + rc[1]; r3 = r2 + rc[2]; nb = r3 + rc[3];
+      s1 = sc[0]; s2 = s1 + sc[1]; s3 = s2 + sc[2]; np = s3 + sc[3];
+      if (nb > CAP || np > CAP) slab_bad = true;
+    } else {
+      rb = r_off[p]; nb = r_off[p + 1] - rb;
+      sb = s_off[p]; np = s_off[p + 1] - sb;
+    }
     regular = nb && np && nb <= CAP && np <= CAP;
     if (regular) {
-      fp_load<THREADS>(br, R + rb, nb, tid);
-      fp_load<THREADS>(pr, S + sb, np, tid);
+      if (SLAB) {
+        fp_load_slab<THREADS>(br, R + (u64)p * 4 * a.r_cap, a.r_cap, r1, r2, r3, nb, tid);
+        fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
+      } else {
+        fp_load<THREADS>(br, R + rb, nb, tid);
+        fp_load<THREADS>(pr, S + sb, np, tid);
+      }
     }
   }
   while (p < P) {
@@ -314,11 +347,24 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
     u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
     bool regular2 = false;
     if (pn < P) {
-      rb2 = r_off[pn]; nb2 = r_off[pn + 1] - rb2;
-      sb2 = s_off[pn]; np2 = s_off[pn + 1] - sb2;
+      if (SLAB) {
+        const u32* rc = a.r_cnt + (u64)pn * 4;
+        const u32* sc = a.s_cnt + (u64)pn * 4;
+        r1n = rc[0]; r2n = r1n + rc[1]; r3n = r2n + rc[2]; nb2 = r3n + rc[3];
+        s1n = sc[0]; s2n = s1n + sc[1]; s3n = s2n + sc[2]; np2 = s3n + sc[3];
+        if (nb2 > CAP || np2 > CAP) slab_bad = true;
+      } else {
+        rb2 = r_off[pn]; nb2 = r_off[pn + 1] - rb2;
+        sb2 = s_off[pn]; np2 = s_off[pn + 1] - sb2;
+      }
       regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
     }
-    if (regular2) fp_load<THREADS>(pq, S + sb2, np2, tid);  // next partition's probe rows
+    if (regular2) {  // next partition's probe rows
+      if (SLAB)
+        fp_load_slab<THREADS>(pq, S + (u64)pn * 4 * a.s_cap, a.s_cap, s1n, s2n, s3n, np2, tid);
+      else
+        fp_load<THREADS>(pq, S + sb2, np2, tid);
+    }
     if (regular) {
       lds_barrier();                   // everyone is done probing the previous table
       if (PCOUNT && prev_p != 0xFFFFFFFFu && tid == 0) {  // its count is complete now
@@ -356,7 +402,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) acc_r += br[k].key;
       }
-      if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);  // next partition's build rows
+      if (regular2) {  // next partition's build rows
+        if (SLAB)
+          fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
+        else
+          fp_load<THREADS>(br, R + rb2, nb2, tid);
+      }
       lds_barrier();                                          // table complete
       const u64 n_before = acc_n;
       if (!(a.debug & 1u)) {
@@ -404,13 +455,20 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
       }
     } else {
       if (PCOUNT && tid == 0 && !(nb && np)) a.part_count[p] = 0;  // empty side: no rows
-      if (tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
-      if (regular2) fp_load<THREADS>(br, R + rb2, nb2, tid);
+      if (!SLAB && tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
+      if (regular2) {
+        if (SLAB)
+          fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
+        else
+          fp_load<THREADS>(br, R + rb2, nb2, tid);
+      }
     }
 #pragma unroll
     for (int k = 0; k < FP_ROWS; k++) pr[k] = pq[k];
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
+    r1 = r1n; r2 = r2n; r3 = r3n; s1 = s1n; s2 = s2n; s3 = s3n;
   }
+  if (SLAB && slab_bad && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_SLAB);
   if (__any(pfx_bad) && (tid & 63) == 0) atomicOr(&a.accum[ACC_ERR], ERR_PREFIX);
   lds_barrier();
   if (PCOUNT && prev_p != 0xFFFFFFFFu && tid == 0) a.part_count[prev_p] = sm.itemcnt[parity ^ 1];
@@ -644,21 +702,21 @@ static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int THREADS, int LOG_NB, bool PCOUNT>
+template <int THREADS, int LOG_NB, bool PCOUNT, bool SLAB = false>
 static hipError_t launch_fast_t(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
                                 hipStream_t st) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT>),
+        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT>), dim3(grid), dim3(THREADS),
+  hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB>), dim3(grid), dim3(THREADS),
                      sizeof(Smem), st, a, irregular, n_irregular);
   return hipGetLastError();
 }
@@ -672,6 +730,10 @@ hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_ir
   }
   if (big) return launch_fast_t<1024, BIG_LOG_NB, false>(a, irregular, n_irregular, num_cus * 4, st);
   return launch_fast_t<512, 11, false>(a, irregular, n_irregular, num_cus * 3 * 4, st);
+}
+
+hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st) {
+  return launch_fast_t<1024, BIG_LOG_NB, false, true>(a, nullptr, nullptr, num_cus * 4, st);
 }
 
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,

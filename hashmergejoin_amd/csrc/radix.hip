@@ -296,13 +296,175 @@ struct WcSmem {
   u32 scratch[WAVES + 1];
 };
 
+// One tile of the write-combining scatter: rank -> plan -> stage -> (prefetch) -> copy out whole
+// lines -> keep the tails.  Shared by the exact kernel (global offsets from the histogram) and the
+// slab kernels (private over-allocated output regions, no histogram).
+//   ALLVALID : every row slot of the tile holds a row (no per-row predicate)
+//   LIMIT    : digit d may only write below limit[d] (an LDS array); a digit that would cross it sets *ovf and
+//              drops its rows (the caller discards the whole result and re-runs the exact path)
+template <int THREADS, int MAXD, bool HI, bool ALLVALID, bool LIMIT, typename Prefetch>
+__device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_ITEMS], u32 tile_n,
+                                        Tup* __restrict__ out, int shift, u32 mask, u32 D,
+                                        Prefetch&& prefetch, const u32* limit, bool* ovf) {
+  typedef WcSmem<THREADS, MAXD> Smem;
+  constexpr int WAVES = Smem::WAVES;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  u16* wc = &sm.wcnt[w][0];
+  u64* lm = &sm.lanemask[w][0];
+  const u64 lanebit = 1ull << lane;
+  const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
+
+  // relaxed workgroup-scope atomics: plain LDS instructions, never cached in registers, and --
+  // unlike volatile accesses -- no s_waitcnt vmcnt(0) around them (the prefetch stays in flight)
+  u32 dr[WC_ITEMS];
+#pragma unroll
+  for (int r = 0; r < WC_ITEMS; r++) {
+    u32 d = 0, rank = 0;
+    if (ALLVALID || wbase + r * 64 < tile_n) {
+      d = digit_of<HI>(t[r].key, shift, mask);
+      __hip_atomic_fetch_or(&lm[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const u64 m = __hip_atomic_load(&lm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const u32 old = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const u32 below = popc_below(m);
+      if (below == 0) {
+        __hip_atomic_store(&lm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&wc[d], (u16)(old + (u32)__popcll(m)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      rank = old + below;
+    }
+    dr[r] = (d << 16) | rank;
+  }
+  lds_barrier();
+
+  // per digit: prefix over waves, tile offsets, this tile's flush plan and its 128-byte lines
+  {
+    u32 cnt = 0, nl = 0, pd = 0, cf = 0, fl = 0;
+    if ((u32)tid < D) {
+#pragma unroll
+      for (int k = 0; k < WAVES; k++) {
+        u32 c = sm.wcnt[k][tid];
+        sm.wcnt[k][tid] = (u16)cnt;
+        cnt += c;
+      }
+      pd = sm.pend[tid];
+      cf = sm.cflush[tid];
+      u32 avail = pd + cnt;
+      if (LIMIT && cf + avail > limit[tid]) {  // slab full: give up on this digit (and the run)
+        *ovf = true;
+        avail = 0;
+        pd = 0;
+      }
+      const u32 tail = (cf + avail) & (WC_LINE - 1);  // rows past the last whole line
+      fl = (tail >= avail) ? 0u : avail - tail;
+      nl = fl ? (((cf & (WC_LINE - 1)) + fl + WC_LINE - 1) >> 3) : 0u;
+      sm.pend[tid] = avail - fl;
+      sm.cflush[tid] = cf + fl;
+    }
+    u32 tot;
+    const u32 sc = block_excl_scan_u32<THREADS>((nl << 16) | cnt, sm.scratch, &tot);
+    if ((u32)tid < D) {
+      const u32 loff = sc >> 16;
+      sm.tile_off[tid] = sc & 0xFFFFu;
+      sm.cf_tile[tid] = cf;
+      sm.plan[tid] = (fl << 8) | pd;
+      sm.line_off[tid] = loff;
+      for (u32 l = 0; l < nl; l++) sm.line_tab[loff + l] = (u16)tid;
+    }
+    if (tid == 0) sm.total_lines = tot >> 16;
+  }
+  lds_barrier();
+
+#pragma unroll
+  for (int r = 0; r < WC_ITEMS; r++) {
+    if (ALLVALID || wbase + r * 64 < tile_n) {
+      const u32 d = dr[r] >> 16;
+      sm.stage[sm.tile_off[d] + sm.wcnt[w][d] + (dr[r] & 0xFFFFu)] = t[r];
+    }
+  }
+  prefetch();  // the rows now live in LDS: start fetching the next tile while this one leaves
+  lds_barrier();
+
+  // copy out WHOLE LINES: 8 consecutive lanes own one 128-byte line (carried rows first, then
+  // this tile's rows), so every line leaves in a single store instruction
+  {
+    const u32 TL = sm.total_lines, k = (u32)tid & (WC_LINE - 1);
+    for (u32 L = (u32)tid >> 3; L < TL; L += THREADS / WC_LINE) {
+      const u32 d = sm.line_tab[L];
+      const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu, cfd = sm.cf_tile[d];
+      const u32 grow = (cfd & ~(u32)(WC_LINE - 1)) + (L - sm.line_off[d]) * WC_LINE + k;
+      const u32 j = grow - cfd;  // wraps (huge) for the slots before an unaligned segment start
+      if (j < fl) out[grow] = (j < pd) ? sm.carry[d][j] : sm.stage[sm.tile_off[d] + j - pd];
+    }
+  }
+  // rows that stay behind (each digit's new partial line): stage -> registers
+  u64 keep_k[WC_ITEMS], keep_v[WC_ITEMS];
+  u32 has = 0;
+#pragma unroll
+  for (int q = 0; q < WC_ITEMS; q++) {
+    const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
+    u32 idx = 0;
+    if (d < D && k < sm.pend[d]) {
+      const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu;
+      if (fl != 0 || k >= pd) {
+        idx = sm.tile_off[d] + (fl ? fl - pd + k : k - pd);
+        has |= 1u << q;
+      }
+    }
+    const Tup kv = sm.stage[idx];  // unconditional read (row 0 when nothing stays)
+    keep_k[q] = kv.key;
+    keep_v[q] = kv.val;
+  }
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < WC_ITEMS; q++) {
+    const u32 s = q * THREADS + tid;
+    if (has & (1u << q)) {
+      Tup kv;
+      kv.key = keep_k[q];
+      kv.val = keep_v[q];
+      sm.carry[s >> 3][s & (WC_LINE - 1)] = kv;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < WC_ITEMS; r++) {
+    if (r * THREADS < Smem::ZROWS) {  // hand the slab back to the lane masks as zeros
+      Tup z;
+      z.key = 0;
+      z.val = 0;
+      sm.stage[r * THREADS + tid] = z;
+    }
+  }
+  for (int i = tid; i < WAVES * MAXD / 2; i += THREADS) reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
+  lds_barrier();
+}
+
+// worker done: whatever still waits in the carry buffers ends this worker's digit segments
+template <int THREADS, int MAXD>
+__device__ __forceinline__ void wc_flush_carry(WcSmem<THREADS, MAXD>& sm, Tup* __restrict__ out, u32 D) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < WC_ITEMS; q++) {
+    const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
+    if (d < D && k < sm.pend[d]) out[sm.cflush[d] + k] = sm.carry[d][k];
+  }
+}
+
+template <int THREADS, int MAXD>
+__device__ __forceinline__ void wc_clear(WcSmem<THREADS, MAXD>& sm) {
+  constexpr int WAVES = WcSmem<THREADS, MAXD>::WAVES;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < WAVES * MAXD / 2; i += THREADS) reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
+  for (int i = tid; i < WAVES * MAXD; i += THREADS) (&sm.lanemask[0][0])[i] = 0;
+}
+
 template <int THREADS, int MAXD, bool HI, bool FULL>
 __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_scatter_wc_kernel(
     const Tup* __restrict__ in, Tup* __restrict__ out, u32 n, u32 n_full, int shift, int bits,
     u32 rows_per_block, u32 worker_base, const u32* __restrict__ hist_scanned,
     const u32* __restrict__ totals, u32 nblk, u64* __restrict__ offsets_out) {
   typedef WcSmem<THREADS, MAXD> Smem;
-  constexpr int TILE = Smem::TILE, WAVES = Smem::WAVES;
+  constexpr int TILE = Smem::TILE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   const u32 D = 1u << bits, mask = D - 1;
@@ -320,8 +482,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
         if ((u32)tid == D - 1) offsets_out[D] = n;
       }
     }
-    for (int i = tid; i < WAVES * MAXD / 2; i += THREADS) reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
-    for (int i = tid; i < WAVES * MAXD; i += THREADS) (&sm.lanemask[0][0])[i] = 0;
+    wc_clear(sm);
   }
   __syncthreads();
 
@@ -335,10 +496,6 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     end = n;
   }
   if (begin >= end) return;
-
-  u16* wc = &sm.wcnt[w][0];
-  u64* lm = &sm.lanemask[w][0];
-  const u64 lanebit = 1ull << lane;
   const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
 
   Tup t[WC_ITEMS];
@@ -346,136 +503,166 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   for (int r = 0; r < WC_ITEMS; r++)
     if (FULL || begin + wbase + r * 64 < end) t[r] = in[begin + wbase + r * 64];
 
+  bool ovf = false;
   for (u64 tile = begin; tile < end; tile += TILE) {
     const u32 tile_n = FULL ? (u32)TILE : (u32)(end - tile);
-    u32 dr[WC_ITEMS];
+    wc_tile<THREADS, MAXD, HI, FULL, false>(
+        sm, t, tile_n, out, shift, mask, D,
+        [&]() {
+          if (FULL && tile + TILE < end) {
+            const Tup* src = in + tile + TILE;
 #pragma unroll
-    for (int r = 0; r < WC_ITEMS; r++) {
-      u32 d = 0, rank = 0;
-      if (FULL || wbase + r * 64 < tile_n) {
-        d = digit_of<HI>(t[r].key, shift, mask);
-        __hip_atomic_fetch_or(&lm[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const u64 m = __hip_atomic_load(&lm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const u32 old = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const u32 below = popc_below(m);
-        if (below == 0) {
-          __hip_atomic_store(&lm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&wc[d], (u16)(old + (u32)__popcll(m)), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        rank = old + below;
-      }
-      dr[r] = (d << 16) | rank;
-    }
-    lds_barrier();
-
-    // per digit: prefix over waves, tile offsets, this tile's flush plan and its 128-byte lines
-    {
-      u32 cnt = 0, nl = 0, pd = 0, cf = 0, fl = 0;
-      if ((u32)tid < D) {
-#pragma unroll
-        for (int k = 0; k < WAVES; k++) {
-          u32 c = sm.wcnt[k][tid];
-          sm.wcnt[k][tid] = (u16)cnt;
-          cnt += c;
-        }
-        pd = sm.pend[tid];
-        cf = sm.cflush[tid];
-        const u32 avail = pd + cnt;
-        const u32 tail = (cf + avail) & (WC_LINE - 1);  // rows past the last whole line
-        fl = (tail >= avail) ? 0u : avail - tail;
-        nl = fl ? (((cf & (WC_LINE - 1)) + fl + WC_LINE - 1) >> 3) : 0u;
-        sm.pend[tid] = avail - fl;
-        sm.cflush[tid] = cf + fl;
-      }
-      u32 tot;
-      const u32 sc = block_excl_scan_u32<THREADS>((nl << 16) | cnt, sm.scratch, &tot);
-      if ((u32)tid < D) {
-        const u32 loff = sc >> 16;
-        sm.tile_off[tid] = sc & 0xFFFFu;
-        sm.cf_tile[tid] = cf;
-        sm.plan[tid] = (fl << 8) | pd;
-        sm.line_off[tid] = loff;
-        for (u32 l = 0; l < nl; l++) sm.line_tab[loff + l] = (u16)tid;
-      }
-      if (tid == 0) sm.total_lines = tot >> 16;
-    }
-    lds_barrier();
-
-#pragma unroll
-    for (int r = 0; r < WC_ITEMS; r++) {
-      if (FULL || wbase + r * 64 < tile_n) {
-        const u32 d = dr[r] >> 16;
-        sm.stage[sm.tile_off[d] + sm.wcnt[w][d] + (dr[r] & 0xFFFFu)] = t[r];
-      }
-    }
-    if (FULL && tile + TILE < end) {
-      const Tup* src = in + tile + TILE;
-#pragma unroll
-      for (int r = 0; r < WC_ITEMS; r++) t[r] = src[wbase + r * 64];
-    }
-    lds_barrier();
-
-    // copy out WHOLE LINES: 8 consecutive lanes own one 128-byte line (carried rows first, then
-    // this tile's rows), so every line leaves in a single store instruction
-    {
-      const u32 TL = sm.total_lines, k = (u32)tid & (WC_LINE - 1);
-      for (u32 L = (u32)tid >> 3; L < TL; L += THREADS / WC_LINE) {
-        const u32 d = sm.line_tab[L];
-        const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu, cfd = sm.cf_tile[d];
-        const u32 grow = (cfd & ~(u32)(WC_LINE - 1)) + (L - sm.line_off[d]) * WC_LINE + k;
-        const u32 j = grow - cfd;  // wraps (huge) for the slots before an unaligned segment start
-        if (j < fl) out[grow] = (j < pd) ? sm.carry[d][j] : sm.stage[sm.tile_off[d] + j - pd];
-      }
-    }
-    // rows that stay behind (each digit's new partial line): stage -> registers
-    u64 keep_k[WC_ITEMS], keep_v[WC_ITEMS];
-    u32 has = 0;
-#pragma unroll
-    for (int q = 0; q < WC_ITEMS; q++) {
-      const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
-      u32 idx = 0;
-      if (d < D && k < sm.pend[d]) {
-        const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu;
-        if (fl != 0 || k >= pd) {
-          idx = sm.tile_off[d] + (fl ? fl - pd + k : k - pd);
-          has |= 1u << q;
-        }
-      }
-      const Tup kv = sm.stage[idx];  // unconditional read (row 0 when nothing stays)
-      keep_k[q] = kv.key;
-      keep_v[q] = kv.val;
-    }
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < WC_ITEMS; q++) {
-      const u32 s = q * THREADS + tid;
-      if (has & (1u << q)) {
-        Tup kv;
-        kv.key = keep_k[q];
-        kv.val = keep_v[q];
-        sm.carry[s >> 3][s & (WC_LINE - 1)] = kv;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < WC_ITEMS; r++) {
-      if (r * THREADS < Smem::ZROWS) {  // hand the slab back to the lane masks as zeros
-        Tup z;
-        z.key = 0;
-        z.val = 0;
-        sm.stage[r * THREADS + tid] = z;
-      }
-    }
-    for (int i = tid; i < WAVES * MAXD / 2; i += THREADS) reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
-    lds_barrier();
+            for (int r = 0; r < WC_ITEMS; r++) t[r] = src[wbase + r * 64];
+          }
+        },
+        nullptr, &ovf);
   }
+  wc_flush_carry(sm, out, D);
+}
 
-  // worker done: whatever still waits in the carry buffers ends this worker's digit segments
-#pragma unroll
-  for (int q = 0; q < WC_ITEMS; q++) {
-    const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
-    if (d < D && k < sm.pend[d]) out[sm.cflush[d] + k] = sm.carry[d][k];
+// ---------------------------------------------------------------------------------------------
+// Slab kernels: the same write-combining scatter WITHOUT a histogram.  Every worker owns a
+// private, over-allocated output region ("slab") per digit, so output positions need no global
+// prefix sums and each pass reads its input exactly once (16 B read + 16 B written per row instead
+// of 16 + 16 + 16).  Slabs hold mean + 8 sigma rows for uniformly distributed digits; a worker whose
+// digit outgrows its slab raises ERR_SLAB and the caller re-runs the exact (histogram) path.
+//
+//   pass A  worker wA = contiguous input rows; writes slabA[dA][wA][CA], cntA[dA][wA]
+//   pass B  worker (dA, k) = the A-slabs [k*WA/KB, (k+1)*WA/KB) of bucket dA, gathered in order
+//           (so the pass stays stable); writes slabB[p][k][CB], cntB[p][k] with p = dB << bitsA | dA
+//   probe   partition p = its KB pieces in order (probe.hip, probe_count_slab_kernel)
+// ---------------------------------------------------------------------------------------------
+template <int THREADS, int MAXD, bool HI>
+__global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_a_kernel(
+    const Tup* __restrict__ in, u32 n, int shift, int bits, u32 rows_per_worker, Tup* __restrict__ slab,
+    u32 CA, u32 WA, u32* __restrict__ cnt_out, u64* __restrict__ accum) {
+  typedef WcSmem<THREADS, MAXD> Smem;
+  constexpr int TILE = Smem::TILE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
+  u32* limit = reinterpret_cast<u32*>(smem_raw + sizeof(Smem));  // MAXD entries
+  const u32 D = 1u << bits, mask = D - 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 worker = blockIdx.x;
+  if ((u32)tid < D) {
+    const u32 base = ((u32)tid * WA + worker) * CA;
+    sm.cflush[tid] = base;
+    limit[tid] = base + CA;
+    sm.pend[tid] = 0;
   }
+  wc_clear(sm);
+  __syncthreads();
+  const u64 begin = (u64)worker * rows_per_worker;
+  u64 end = begin + rows_per_worker;
+  if (end > n) end = n;
+  const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
+  bool ovf = false;
+  if (begin < end) {
+    Tup t[WC_ITEMS];
+    {
+      const u32 tn = (u32)((end - begin < TILE) ? end - begin : TILE);
+#pragma unroll
+      for (int r = 0; r < WC_ITEMS; r++) {
+        const u32 q = wbase + r * 64;
+        t[r] = in[begin + (q < tn ? q : tn - 1)];  // clamped, unpredicated: loads issue back to back
+      }
+    }
+    for (u64 tile = begin; tile < end; tile += TILE) {
+      const u32 tile_n = (u32)((end - tile < TILE) ? end - tile : TILE);
+      wc_tile<THREADS, MAXD, HI, false, true>(
+          sm, t, tile_n, slab, shift, mask, D,
+          [&]() {
+            if (tile + TILE < end) {
+              const u64 nt = tile + TILE;
+              const u32 tn = (u32)((end - nt < TILE) ? end - nt : TILE);
+              const Tup* src = in + nt;
+#pragma unroll
+              for (int r = 0; r < WC_ITEMS; r++) {
+                const u32 q = wbase + r * 64;
+                t[r] = src[q < tn ? q : tn - 1];
+              }
+            }
+          },
+          limit, &ovf);
+    }
+    wc_flush_carry(sm, slab, D);
+  }
+  if ((u32)tid < D) cnt_out[(u32)tid * WA + worker] = sm.cflush[tid] + sm.pend[tid] - ((u32)tid * WA + worker) * CA;
+  if (ovf) atomicOr(&accum[ACC_ERR], ERR_SLAB);
+}
+
+constexpr int SLAB_KB = 4;        // pass-B workers per bucket == pieces per final partition
+constexpr int SLAB_MAXSEG = 512;  // A-slabs one pass-B worker gathers (WA / KB <= 512)
+
+template <int THREADS, int MAXD, bool HI>
+__global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_b_kernel(
+    const Tup* __restrict__ slab_a, const u32* __restrict__ cnt_a, u32 CA, u32 WA, int bits_a, int shift,
+    int bits, Tup* __restrict__ slab_b, u32 CB, u32* __restrict__ cnt_b, u64* __restrict__ accum) {
+  typedef WcSmem<THREADS, MAXD> Smem;
+  constexpr int TILE = Smem::TILE;
+  static_assert(SLAB_MAXSEG <= THREADS, "one A-slab count per thread in the prologue scan");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
+  u32* limit = reinterpret_cast<u32*>(smem_raw + sizeof(Smem));  // MAXD entries
+  u32* pre = limit + MAXD;                                       // SLAB_MAXSEG + 1 prefix sums
+  const u32 D = 1u << bits, mask = D - 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 dA = blockIdx.x / SLAB_KB, k = blockIdx.x % SLAB_KB;
+  const u32 w0 = (u32)((u64)k * WA / SLAB_KB), w1 = (u32)((u64)(k + 1) * WA / SLAB_KB), ns = w1 - w0;
+  {
+    const u32 c = ((u32)tid < ns) ? cnt_a[dA * WA + w0 + tid] : 0;
+    u32 tot;
+    const u32 ex = block_excl_scan_u32<THREADS>(c, sm.scratch, &tot);
+    if ((u32)tid < ns) pre[tid] = ex;
+    if (tid == 0) pre[ns] = tot;
+    if ((u32)tid < D) {
+      const u32 base = ((((u32)tid << bits_a) | dA) * SLAB_KB + k) * CB;
+      sm.cflush[tid] = base;
+      limit[tid] = base + CB;
+      sm.pend[tid] = 0;
+    }
+    wc_clear(sm);
+  }
+  __syncthreads();
+  const u32 total = pre[ns];
+  const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
+  const Tup* __restrict__ bucket = slab_a + (u64)(dA * WA + w0) * CA;  // A-slab j of this worker: + j*CA
+  bool ovf = false;
+  if (total) {
+    u32 seg = 0;  // first A-slab overlapping the tile being loaded (same value in every thread)
+    Tup t[WC_ITEMS];
+    auto load = [&](u32 tile_begin) {
+      const u32 tn = (total - tile_begin < (u32)TILE) ? total - tile_begin : (u32)TILE;
+      while (seg + 1 < ns && pre[seg + 1] <= tile_begin) seg++;
+      u32 s = seg;
+      u64 off[WC_ITEMS];
+#pragma unroll
+      for (int r = 0; r < WC_ITEMS; r++) {
+        u32 q = wbase + r * 64;
+        q = tile_begin + (q < tn ? q : tn - 1);
+        while (s + 1 < ns && pre[s + 1] <= q) s++;
+        off[r] = (u64)s * CA + (q - pre[s]);
+      }
+#pragma unroll
+      for (int r = 0; r < WC_ITEMS; r++) t[r] = bucket[off[r]];
+    };
+    load(0);
+    for (u32 tile = 0; tile < total; tile += TILE) {
+      const u32 tile_n = (total - tile < (u32)TILE) ? total - tile : (u32)TILE;
+      wc_tile<THREADS, MAXD, HI, false, true>(
+          sm, t, tile_n, slab_b, shift, mask, D,
+          [&]() {
+            if (tile + TILE < total) load(tile + TILE);
+          },
+          limit, &ovf);
+    }
+    wc_flush_carry(sm, slab_b, D);
+  }
+  if ((u32)tid < D) {
+    const u32 pid = (((u32)tid << bits_a) | dA) * SLAB_KB + k;
+    cnt_b[pid] = sm.cflush[tid] + sm.pend[tid] - pid * CB;
+  }
+  if (ovf) atomicOr(&accum[ACC_ERR], ERR_SLAB);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -538,6 +725,80 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
     out[0] = acc;
     out[1] = ref;
   }
+}
+
+template <bool HI>
+static hipError_t launch_slab_a_t(const void* in, u32 n, int shift, int bits, u32 rpw, void* slab, u32 CA,
+                                  u32 WA, u32* cnt, u64* accum, hipStream_t st) {
+  typedef WcSmem<512, 256> Smem;
+  const size_t smem = sizeof(Smem) + 256 * sizeof(u32);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(radix_slab_a_kernel<512, 256, HI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((radix_slab_a_kernel<512, 256, HI>), dim3(WA), dim3(512), smem, st,
+                     static_cast<const Tup*>(in), n, shift, bits, rpw, static_cast<Tup*>(slab), CA, WA, cnt,
+                     accum);
+  return hipGetLastError();
+}
+
+template <bool HI>
+static hipError_t launch_slab_b_t(const void* slab_a, const u32* cnt_a, u32 CA, u32 WA, int bits_a, int shift,
+                                  int bits, void* slab_b, u32 CB, u32* cnt_b, u64* accum, hipStream_t st) {
+  typedef WcSmem<512, 256> Smem;
+  const size_t smem = sizeof(Smem) + (256 + SLAB_MAXSEG + 1) * sizeof(u32);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI>), dim3((1u << bits_a) * SLAB_KB), dim3(512), smem, st,
+                     static_cast<const Tup*>(slab_a), cnt_a, CA, WA, bits_a, shift, bits,
+                     static_cast<Tup*>(slab_b), CB, cnt_b, accum);
+  return hipGetLastError();
+}
+
+// Geometry of the slab path for a relation of n rows split by bits_a then bits_b (both <= 8).
+// cap(m) = m + 8 sqrt(m) + 24 rounded up to whole 128-byte lines.
+static u32 slab_cap(double mean) {
+  double c = mean + 8.0 * __builtin_sqrt(mean) + 24.0;
+  return ((u32)c + 8) & ~7u;
+}
+bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g) {
+  const u32 tile = 2048;
+  u64 tiles = ((u64)n + tile - 1) / tile;
+  u64 tpw = (tiles + 2047) / 2048;
+  if (tpw == 0) tpw = 1;
+  g->WA = (u32)((tiles + tpw - 1) / tpw);
+  g->rpw = (u32)(tpw * tile);
+  g->KB = SLAB_KB;
+  if (g->WA < (u32)SLAB_KB || (g->WA + SLAB_KB - 1) / SLAB_KB > (u32)SLAB_MAXSEG) return false;
+  g->CA = slab_cap((double)g->rpw / (double)(1u << bits_a));
+  g->CB = slab_cap((double)n / (double)(1u << bits_a) / SLAB_KB / (double)(1u << bits_b));
+  const u64 rows_a = (u64)(1u << bits_a) * g->WA * g->CA;
+  const u64 rows_b = (u64)(1u << (bits_a + bits_b)) * SLAB_KB * g->CB;
+  g->rows_a = rows_a;
+  g->rows_b = rows_b;
+  return rows_a < 0xFFFFFFF0ull && rows_b < 0xFFFFFFF0ull;
+}
+
+hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a,
+                         u32* cnt_a, u64* accum, hipStream_t st) {
+  return shift >= 32 ? launch_slab_a_t<true>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st)
+                     : launch_slab_a_t<false>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st);
+}
+
+hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
+                         const SlabGeom& g, void* slab_b, u32* cnt_b, u64* accum, hipStream_t st) {
+  return shift >= 32 ? launch_slab_b_t<true>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
+                                             cnt_b, accum, st)
+                     : launch_slab_b_t<false>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
+                                              cnt_b, accum, st);
 }
 
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st) {

@@ -446,3 +446,31 @@ def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
     r = ex.join_host(D, D[::-1].copy(), H.HMJ_ORDERED)
     got = ex.columns_to_numpy(r, host=True)
     assert int(r.n_matches) == nref == 12345 and np.array_equal(got, tref)
+
+
+def test_slab_path_parity_and_fallback(ex, H, oracle):
+    # The histogram-free slab path (plain count joins, >= 2^22 rows per side) against the CPU oracle,
+    # including ragged sizes, a probe side of a different size, and misses.
+    for nb, npb, miss in [(1 << 22, 1 << 22, 0), ((1 << 22) + 12345, (1 << 23) - 777, 3)]:
+        B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=miss)
+        ck, _ = oracle.equijoin(B, P, cap=0)
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), 0)
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"])
+        assert t["ms_hist"] == 0.0 and t["n_scatter_launches"] == 4  # really the slab path: no histogram
+    # skewed digits overflow a slab -> automatic fallback to the exact (histogram) path, same answer
+    n = 1 << 22
+    keys = oracle.gen_build(n)[:, 0]
+    hot = keys.copy()
+    hot[: n // 2] = (hot[: n // 2] & np.uint64((1 << 50) - 1)) | np.uint64(0xABC << 52)  # half the rows in one bucket
+    B = np.stack([hot, np.arange(n, dtype=np.uint64)], 1)
+    P = np.stack([hot[::-1].copy(), np.arange(n, dtype=np.uint64) + np.uint64(9)], 1)
+    ck, _ = oracle.equijoin(B, P, cap=0)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(B), to_dev(P), 0)
+    t = ex.last_timing()
+    ex.set_profiling(False)
+    assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"])
+    assert t["ms_hist"] > 0.0  # the exact path produced this result
