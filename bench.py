@@ -199,7 +199,7 @@ def main():
                        "rows_per_relation_per_gpu": n, "rows_per_relation_total": n_total,
                        "parallelism": "radix-sharded x%d" % world},
             "roofline": dict(roof(sc_bytes, sc_ms, traffic), kernel="radix_scatter_kernel",
-                             launches_per_step=launches // K, kernel_name="radix_scatter_wc_kernel (write-combining stable scatter)"),
+                             launches_per_step=launches // K, kernel_name="radix_slab_a_kernel / radix_slab_b_kernel (write-combining stable scatter, mean of the launches)"),
             "roofline_probe": dict(roof(pr_bytes, pr_ms), kernel="probe_kernel<count>",
                                    probe_tuples_per_s=round(n / (pr_ms * 1e-3)) if pr_ms > 0 else None),
             "phases_ms_per_step": {k[3:]: round(v / K, 4) for k, v in agg.items() if k.startswith("ms_")},

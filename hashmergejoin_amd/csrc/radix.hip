@@ -708,9 +708,9 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
   if (tid == 0) acc = 0;
   __syncthreads();
   u64 x = 0;
-  const u32 sr = nb / 8192 + 1, ss = np / 8192 + 1;
+  const u32 sr = nb / 2048 + 1, ss = np / 2048 + 1;  // ~2048 samples per relation
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < 2; k++) {
     const u64 i = (u64)(tid + k * 1024) * sr, j = (u64)(tid + k * 1024) * ss;
     if (i < nb) x |= rk[2 * i] ^ ref;
     if (j < np) x |= sk[2 * j] ^ ref;
