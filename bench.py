@@ -123,14 +123,15 @@ def main():
             res = ex.join_device(R, S, flags)
             return res, ex.last_timing()
         b = max(hdist.owner_bits(world), 1 if force_dist else 0)
-        recv = []
-        for rel in (R, S):
-            parted, off = ex.partition_device(rel, 64 - b, b)
-            if force_dist:  # one rank: everything is sent to self, as one message
-                off = off[[0, -1]]
-            rows, _ = hdist.exchange_rows(parted, hdist.split_counts_from_offsets(off))
-            recv.append(rows)
-        res = ex.join_device(recv[0], recv[1], flags)  # ex.set_key_prefix_bits(b) was set below
+        if force_dist:  # one rank: everything is sent to self, as one message per relation
+            recv = []
+            for rel in (R, S):
+                parted, off = ex.partition_device(rel, 64 - b, b)
+                rows, _ = hdist.exchange_rows(parted, hdist.split_counts_from_offsets(off[[0, -1]]))
+                recv.append(rows)
+            res = ex.join_device(recv[0], recv[1], flags)
+        else:  # owner split, RCCL all-to-all hidden behind the splits / build-side partitioning, join
+            res = hdist.pipelined_exchange_join(ex, R, S, b, flags)
         return res, ex.last_timing()
 
     for _ in range(a.warmup):

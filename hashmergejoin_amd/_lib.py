@@ -88,6 +88,8 @@ def load_library():
     L.hmj_version.argtypes = []
     L.hmj_join_u64_device.restype = i
     L.hmj_join_u64_device.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult)]
+    L.hmj_prepare_build_u64_device.restype = i
+    L.hmj_prepare_build_u64_device.argtypes = [vp, vp, u, u]
     L.hmj_join_u64.restype = i
     L.hmj_join_u64.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult)]
     L.hmj_join_u64_rows.restype = i

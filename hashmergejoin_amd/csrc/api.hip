@@ -53,6 +53,16 @@ struct hmj_ctx {
   std::vector<HostBuf> up_slots;      // 2 per staging thread
   int force_bits = -1;
   int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
+  // build side partitioned ahead of the join by hmj_prepare_build_u64_device (one-shot)
+  struct Prep {
+    bool valid = false, slab = false;
+    const void* ptr = nullptr;
+    const void* Rp = nullptr;
+    u32 n = 0;
+    int low = 0, B = 0;
+  } prep;
+  bool prepare_only = false;
+  u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
@@ -340,6 +350,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   const bool materialize = flags & HMJ_MATERIALIZE, first = flags & HMJ_FIRST_WINS;
   const bool extra = flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE);
   const u32 nb = (u32)n_build, np = (u32)n_probe;
+  const u32 np_plan = c->prepare_only ? (u32)c->probe_hint : np;  // probe size the plan is made for
 
   int B, passes, pass_bits[4];
   plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
@@ -349,7 +360,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   const u32 target_items = (u32)hmj::probe_default_grid(c->num_cus);
   if (P < target_items) {
     u64 by_grid = (target_items + P - 1) / P;
-    u64 by_rows = ((u64)np / P + hmj::PB_TARGET_AVG - 1) / hmj::PB_TARGET_AVG;
+    u64 by_rows = ((u64)np_plan / P + hmj::PB_TARGET_AVG - 1) / hmj::PB_TARGET_AVG;
     Q = (u32)(by_grid < by_rows ? by_grid : by_rows);
     if (Q < 1) Q = 1;
   }
@@ -388,9 +399,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;
   hmj::SlabGeom gr, gs;
   if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && !materialize && !first && !extra && Q == 1 &&
-      passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && nb >= (1u << 22) && np >= (1u << 22) &&
+      passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && nb >= (1u << 22) && np_plan >= (1u << 22) &&
       hmj::slab_geometry(nb, pass_bits[0], pass_bits[1], &gr) &&
-      hmj::slab_geometry(np, pass_bits[0], pass_bits[1], &gs)) {
+      hmj::slab_geometry(np_plan, pass_bits[0], pass_bits[1], &gs)) {
+    const bool reuse = c->prep.valid && c->prep.slab && c->prep.ptr == R && c->prep.n == nb &&
+                       c->prep.low == low && c->prep.B == B;
+    c->prep.valid = false;  // one-shot; slab_br is about to be (re)written unless reused
     const int ba = pass_bits[0], bb = pass_bits[1];
     const u64 rows_a = gr.rows_a > gs.rows_a ? gr.rows_a : gs.rows_a;
     const u32 wa = gr.WA > gs.WA ? gr.WA : gs.WA;
@@ -404,6 +418,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     struct { const void* in; u32 n; const hmj::SlabGeom* g; void* sb; u32* cb; int rel; } side[2] = {
         {R, nb, &gr, c->slab_br.p, (u32*)c->cnt_br.p, 0}, {S, np, &gs, c->slab_bs.p, (u32*)c->cnt_bs.p, 1}};
     for (auto& sd : side) {
+      if (sd.rel == 0 && reuse) continue;            // build side already in slab_br / cnt_br
+      if (sd.rel == 1 && c->prepare_only) continue;  // hmj_prepare_build: build side only
       int sp = span_begin(c, K_SCATTER, sd.rel);
       HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
       span_end(c, sp);
@@ -412,6 +428,22 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
                                  acc, c->stream));
       span_end(c, sp);
       c->timing.bytes_scatter += 2 * 32ull * sd.n;
+    }
+    u64* hh = (u64*)c->h_accum.p;
+    if (c->prepare_only) {
+      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {
+        c->slab_cooldown = 8;
+        return kRetryNoSlab;
+      }
+      c->prep.valid = true;
+      c->prep.slab = true;
+      c->prep.ptr = R;
+      c->prep.n = nb;
+      c->prep.low = low;
+      c->prep.B = B;
+      return HMJ_OK;
     }
     hmj::ProbeArgs sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -429,7 +461,6 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     HIP_TRY(hmj::launch_probe_count_slab(sa, c->num_cus, c->stream));
     span_end(c, sp);
     c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
-    u64* hh = (u64*)c->h_accum.p;
     HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // skewed digits: remember, and take the exact path
@@ -442,10 +473,31 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     return HMJ_OK;
   }
 
-  if ((rc = partition_relation(c, R, nb, c->rbuf, low, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
+  const bool reuse_exact = c->prep.valid && !c->prep.slab && c->prep.ptr == R && c->prep.n == nb &&
+                           c->prep.low == low && c->prep.B == B;
+  c->prep.valid = false;  // one-shot; rbuf / r_off are about to be (re)written unless reused
+  int s;
+  if (reuse_exact) {
+    Rp = c->prep.Rp;
+  } else {
+    if ((rc = partition_relation(c, R, nb, c->rbuf, low, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
+    s = span_begin(c, K_OFFSETS, -1);
+    HIP_TRY(hmj::launch_part_offsets(Rp, nb, low, B, (u32*)c->r_off.p, c->stream));
+    span_end(c, s);
+  }
+  if (c->prepare_only) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->prep.valid = true;
+    c->prep.slab = false;
+    c->prep.ptr = R;
+    c->prep.Rp = Rp;
+    c->prep.n = nb;
+    c->prep.low = low;
+    c->prep.B = B;
+    return HMJ_OK;
+  }
   if ((rc = partition_relation(c, S, np, c->sbuf, low, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
-  int s = span_begin(c, K_OFFSETS, -1);
-  HIP_TRY(hmj::launch_part_offsets(Rp, nb, low, B, (u32*)c->r_off.p, c->stream));
+  s = span_begin(c, K_OFFSETS, -1);
   HIP_TRY(hmj::launch_part_offsets(Sp, np, low, B, (u32*)c->s_off.p, c->stream));
   span_end(c, s);
 
@@ -715,6 +767,25 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
   return HMJ_OK;
 }
 
+int hmj_prepare_build_u64_device(hmj_ctx* c, const void* build_aos_dev, uint64_t n_build,
+                                 uint64_t n_probe_hint) {
+  if (!c) return HMJ_E_ARG;
+  if (n_probe_hint > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "too many rows");
+  HIP_TRY(hipSetDevice(c->device));
+  spans_reset(c);
+  hmj_result dummy;
+  c->prepare_only = true;
+  c->probe_hint = n_probe_hint;
+  c->prep.valid = false;
+  int rc = join_device(c, build_aos_dev, n_build, nullptr, 0, 0, &dummy, false);
+  c->prepare_only = false;
+  if (c->profiling) {
+    (void)hipStreamSynchronize(c->stream);
+    spans_collect(c);
+  }
+  return rc;
+}
+
 int hmj_join_u64_device(hmj_ctx* c, const void* build_aos_dev, uint64_t n_build,
                         const void* probe_aos_dev, uint64_t n_probe, uint32_t flags,
                         hmj_result* out) {
@@ -848,6 +919,7 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
   HIP_TRY(hipSetDevice(c->device));
   spans_reset(c);
   if (n == 0) return HMJ_OK;
+  c->prep.valid = false;  // rbuf[0] is the sort's ping-pong buffer
   if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
   const void* src = in_aos_dev;
   for (int pass = 0; pass < 8; pass++) {  // LSD: bits [8*pass, 8*pass+8); even passes land in tmp

@@ -46,6 +46,25 @@ def exchange_rows(parted, send_counts, group=None):
     return out, recv_counts
 
 
+def exchange_rows_async(parted, send_counts, group=None):
+    """Like exchange_rows but returns (rows, work) right after queueing the data exchange: the caller
+    overlaps other GPU work and calls work.wait() (a stream wait, not a host wait) before using rows.
+    The small counts exchange stays synchronous (the receive size must be known to allocate)."""
+    world = dist.get_world_size(group)
+    assert len(send_counts) == world and sum(send_counts) == parted.shape[0]
+    if dist.get_backend(group) != "nccl" or not parted.is_cuda:
+        rows, _ = exchange_rows(parted, send_counts, group)
+        return rows, None
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=parted.device)
+    rc = torch.empty(world, dtype=torch.int64, device=parted.device)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.tolist()]
+    out = torch.empty((sum(recv_counts), 2), dtype=parted.dtype, device=parted.device)
+    work = dist.all_to_all_single(out, parted.contiguous(), output_split_sizes=recv_counts,
+                                  input_split_sizes=list(send_counts), group=group, async_op=True)
+    return out, work
+
+
 def allreduce_checks(local, device, group=None):
     """local: dict n_matches/sum_r/sum_s/xor_fold/mix_sum (python ints mod 2^64) -> global dict.
     Sums wrap mod 2^64 (two's complement int64 add); the xor is folded after an all_gather."""
@@ -79,6 +98,24 @@ def allreduce_checks(local, device, group=None):
     return out
 
 
+def pipelined_exchange_join(ex, r_shard, s_shard, b, flags=0, group=None):
+    """Owner split + exchange + local join with the exchange hidden behind GPU work:
+         split R | exchange R  || split S | exchange S || partition received R | ... probe
+    (|| = runs concurrently: RCCL on its stream, the HIP kernels on the current stream).
+    The caller has set ex.set_key_prefix_bits(b)."""
+    parted_r, off_r = ex.partition_device(r_shard, 64 - b, b)
+    rows_r, work_r = exchange_rows_async(parted_r, split_counts_from_offsets(off_r), group)
+    parted_s, off_s = ex.partition_device(s_shard, 64 - b, b)   # overlaps the exchange of R
+    rows_s, work_s = exchange_rows_async(parted_s, split_counts_from_offsets(off_s), group)
+    if work_r is not None:
+        work_r.wait()
+    if flags == 0:
+        ex.prepare_build(rows_r, rows_s.shape[0])               # overlaps the exchange of S
+    if work_s is not None:
+        work_s.wait()
+    return ex.join_device(rows_r, rows_s, flags)
+
+
 def distributed_join(ex, r_shard, s_shard, flags=0, group=None):
     """Each rank holds a row shard of R (build) and S (probe) on its GPU.  Returns
     (local JoinResult for this rank's key range, global checks dict)."""
@@ -87,14 +124,9 @@ def distributed_join(ex, r_shard, s_shard, flags=0, group=None):
         res = ex.join_device(r_shard, s_shard, flags)
         return res, res.checks()
     b = owner_bits(world)
-    recv = []
-    for rel in (r_shard, s_shard):
-        parted, off = ex.partition_device(rel, 64 - b, b)
-        rows, _ = exchange_rows(parted, split_counts_from_offsets(off), group)
-        recv.append(rows)
     ex.set_key_prefix_bits(b)  # every row received here carries this rank's owner bits on top
     try:
-        res = ex.join_device(recv[0], recv[1], flags)
+        res = pipelined_exchange_join(ex, r_shard, s_shard, b, flags, group)
     finally:
         ex.set_key_prefix_bits(-1)
     return res, allreduce_checks(res.checks(), r_shard.device, group)

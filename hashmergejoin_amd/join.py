@@ -108,6 +108,12 @@ class Executor:
         self._check(self.L.hmj_join_u64_device(self.h, C.c_void_p(bp), nb, C.c_void_p(pp), np_, flags, C.byref(res)))
         return res
 
+    def prepare_build(self, build, n_probe_hint):
+        """Partition the build side now; the next matching plain-count join_device skips that work."""
+        self._sync_stream()
+        bp, nb = _dev_ptr(build)
+        self._check(self.L.hmj_prepare_build_u64_device(self.h, C.c_void_p(bp), nb, n_probe_hint))
+
     def join_host(self, build, probe, flags=0):
         """build/probe: numpy uint64 [n,2] in host memory (the reference ctor's situation)."""
         self._sync_stream()

@@ -132,6 +132,14 @@ const char* hmj_version(void);
 int hmj_join_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_build,
                         const void* probe_aos_dev, uint64_t n_probe, uint32_t flags,
                         hmj_result* out);
+/* Partition the build side ahead of the join (e.g. while the probe side is still arriving over
+ * xGMI).  One-shot: the NEXT hmj_join_u64_device on this ctx whose build pointer, row count and plan
+ * match, and whose flags are plain count mode (flags == 0), skips re-partitioning R; any other call
+ * discards the prepared state.  The caller promises the build rows do not change in between.
+ * n_probe_hint: the probe size the join will have (it selects the partitioning path).
+ * Corresponds to the first radix_non_inplace_par call of the reference ctor (hashjoin.h:65).       */
+int hmj_prepare_build_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_build,
+                                 uint64_t n_probe_hint);
 /* Same with host-resident relations (what a caller of the reference's ctor holds: pointers into
  * std::vector<std::pair<uint64_t,uint64_t>>).  Copies in over PCIe, joins, copies results out.   */
 int hmj_join_u64(hmj_ctx* ctx, const void* build_aos_host, uint64_t n_build,

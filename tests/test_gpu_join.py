@@ -474,3 +474,24 @@ def test_slab_path_parity_and_fallback(ex, H, oracle):
     ex.set_profiling(False)
     assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"])
     assert t["ms_hist"] > 0.0  # the exact path produced this result
+
+
+def test_prepared_build_side(ex, H, oracle):
+    # hmj_prepare_build_u64_device: partition R ahead of the join (one-shot), for both partitioning paths
+    for nb, npb in [(1 << 22, (1 << 22) + 999), (300000, 200000)]:
+        B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=4)
+        ck, _ = oracle.equijoin(B, P, cap=0)
+        bd, pd = to_dev(B), to_dev(P)
+        ex.set_profiling(True)
+        ex.prepare_build(bd, npb)
+        r = ex.join_device(bd, pd, 0)
+        t = ex.last_timing()
+        assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"])
+        assert t["ms_partition_build"] == 0.0 and t["ms_partition_probe"] > 0.0  # build side was reused
+        r = ex.join_device(bd, pd, 0)  # one-shot: the next join partitions R again
+        assert ex.last_timing()["ms_partition_build"] > 0.0 and int(r.n_matches) == ck["n_matches"]
+        # a prepared build side is ignored (not misused) when the join needs another plan
+        ex.prepare_build(bd, npb)
+        r = ex.join_device(bd, pd, H.HMJ_CHECKSUM)
+        assert r.checks() == ck
+        ex.set_profiling(False)
