@@ -763,6 +763,25 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
     if ((rc = ensure_dev(c, c->out_key, max_matches * 8)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->out_rval, max_matches * 8)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->out_sval, max_matches * 8)) != HMJ_OK) return rc;
+    if (flags & HMJ_ORDERED) {
+      if ((rc = ensure_dev(c, c->ord_key, max_matches * 8)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->ord_rval, max_matches * 8)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->ord_sval, max_matches * 8)) != HMJ_OK) return rc;
+    }
+  } else if (c->slab_mode && passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8) {
+    hmj::SlabGeom gr, gs;  // plain count joins of large relations take the slab path
+    if (n_build >= (1u << 22) && n_probe >= (1u << 22) &&
+        hmj::slab_geometry((u32)n_build, pass_bits[0], pass_bits[1], &gr) &&
+        hmj::slab_geometry((u32)n_probe, pass_bits[0], pass_bits[1], &gs)) {
+      const u64 rows_a = gr.rows_a > gs.rows_a ? gr.rows_a : gs.rows_a;
+      const u32 wa = gr.WA > gs.WA ? gr.WA : gs.WA;
+      if ((rc = ensure_dev(c, c->slab_a, rows_a * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_a, ((size_t)wa << pass_bits[0]) * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->slab_br, gr.rows_b * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->slab_bs, gs.rows_b * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_br, P * 4 * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_bs, P * 4 * 4)) != HMJ_OK) return rc;
+    }
   }
   return HMJ_OK;
 }

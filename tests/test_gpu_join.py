@@ -495,3 +495,33 @@ def test_prepared_build_side(ex, H, oracle):
         r = ex.join_device(bd, pd, H.HMJ_CHECKSUM)
         assert r.checks() == ck
         ex.set_profiling(False)
+
+
+def test_argument_errors(ex, H):
+    # the reference has no error handling (assert / UB, strgen.cc:60); the ABI reports instead of crashing
+    import ctypes as C
+
+    import torch
+
+    L = ex.L
+    res = H.JoinResult()
+    good = torch.zeros((8, 2), dtype=torch.int64, device="cuda")
+    # misaligned relation pointer
+    rc = L.hmj_join_u64_device(ex.h, C.c_void_p(good.data_ptr() + 8), 4, C.c_void_p(good.data_ptr()), 4, 0, C.byref(res))
+    assert rc == -1 and b"aligned" in L.hmj_last_error(ex.h)
+    # NULL relation with rows, NULL out
+    assert L.hmj_join_u64_device(ex.h, None, 4, C.c_void_p(good.data_ptr()), 4, 0, C.byref(res)) == -1
+    assert L.hmj_join_u64_device(ex.h, C.c_void_p(good.data_ptr()), 4, C.c_void_p(good.data_ptr()), 4, 0, None) == -1
+    # more rows than one call takes
+    assert L.hmj_join_u64_device(ex.h, C.c_void_p(good.data_ptr()), 1 << 33, C.c_void_p(good.data_ptr()), 4, 0, C.byref(res)) == -1
+    # bad radix pass parameters
+    off = torch.zeros(1025, dtype=torch.int64, device="cuda")
+    assert L.hmj_partition_u64_device(ex.h, C.c_void_p(good.data_ptr()), 8, 60, 10, C.c_void_p(good.data_ptr()), C.c_void_p(off.data_ptr())) == -1
+    assert L.hmj_partition_u64_device(ex.h, C.c_void_p(good.data_ptr()), 8, 60, 8, C.c_void_p(good.data_ptr()), C.c_void_p(off.data_ptr())) == -1  # shift+bits > 64
+    assert L.hmj_set_radix_bits(ex.h, 40) == -1 and L.hmj_set_key_prefix_bits(ex.h, 60) == -1
+    # the ctx is still usable afterwards
+    r = ex.join_device(good, good, 0)
+    assert int(r.n_matches) == 64  # 8 x 8 rows, all keys 0: cross product
+    # reserve pre-allocates for the stated sizes and joins still work
+    ex.reserve(1 << 20, 1 << 20, 1 << 20, H.HMJ_ORDERED)
+    assert int(ex.join_device(ex.gen_build(1 << 20), ex.gen_probe(1 << 20, 1 << 20), H.HMJ_ORDERED).n_matches) == 1 << 20
