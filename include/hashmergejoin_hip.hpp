@@ -15,11 +15,12 @@
 // object lives (the reference points into its sorted copies; this class points into its result
 // columns).  Rows come in ascending key order, as the reference's do.
 //
-// Host code only: compile with any C++11 compiler and link -lhmj_hip.  The GPU path handles
-// Key = uint64_t with 8-byte trivially copyable payloads in contiguous storage
-// (std::vector<std::pair<uint64_t,V>>); other instantiations do not compile --
-// there is deliberately no CPU fallback in this library.  Errors (the reference has none:
-// assert/UB) surface as std::runtime_error.
+// Host code only: compile with any C++11 compiler and link -lhmj_hip.  Key = uint64_t with 8-byte
+// trivially copyable payloads in contiguous storage (std::vector<std::pair<uint64_t,V>>, SURVEY.md
+// D4) goes to the GPU as is.  Any other hashable key type (std::string, the reference's KeyValVec)
+// is hashed on the host with std::hash<Key> -- as the reference does -- and joined on the GPU as
+// {hash, row index} rows.  The join itself always runs on the GPU: there is no CPU join path.
+// Errors (the reference has none: assert/UB) surface as std::runtime_error.
 //
 // Semantics note: relational equi-join.  Identical to the reference for relations whose keys are
 // unique per relation (what its generator produces, strgen_test.cc:24-33); with duplicate keys
@@ -28,12 +29,15 @@
 #ifndef HASHMERGEJOIN_HIP_HPP
 #define HASHMERGEJOIN_HIP_HPP 1
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <iterator>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -76,15 +80,21 @@ struct is_hmj_relation_iter {
 
 }  // namespace hmj_detail
 
+// Primary template.  Native == true : uint64_t keys with 8-byte payloads in contiguous storage go to the
+//                                       GPU as they are (the path BASELINE.json names).
+//                    Native == false: any other key type with std::hash / == / < (e.g. the reference's
+//                                       KeyValVec of std::string keys, hashjoin.h:29): see below.
+template <typename RIter, typename SIter,
+          bool Native = hmj_detail::is_hmj_relation_iter<RIter>::value && hmj_detail::is_hmj_relation_iter<SIter>::value>
+class HashMergeJoin;
+
 template <typename RIter, typename SIter>
-class HashMergeJoin {
+class HashMergeJoin<RIter, SIter, true> {
   static_assert(std::is_same<typename RIter::value_type::first_type,
                              typename SIter::value_type::first_type>::value,
                 "RIter and SIter key type must be the same");
   static_assert(std::is_same<typename RIter::difference_type, typename SIter::difference_type>::value,
                 "RIter and SIter difference type must be the same");
-  static_assert(hmj_detail::is_hmj_relation_iter<RIter>::value && hmj_detail::is_hmj_relation_iter<SIter>::value,
-                "the MI355X executor joins contiguous std::pair<uint64_t, 8-byte payload> relations");
 
   typedef typename RIter::difference_type distance_type;
   typedef typename RIter::value_type::first_type Key;
@@ -162,6 +172,147 @@ class HashMergeJoin {
   Key* _key = nullptr;
   RValue* _rval = nullptr;
   SValue* _sval = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Keys of any hashable type (the reference's own benchmark joins std::string keys,
+// hashjoin_bench.cc:109-143).  The reference sorts (hash, key, value) tuples by std::hash<Key>
+// (hashjoin.h:65-67 -> radix_hash.h:314) and merges on (hash, key).  Here the host computes the same
+// std::hash<Key> once per row (the reference computes it twice, radix_hash.h:314,340) with
+// `num_threads` threads, the GPU joins the 16-byte rows {hash, row index} in hash order, and the host
+// drops the (astronomically rare) pairs whose 64-bit hashes collide on different keys.  Iteration order
+// is the reference's: ascending hash, then key.  operator* points at the key and payloads INSIDE THE
+// CALLER'S RELATIONS (the reference points into its sorted copies), so they must outlive the join.
+// ---------------------------------------------------------------------------------------------------
+template <typename RIter, typename SIter>
+class HashMergeJoin<RIter, SIter, false> {
+  static_assert(std::is_same<typename RIter::value_type::first_type,
+                             typename SIter::value_type::first_type>::value,
+                "RIter and SIter key type must be the same");
+  static_assert(std::is_same<typename RIter::difference_type, typename SIter::difference_type>::value,
+                "RIter and SIter difference type must be the same");
+  static_assert(std::is_base_of<std::random_access_iterator_tag,
+                                typename std::iterator_traits<RIter>::iterator_category>::value &&
+                    std::is_base_of<std::random_access_iterator_tag,
+                                    typename std::iterator_traits<SIter>::iterator_category>::value,
+                "random access iterators are required");
+
+  typedef typename RIter::difference_type distance_type;
+  typedef typename RIter::value_type::first_type Key;
+  typedef typename RIter::value_type::second_type RValue;
+  typedef typename SIter::value_type::second_type SValue;
+
+  template <typename Iter>
+  static void hash_rows(Iter begin, std::size_t n, std::vector<std::pair<std::uint64_t, std::uint64_t>>& out,
+                        unsigned threads) {
+    out.resize(n);
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    auto work = [&](std::size_t b, std::size_t e) {
+      std::hash<Key> h;
+      for (std::size_t i = b; i < e; i++) out[i] = std::make_pair((std::uint64_t)h(begin[i].first), (std::uint64_t)i);
+    };
+    if (threads == 1 || n < 65536) {
+      work(0, n);
+      return;
+    }
+    std::vector<std::thread> th;
+    const std::size_t per = (n + threads - 1) / threads;
+    for (unsigned t = 0; t < threads; t++) {
+      const std::size_t b = t * per, e = b + per < n ? b + per : n;
+      if (b < e) th.emplace_back(work, b, e);
+    }
+    for (auto& x : th) x.join();
+  }
+
+ public:
+  HashMergeJoin() = default;
+  HashMergeJoin(RIter r_begin, RIter r_end, SIter s_begin, SIter s_end, unsigned int num_threads = 1)
+      : _r(r_begin), _s(s_begin) {
+    const std::size_t nr = (std::size_t)std::distance(r_begin, r_end), ns = (std::size_t)std::distance(s_begin, s_end);
+    std::vector<std::pair<std::uint64_t, std::uint64_t>> hr, hs;
+    hash_rows(r_begin, nr, hr, num_threads);
+    hash_rows(s_begin, ns, hs, num_threads);
+    hmj_ctx* c = hmj_detail::thread_ctx();
+    hmj_set_host_threads(c, num_threads > 16 ? 16 : (int)num_threads);
+    hmj_result res;
+    hmj_rows* rows = nullptr;
+    hmj_detail::check(c, hmj_join_u64_rows(c, nr ? hr.data() : nullptr, nr, ns ? hs.data() : nullptr, ns,
+                                           HMJ_MATERIALIZE | HMJ_ORDERED, &res, &rows), "hmj_join_u64_rows");
+    std::shared_ptr<hmj_rows> guard(rows, hmj_rows_free);
+    // rows are (hash, r index, s index) in ascending (hash, r index, s index).  Keep the pairs whose
+    // KEYS are equal; inside a run of equal hashes order by key, as the reference's sort does
+    // (radix_hash.h:86-109 breaks hash ties on the key).
+    const std::size_t n = (std::size_t)res.n_matches;
+    _ri.reserve(n);
+    _si.reserve(n);
+    std::size_t i = 0;
+    while (i < n) {
+      std::size_t j = i + 1;
+      while (j < n && res.key[j] == res.key[i]) j++;
+      const std::size_t first = _ri.size();
+      for (std::size_t k = i; k < j; k++)
+        if (r_begin[res.rval[k]].first == s_begin[res.sval[k]].first) {
+          _ri.push_back(res.rval[k]);
+          _si.push_back(res.sval[k]);
+        }
+      if (_ri.size() - first > 1) {  // several rows share this hash: order them by key
+        std::vector<std::pair<std::uint64_t, std::uint64_t>> grp;
+        for (std::size_t k = first; k < _ri.size(); k++) grp.emplace_back(_ri[k], _si[k]);
+        std::stable_sort(grp.begin(), grp.end(),
+                         [&](const std::pair<std::uint64_t, std::uint64_t>& a,
+                             const std::pair<std::uint64_t, std::uint64_t>& b) {
+                           return r_begin[a.first].first < r_begin[b.first].first;
+                         });
+        for (std::size_t k = 0; k < grp.size(); k++) {
+          _ri[first + k] = grp[k].first;
+          _si[first + k] = grp[k].second;
+        }
+      }
+      i = j;
+    }
+  }
+
+  class iterator : public std::iterator<std::input_iterator_tag, std::tuple<Key*, RValue*, SValue*>> {
+   public:
+    iterator(HashMergeJoin* owner, std::size_t pos) : _owner(owner), _pos(pos) {}
+    iterator& operator++() {
+      ++_pos;
+      return *this;
+    }
+    iterator operator++(int) {
+      iterator retval = *this;
+      ++(*this);
+      return retval;
+    }
+    bool operator==(iterator other) const { return _pos == other._pos; }
+    bool operator!=(iterator other) const { return _pos != other._pos; }
+    std::tuple<Key*, RValue*, SValue*>& operator*() {
+      const typename RIter::value_type& rr = _owner->_r[_owner->_ri[_pos]];
+      const typename SIter::value_type& ss = _owner->_s[_owner->_si[_pos]];
+      tmp_val = std::make_tuple(const_cast<Key*>(&rr.first), const_cast<RValue*>(&rr.second),
+                                const_cast<SValue*>(&ss.second));
+      return tmp_val;
+    }
+
+   protected:
+    HashMergeJoin* _owner;
+    std::size_t _pos;
+    std::tuple<Key*, RValue*, SValue*> tmp_val;
+  };
+
+  iterator begin() { return iterator(this, 0); }
+  iterator end() { return iterator(this, _ri.size()); }
+  void clear() {
+    _ri.clear();
+    _si.clear();
+  }
+  std::size_t size() const { return _ri.size(); }
+
+ protected:
+  RIter _r;
+  SIter _s;
+  std::vector<std::uint64_t> _ri, _si;  // matching row indices into the caller's relations
 };
 
 // Convenience spelled the way BASELINE.json's north_star names the entry point.

@@ -245,6 +245,8 @@ class Reference:
         L.ref_partitioned_hash_table_sizes_u64.argtypes = [vp, u, i, i, vp]
         L.ref_partitioned_join_sum_u64.restype = u
         L.ref_partitioned_join_sum_u64.argtypes = [vp, u, vp, u, i, i, vp]
+        L.ref_hashmergejoin_str.restype = u
+        L.ref_hashmergejoin_str.argtypes = [u, u, u, ui, vp, u, vp]
         L.ref_hashmergejoin2_u64.restype = u
         L.ref_hashmergejoin2_u64.argtypes = [vp, u, vp, u, ui, vp, u, vp]
 
@@ -319,6 +321,14 @@ class Reference:
                                                       len(build), threads, bits,
                                                       C.cast(C.byref(f), _U64P)))
         return s, int(f.value)
+
+    def hashmergejoin_str(self, nr, ns, seed, threads=1):
+        """Reference HashMergeJoin over synthetic std::string-keyed relations (ref_driver.cc)."""
+        cap = nr + ns + 1
+        pairs = np.zeros((cap, 2), np.uint64)
+        sm = C.c_uint64(0)
+        n = int(self.lib.ref_hashmergejoin_str(nr, ns, seed, threads, _p(pairs), cap, C.cast(C.byref(sm), _U64P)))
+        return n, int(sm.value), pairs[:n]
 
     # opaque PairVec handles so a timed region excludes the AoS->vector conversion
     def pairs_new(self, aos):

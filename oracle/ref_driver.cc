@@ -244,4 +244,41 @@ uint64_t ref_hashmergejoin2_u64(uint64_t* r_hkv, uint64_t nr, uint64_t* s_hkv, u
   return cnt;
 }
 
+// String keys: the reference's own benchmark type (KeyValVec = vector<pair<string,uint64_t>>,
+// hashjoin.h:29; hashjoin_bench.cc:109-143).  strgen needs /usr/share/dict/words (absent), so the
+// relations come from a synthetic generator of the same shape ("word-word" keys, unique, shuffled);
+// tests/cpp/test_dropin.cc generates the identical relations.  Writes at most cap (rval, sval) pairs
+// in iteration order; returns the number of tuples yielded.
+static inline uint64_t drv_mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return x;
+}
+static std::string drv_synth_key(uint64_t i, uint64_t seed) {
+  return "w" + std::to_string(drv_mix64(i + seed) % 1000003ull) + "-" + std::to_string(i);
+}
+uint64_t ref_hashmergejoin_str(uint64_t nr, uint64_t ns, uint64_t seed, unsigned threads, uint64_t* pairs,
+                               uint64_t cap, uint64_t* sum_out) {
+  KeyValVec r(nr), s(ns);
+  for (uint64_t k = 0; k < nr; k++) {
+    uint64_t i = (2654435761ull * k + 1) % nr;
+    r[k] = std::make_pair(drv_synth_key(i, seed), i);
+  }
+  for (uint64_t k = 0; k < ns; k++) {
+    uint64_t i = (40503ull * k + 5) % ns;
+    s[k] = std::make_pair(drv_synth_key(nr / 2 + i, seed), 7 * i + 3);
+  }
+  HashMergeJoin<KeyValVec::iterator, KeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), threads);
+  uint64_t cnt = 0, sum = 0;
+  for (auto t : hmj) {
+    if (pairs && cnt < cap) {
+      pairs[2 * cnt] = *std::get<1>(t);
+      pairs[2 * cnt + 1] = *std::get<2>(t);
+    }
+    sum += *std::get<1>(t) + *std::get<2>(t);
+    cnt++;
+  }
+  if (sum_out) *sum_out = sum;
+  return cnt;
+}
+
 }  // extern "C"

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -69,6 +70,44 @@ static int run_case(uint64_t nb, uint64_t np, uint64_t miss, bool time_it) {
   return 0;
 }
 
+// ---- std::string keys: the reference's own benchmark type (KeyValVec, hashjoin.h:29).  The same
+// synthetic strgen-shaped relations as oracle/ref_driver.cc ref_hashmergejoin_str; the expected
+// count / sum / ordered FNV come from the compiled reference (tests/golden/golden.json) and are
+// compared by tests/test_gpu_join.py::test_cpp_dropin_operator from the STR lines printed here.
+typedef std::vector<std::pair<std::string, uint64_t>> StrKeyValVec;
+static std::string synth_key(uint64_t i, uint64_t seed) {
+  return "w" + std::to_string(orc_mix64(i + seed) % 1000003ull) + "-" + std::to_string(i);
+}
+static void run_string_case(uint64_t nr, uint64_t ns, uint64_t seed) {
+  StrKeyValVec r(nr), s(ns);
+  for (uint64_t k = 0; k < nr; k++) {
+    uint64_t i = (2654435761ull * k + 1) % nr;
+    r[k] = std::make_pair(synth_key(i, seed), i);
+  }
+  for (uint64_t k = 0; k < ns; k++) {
+    uint64_t i = (40503ull * k + 5) % ns;
+    s[k] = std::make_pair(synth_key(nr / 2 + i, seed), 7 * i + 3);
+  }
+  HashMergeJoin<StrKeyValVec::iterator, StrKeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), 4);
+  uint64_t cnt = 0, sum = 0, fnv = 0xCBF29CE484222325ull;
+  bool keys_ok = true;
+  for (auto tuple : hmj) {
+    const uint64_t rv = *std::get<1>(tuple), sv = *std::get<2>(tuple);
+    sum += rv + sv;
+    cnt++;
+    keys_ok = keys_ok && *std::get<0>(tuple) == synth_key(rv, seed);  // the key handed out is the row's key
+    const uint64_t w[2] = {rv, sv};
+    for (int q = 0; q < 2; q++)
+      for (int b = 0; b < 8; b++) {
+        fnv ^= (w[q] >> (8 * b)) & 0xFF;
+        fnv *= 0x100000001B3ull;
+      }
+  }
+  std::printf("STR %llu %llu %llu count=%llu sum=%llu fnv=%llu keys_ok=%d\n", (unsigned long long)nr,
+              (unsigned long long)ns, (unsigned long long)seed, (unsigned long long)cnt, (unsigned long long)sum,
+              (unsigned long long)fnv, keys_ok ? 1 : 0);
+}
+
 int main() {
   int fails = 0;
   fails += run_case(0, 0, 0, false);
@@ -80,6 +119,9 @@ int main() {
   fails += run_case(1 << 16, 1 << 16, 2, false);
   fails += run_case(1 << 20, 1 << 20, 0, true);
   fails += run_case(1 << 22, 1 << 22, 0, true);
+  run_string_case(1000, 1000, 1);
+  run_string_case(5000, 3000, 2);
+  run_string_case(200000, 150000, 3);
   std::printf(fails ? "FAILED\n" : "all drop-in cases passed\n");
   return fails ? 1 : 0;
 }

@@ -132,6 +132,12 @@ for nb, npb, dom in [(200, 300, 50), (5000, 8000, 1200), (1 << 14, 1 << 15, 3000
     C["dup_partitioned"].append({"file": name, "psum": s, "pfound": f, "hmj_n": n, "hmj_sum": sm,
                                  "hmj_fnv": o.fnv1a_triples(t)})
 
+# (7) std::string keys through the reference (synthetic strgen-shaped relations, ref_driver.cc) -----
+C["string_join"] = []
+for nr, ns, seed in [(1000, 1000, 1), (5000, 3000, 2), (200000, 150000, 3)]:
+    n, sm, pairs = ref.hashmergejoin_str(nr, ns, seed, 4)
+    C["string_join"].append({"nr": nr, "ns": ns, "seed": seed, "n": n, "sum": sm, "fnv_pairs": fnv_rows(pairs)})
+
 # optimal_partition table --------------------------------------------------------------------------
 ns = [0, 1, 5, 63, 64, 65, 1000, 4095, 4096, 12345, 10 ** 6, 1 << 16, 1 << 18, 1 << 20, 1 << 24, 1 << 26, 1 << 28, 1 << 30, 1 << 31,
       10 ** 7, 10 ** 9]

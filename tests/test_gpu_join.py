@@ -281,7 +281,7 @@ def test_full_size_closed_form(ex, H, log2n):
     ex.release_result()
 
 
-def test_cpp_dropin_operator():
+def test_cpp_dropin_operator(G):
     # the C++ HashMergeJoin<RIter,SIter> drop-in (include/hashmergejoin_hip.hpp), built host-only
     # with g++ against the C ABI, driven exactly like hashjoin_bench.cc:109-143
     import subprocess
@@ -291,6 +291,16 @@ def test_cpp_dropin_operator():
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     txt = out.stdout.decode()
     assert out.returncode == 0 and "all drop-in cases passed" in txt, txt
+    # std::string keys (the reference's KeyValVec): count, sum and iteration order as the compiled
+    # reference produced them for the same relations (tests/golden/make_golden.py, string_join)
+    got = {}
+    for line in txt.splitlines():
+        if line.startswith("STR "):
+            f = line.split()
+            got[(int(f[1]), int(f[2]), int(f[3]))] = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in f[4:]}
+    for c in G["string_join"]:
+        g = got[(c["nr"], c["ns"], c["seed"])]
+        assert (g["count"], g["sum"], g["fnv"], g["keys_ok"]) == (c["n"], c["sum"], c["fnv_pairs"], 1), (c, g)
 
 
 def test_inputs_written_on_the_torch_stream_are_ordered(ex, oracle):
