@@ -535,3 +535,55 @@ def test_argument_errors(ex, H):
     # reserve pre-allocates for the stated sizes and joins still work
     ex.reserve(1 << 20, 1 << 20, 1 << 20, H.HMJ_ORDERED)
     assert int(ex.join_device(ex.gen_build(1 << 20), ex.gen_probe(1 << 20, 1 << 20), H.HMJ_ORDERED).n_matches) == 1 << 20
+
+
+def test_randomized_shapes_and_flags(ex, H, oracle):
+    # seeded sweep over sizes around the tile / table / slice boundaries, key distributions (uniform,
+    # dense, duplicate-heavy, sorted, clustered in few digits) and every flag combination
+    rng = np.random.default_rng(20251003)
+    sizes = [1, 2, 63, 64, 65, 511, 2047, 2048, 2049, 4095, 4096, 4097, 5119, 5120, 5121, 8191, 10240, 12288,
+             20000, 65535, 65536, 65537, 100000, 262144, 300001]
+    flag_sets = [0, H.HMJ_CHECKSUM, H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_ORDERED | H.HMJ_CHECKSUM,
+                 H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, H.HMJ_FIRST_WINS | H.HMJ_ORDERED,
+                 H.HMJ_ORDERED | H.HMJ_SUM_PROBE]
+
+    def keys(kind, n, dom):
+        if kind == "uniform":
+            return rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+        if kind == "dense":
+            return rng.integers(0, dom, size=n, dtype=np.uint64)
+        if kind == "dups":
+            return np.array([oracle.mix64(int(x)) for x in rng.integers(0, max(2, dom // 50), size=n)], np.uint64) if n < 5000 else \
+                (rng.integers(0, max(2, dom // 50), size=n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        if kind == "sorted":
+            return np.sort(rng.integers(0, 1 << 63, size=n, dtype=np.uint64))
+        # clustered: only a few values of the top bits occur
+        return (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(61)) | rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
+
+    for it in range(70):
+        nb, npb = int(rng.choice(sizes)), int(rng.choice(sizes))
+        kind = str(rng.choice(["uniform", "dense", "dups", "sorted", "clustered"]))
+        dom = int(rng.choice([97, 5000, 1 << 20]))
+        kb = keys(kind, nb, dom)
+        # probe keys: a mix of build keys (matches) and fresh keys of the same distribution
+        kp = np.where(rng.random(npb) < 0.6, kb[rng.integers(0, nb, size=npb)], keys(kind, npb, dom))
+        B = np.stack([kb, rng.integers(0, 1 << 62, size=nb, dtype=np.uint64)], 1)
+        P = np.stack([kp, rng.integers(0, 1 << 62, size=npb, dtype=np.uint64)], 1)
+        fl = int(rng.choice(flag_sets))
+        first = bool(fl & H.HMJ_FIRST_WINS)
+        ck, rows = oracle.equijoin(B, P, first_wins=first)
+        if ck["n_matches"] > 30_000_000:
+            continue
+        r = ex.join_device(to_dev(B), to_dev(P), fl)
+        tag = (it, nb, npb, kind, dom, fl)
+        assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), tag
+        if fl & H.HMJ_CHECKSUM:
+            assert r.checks() == ck, tag
+        if fl & H.HMJ_SUM_PROBE:
+            assert int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64)), tag
+        if fl & (H.HMJ_MATERIALIZE | H.HMJ_ORDERED):
+            got = ex.columns_to_numpy(r, host=False)
+            if fl & H.HMJ_ORDERED:
+                assert np.array_equal(got, rows), tag
+            else:
+                assert np.array_equal(sorted_rows(got), rows), tag
