@@ -62,6 +62,7 @@ struct hmj_ctx {
     int low = 0, B = 0;
   } prep;
   bool prepare_only = false;
+  int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
   u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
@@ -335,12 +336,101 @@ int check_rel(hmj_ctx* c, const void* p, uint64_t n, const char* name) {
   return HMJ_OK;
 }
 
+constexpr int kRetryNoFastWrite = 1002;  // internal: unique-key write mode gave up -> general materialise
 constexpr int kRetryNoSlab = 1001;    // internal: the slab path gave up (skew) -> exact path
 constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-planned without the sampled prefix
 
+// Ordered join, unique-build-key fast path: ONE probe pass writes each partition's rows into the slots
+// of its own probe rows (no count pass), a scan of the per-partition row counts gives the final offsets,
+// and the ordered epilogue moves every partition to its place while sorting it.  Returns
+// kRetryNoFastWrite when the kernel met duplicate build keys or an oversized partition.
+int ordered_unique_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, int low, bool extra,
+                         int verify_prefix, u64 pfx_ref, bool to_host, hmj_result* out) {
+  int rc;
+  const u32 P = wa.P;
+  const size_t cap_bytes = ((size_t)np + 8) * 8;  // at most one row per probe row
+  if ((rc = ensure_dev(c, c->part_count, (size_t)P * 8)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->part_out_off, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->out_key, cap_bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->out_rval, cap_bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->out_sval, cap_bytes)) != HMJ_OK) return rc;
+  wa.part_count = (u64*)c->part_count.p;
+  wa.out_key = (u64*)c->out_key.p;
+  wa.out_rval = (u64*)c->out_rval.p;
+  wa.out_sval = (u64*)c->out_sval.p;
+  wa.extra = extra ? 1u : 0u;
+  if (verify_prefix > 0) {
+    wa.pfx_shift = (u32)(64 - verify_prefix);
+    wa.pfx_val = pfx_ref >> (64 - verify_prefix);
+  }
+  const u64* in_base64 = nullptr;
+  const u32* in_base32 = nullptr;
+  if (slab) {  // first output slot of partition p = number of probe rows in partitions < p
+    if ((rc = ensure_dev(c, c->offs64, ((size_t)P * 2 + 2) * 8)) != HMJ_OK) return rc;
+    u64* npv = (u64*)c->offs64.p;
+    u64* base = npv + P;
+    HIP_TRY(hmj::launch_slab_np(wa.s_cnt, P, npv, c->stream));
+    HIP_TRY(hmj::launch_scan_u64(npv, base, P, c->stream));
+    wa.item_base = base;
+    in_base64 = base;
+  } else {
+    in_base32 = wa.s_off;
+  }
+  int sp = span_begin(c, K_PROBE_WRITE, -1);
+  HIP_TRY(hmj::launch_probe_write_uniq(wa, slab, c->num_cus, c->stream));
+  span_end(c, sp);
+  sp = span_begin(c, K_OUT_SCAN, -1);
+  HIP_TRY(hmj::launch_scan_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p, P, c->stream));
+  span_end(c, sp);
+  u64* h = (u64*)c->h_accum.p;
+  HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h[hmj::ACC_ERR] & hmj::ERR_SLAB) {
+    c->slab_cooldown = 8;
+    return kRetryNoSlab;
+  }
+  if (h[hmj::ACC_ERR] & hmj::ERR_PREFIX) return kRetryNoPrefix;
+  if (h[hmj::ACC_ERR] & hmj::ERR_FASTPATH) {
+    c->uniq_cooldown = 8;
+    return kRetryNoFastWrite;
+  }
+  out->n_matches = h[hmj::ACC_N];
+  out->sum_r = h[hmj::ACC_SUM_R];
+  out->sum_s = h[hmj::ACC_SUM_S];
+  out->xor_fold = h[hmj::ACC_XOR];
+  out->mix_sum = h[hmj::ACC_MIX];
+  out->sum_probe_all = h[hmj::ACC_SUM_P];
+  c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
+  if (out->n_matches == 0) return HMJ_OK;
+  const size_t bytes = (size_t)out->n_matches * 8;
+  if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
+  sp = span_begin(c, K_ORDER, -1);
+  HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, in_base32, in_base64, P, 1, low, wa.out_key,
+                            wa.out_rval, wa.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
+                            (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
+  span_end(c, sp);
+  if (to_host) {
+    if ((rc = ensure_host(c, c->h_key, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_host(c, c->h_rval, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_host(c, c->h_sval, bytes)) != HMJ_OK) return rc;
+    sp = span_begin(c, K_D2H, -1);
+    HIP_TRY(hipMemcpyAsync(c->h_key.p, c->ord_key.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_rval.p, c->ord_rval.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_sval.p, c->ord_sval.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    span_end(c, sp);
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  out->key = to_host ? (const uint64_t*)c->h_key.p : (const uint64_t*)c->ord_key.p;
+  out->rval = to_host ? (const uint64_t*)c->h_rval.p : (const uint64_t*)c->ord_rval.p;
+  out->sval = to_host ? (const uint64_t*)c->h_sval.p : (const uint64_t*)c->ord_sval.p;
+  return HMJ_OK;
+}
+
 int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                      uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix,
-                     bool allow_slab) {
+                     bool allow_slab, bool allow_fast_write) {
   int rc;
   if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
   std::memset(out, 0, sizeof(*out));
@@ -398,7 +488,15 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;
   hmj::SlabGeom gr, gs;
-  if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && !materialize && !first && !extra && Q == 1 &&
+  // ordered joins whose build keys are unique take the unique-key write mode (one probe pass, no count
+  // pass); it works on either partition layout
+  if (c->uniq_cooldown > 0 && allow_fast_write && (flags & HMJ_ORDERED)) c->uniq_cooldown--;
+  // the pipelined probe kernels hold one partition's probe rows in registers (5120 at most)
+  const bool probe_fits = ((u64)np_plan >> B) <= 4608;
+  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && (flags & HMJ_ORDERED) && !first &&
+                          Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
+  if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && !first &&
+      (!extra || fast_write) && Q == 1 && probe_fits &&
       passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && nb >= (1u << 22) && np_plan >= (1u << 22) &&
       hmj::slab_geometry(nb, pass_bits[0], pass_bits[1], &gr) &&
       hmj::slab_geometry(np_plan, pass_bits[0], pass_bits[1], &gs)) {
@@ -444,6 +542,20 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       c->prep.low = low;
       c->prep.B = B;
       return HMJ_OK;
+    }
+    if (fast_write) {
+      hmj::ProbeArgs wa;
+      std::memset(&wa, 0, sizeof(wa));
+      wa.R = c->slab_br.p;
+      wa.S = c->slab_bs.p;
+      wa.r_cnt = (const u32*)c->cnt_br.p;
+      wa.s_cnt = (const u32*)c->cnt_bs.p;
+      wa.r_cap = gr.CB;
+      wa.s_cap = gs.CB;
+      wa.P = P;
+      wa.Q = 1;
+      wa.accum = acc;
+      return ordered_unique_write(c, wa, true, nb, np, low, extra, sampled ? prefix : 0, pfx_ref, to_host, out);
     }
     hmj::ProbeArgs sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -501,6 +613,21 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   HIP_TRY(hmj::launch_part_offsets(Sp, np, low, B, (u32*)c->s_off.p, c->stream));
   span_end(c, s);
 
+  if (fast_write) {
+    hmj::ProbeArgs wa;
+    std::memset(&wa, 0, sizeof(wa));
+    wa.R = Rp;
+    wa.r_off = (const u32*)c->r_off.p;
+    wa.S = Sp;
+    wa.s_off = (const u32*)c->s_off.p;
+    wa.P = P;
+    wa.Q = 1;
+    wa.accum = (u64*)c->accum.p;
+    rc = ordered_unique_write(c, wa, false, nb, np, low, extra, sampled ? prefix : 0, pfx_ref, to_host, out);
+    if (rc != kRetryNoFastWrite) return rc;
+    // duplicate build keys: the partitions stay valid, carry on with the count / scan / write passes
+    HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+  }
   hmj::ProbeArgs a;
   std::memset(&a, 0, sizeof(a));
   a.R = Rp;
@@ -579,7 +706,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
       if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
       s = span_begin(c, K_ORDER, -1);
-      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, P, Q, low, a.out_key, a.out_rval,
+      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, nullptr, nullptr, P, Q, low, a.out_key, a.out_rval,
                                 a.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
                                 (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
       span_end(c, s);
@@ -607,17 +734,19 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
 
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
-  bool auto_prefix = true, slab = true;
-  for (int attempt = 0; attempt < 3; attempt++) {
-    int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab);
-    if (rc == kRetryNoSlab || rc == kRetryNoPrefix) {
+  bool auto_prefix = true, slab = true, fast_write = true;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab, fast_write);
+    if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite) {
       // forget the abandoned attempt's phase spans (the enclosing total / h2d spans stay)
       std::vector<Span> keep;
       for (const Span& sp : c->spans)
         if (sp.kind == K_TOTAL || sp.kind == K_H2D) keep.push_back(sp);
       c->spans.swap(keep);
       std::memset(&c->timing, 0, sizeof(c->timing));
-      if (rc == kRetryNoSlab) slab = false; else auto_prefix = false;
+      if (rc == kRetryNoSlab) slab = false;
+      else if (rc == kRetryNoFastWrite) fast_write = false;
+      else auto_prefix = false;
       continue;
     }
     return rc;

@@ -53,6 +53,8 @@ struct ProbeArgs {
   const u32* r_cnt;
   const u32* s_cnt;
   u32 r_cap, s_cap;
+  const u64* item_base;    // unique-key write mode, slab layout: first output slot of partition p
+  u32 extra;               // unique-key write mode: also accumulate checksums / sum_probe_all
   u32 pfx_shift;           // ordered mode: verify (key >> pfx_shift) == pfx_val for every row (0 = off)
   u64 pfx_val;
   u32* matched;            // HMJ_FIRST_WINS + chunked build: one bit per probe row already paired
@@ -63,13 +65,15 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
                         hipStream_t st);
 int probe_default_grid(int num_cus);
 hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st);
+hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, hipStream_t st);
+hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st);
 // count-mode fast path (Q == 1, no flags); partitions it cannot take go to irregular[]
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
                                    bool per_partition_counts, int num_cus, hipStream_t st);
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
-hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, int low, const u64* akey,
-                        const u64* arval, const u64* asval, u64* bkey, u64* brval, u64* bsval,
-                        int grid, hipStream_t st);
+hipError_t launch_order(const u64* part_out_off, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
+                        int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
+                        u64* bsval, int grid, hipStream_t st);
 
 // gen.hip
 hipError_t launch_gen_build(void* out, u64 n, u64 start, u64 seed, hipStream_t st);

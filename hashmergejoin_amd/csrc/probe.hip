@@ -250,6 +250,7 @@ struct FastSmem {
   u16 next[CAP];
   u64 red[8];
   u32 itemcnt[2];  // per-partition match count, double-buffered by partition parity
+  u64 wscan[THREADS / kWave + 1];  // OUT == 1: packed 64-bit block scan
 };
 
 template <int LOG_NB>
@@ -290,8 +291,13 @@ __device__ __forceinline__ void fp_load_slab(Tup (&t)[FP_ROWS], const Tup* __res
 // PCOUNT: also store each partition's match count in a.part_count[p] (first pass of materialising).
 // SLAB: the partitioned relations are in the histogram-free slab layout (radix.hip, slab kernels);
 //       a partition that does not fit the pipeline raises ERR_SLAB (the caller re-runs the exact path).
-template <int THREADS, int LOG_NB, bool PCOUNT, bool SLAB>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_fast_kernel(
+// OUT == 1: "unique build keys" write mode for ordered joins.  Every probe row yields at most one
+//       result row, so partition p's rows go to the slots of its own probe rows (base = a.s_off[p] /
+//       a.item_base[p]; no count pass, no output atomics): (key, rval, sval) columns are written in probe
+//       order, the row count goes to a.part_count[p].  A probe row with two matches (duplicate build
+//       keys) or a partition that does not fit raises ERR_FASTPATH: the caller re-runs the general path.
+template <int THREADS, int LOG_NB, bool PCOUNT, bool SLAB, int OUT>
+__global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     ProbeArgs a, u32* __restrict__ irregular, u32* __restrict__ n_irregular) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
   constexpr u32 CAP = Smem::CAP, NB = 1u << LOG_NB;
@@ -303,8 +309,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
   const u32* __restrict__ s_off = a.s_off;
   const u32 P = a.P;
   const int tid = threadIdx.x;
-  u64 acc_n = 0, acc_r = 0, acc_s = 0;
-  bool pfx_bad = false;
+  u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
+  bool pfx_bad = false, giveup = false;
   for (u32 i = tid; i < NB; i += THREADS) sm.head[i] = 0;
   if (tid < 2) sm.itemcnt[tid] = 0;
   u32 epoch = 0;
@@ -335,10 +341,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
     if (regular) {
       if (SLAB) {
         fp_load_slab<THREADS>(br, R + (u64)p * 4 * a.r_cap, a.r_cap, r1, r2, r3, nb, tid);
-        fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
+        if (OUT == 0) fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
       } else {
         fp_load<THREADS>(br, R + rb, nb, tid);
-        fp_load<THREADS>(pr, S + sb, np, tid);
+        if (OUT == 0) fp_load<THREADS>(pr, S + sb, np, tid);
       }
     }
   }
@@ -359,11 +365,18 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
       }
       regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
     }
-    if (regular2) {  // next partition's probe rows
+    if (OUT == 0) {
+      if (regular2) {  // next partition's probe rows, one whole partition ahead
+        if (SLAB)
+          fp_load_slab<THREADS>(pq, S + (u64)pn * 4 * a.s_cap, a.s_cap, s1n, s2n, s3n, np2, tid);
+        else
+          fp_load<THREADS>(pq, S + sb2, np2, tid);
+      }
+    } else if (regular) {  // write mode keeps fewer rows in flight (registers): this partition's probe rows
       if (SLAB)
-        fp_load_slab<THREADS>(pq, S + (u64)pn * 4 * a.s_cap, a.s_cap, s1n, s2n, s3n, np2, tid);
+        fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
       else
-        fp_load<THREADS>(pq, S + sb2, np2, tid);
+        fp_load<THREADS>(pr, S + sb, np, tid);
     }
     if (regular) {
       lds_barrier();                   // everyone is done probing the previous table
@@ -413,12 +426,16 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
       if (!(a.debug & 1u)) {
         // probe: walk the five chains in lockstep so their LDS latencies overlap
         u32 cur[FP_ROWS];
+        u32 cnt[FP_ROWS], first[FP_ROWS];  // OUT == 1
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 j = k * THREADS + tid;
           cur[k] = NIL;
+          cnt[k] = 0;
+          first[k] = 0;
           if (j < np) {
             if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+            if (OUT == 1 && a.extra) acc_p += pr[k].val;
             const u32 hv = sm.head[fast_hash<LOG_NB>(pr[k].key)];
             cur[k] = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
           }
@@ -438,8 +455,65 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
                 acc_n++;
                 acc_r += vv;
                 acc_s += pr[k].val;
+                if (OUT == 1) {
+                  if (cnt[k] == 0) first[k] = i;
+                  cnt[k]++;
+                  if (a.extra) {
+                    const u64 m = tmix(kk, vv, pr[k].val);
+                    acc_x ^= m;
+                    acc_m += m;
+                  }
+                }
               }
             }
+          }
+        }
+        if (OUT == 1) {
+          // compact this partition's result rows in probe order: one packed block scan gives every
+          // thread the offsets of its five rows (12 bits per row slot k; bit 60+: "a row matched twice")
+          u64 packed = 0;
+          bool cx = false;
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            cx |= cnt[k] > 1;
+            packed |= (u64)(cnt[k] ? 1u : 0u) << (12 * k);
+          }
+          packed |= (u64)(cx ? 1u : 0u) << 60;
+          const int lane = tid & 63, wv = tid >> 6;
+          u64 incl = packed;
+#pragma unroll
+          for (int o = 1; o < kWave; o <<= 1) {
+            u64 t = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += t;
+          }
+          if (lane == 63) sm.wscan[wv] = incl;
+          lds_barrier();
+          u64 pre = 0, tot = 0;
+#pragma unroll
+          for (int q = 0; q < THREADS / kWave; q++) {
+            const u64 ws = sm.wscan[q];
+            if (q < wv) pre += ws;
+            tot += ws;
+          }
+          const u64 ex = pre + incl - packed;
+          if (tot >> 60) {
+            giveup = true;  // duplicate build keys here: not the unique-key case
+          } else {
+            u64 o = SLAB ? a.item_base[p] : (u64)sb;
+            u32 total = 0;
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; k++) {
+              if (cnt[k]) {
+                const u64 d = o + ((ex >> (12 * k)) & 0xFFFu);
+                a.out_key[d] = pr[k].key;
+                a.out_rval[d] = sm.val[first[k]];
+                a.out_sval[d] = pr[k].val;
+              }
+              const u32 tk = (u32)((tot >> (12 * k)) & 0xFFFu);
+              o += tk;
+              total += tk;
+            }
+            if (tid == 0) a.part_count[p] = total;
           }
         }
       } else {
@@ -454,8 +528,21 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
         parity ^= 1;
       }
     } else {
-      if (PCOUNT && tid == 0 && !(nb && np)) a.part_count[p] = 0;  // empty side: no rows
-      if (!SLAB && tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
+      if ((PCOUNT || OUT == 1) && tid == 0 && !(nb && np)) a.part_count[p] = 0;  // empty side: no rows
+      if (OUT == 1 && nb && np) giveup = true;  // does not fit the pipeline: general path
+      if (OUT == 1 && a.extra && !nb) {  // probe rows without a build partition still count in sum_probe_all
+        if (SLAB) {
+          const Tup* base = S + (u64)p * 4 * a.s_cap;
+          for (u32 j = tid; j < np; j += THREADS) {
+            const u32 pc = (j >= s1) + (j >= s2) + (j >= s3);
+            const u32 pre = pc == 0 ? 0 : pc == 1 ? s1 : pc == 2 ? s2 : s3;
+            acc_p += base[(u64)pc * a.s_cap + (j - pre)].val;
+          }
+        } else {
+          for (u32 j = tid; j < np; j += THREADS) acc_p += S[sb + j].val;
+        }
+      }
+      if (OUT == 0 && !SLAB && tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
       if (regular2) {
         if (SLAB)
           fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
@@ -463,19 +550,22 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void probe_count_f
           fp_load<THREADS>(br, R + rb2, nb2, tid);
       }
     }
+    if (OUT == 0) {
 #pragma unroll
-    for (int k = 0; k < FP_ROWS; k++) pr[k] = pq[k];
+      for (int k = 0; k < FP_ROWS; k++) pr[k] = pq[k];
+    }
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
     r1 = r1n; r2 = r2n; r3 = r3n; s1 = s1n; s2 = s2n; s3 = s3n;
   }
   if (SLAB && slab_bad && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_SLAB);
+  if (OUT == 1 && __any(giveup) && (tid & 63) == 0) atomicOr(&a.accum[ACC_ERR], ERR_FASTPATH);
   if (__any(pfx_bad) && (tid & 63) == 0) atomicOr(&a.accum[ACC_ERR], ERR_PREFIX);
   lds_barrier();
   if (PCOUNT && prev_p != 0xFFFFFFFFu && tid == 0) a.part_count[prev_p] = sm.itemcnt[parity ^ 1];
   if (tid < 8) sm.red[tid] = 0;
   lds_barrier();
-  const u64 v[6] = {acc_n, acc_r, acc_s, 0, 0, 0};
-  block_accumulate(sm.red, a.accum, v, 0u);
+  const u64 v[6] = {acc_n, acc_r, acc_s, acc_x, acc_m, acc_p};
+  block_accumulate(sm.red, a.accum, v, 1u << ACC_XOR);
 }
 
 // Exclusive scan of n u64 counts into n+1 offsets (single workgroup; n = partition count).
@@ -566,8 +656,12 @@ __device__ __forceinline__ void order_network_global(u64* k, u64* r, u64* s, u32
   }
 }
 
+// Segment p: input rows A[in_base(p) .. + len(p)), output rows B[off[p*Q] ..).  By default the input is
+// laid out like the output (in_base32 == in_base64 == NULL); the unique-key write mode passes where
+// each partition's rows were written (slot of its first probe row) and their count.
 __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
-    const u64* __restrict__ off, u32 P, u32 Q, int low, const u64* __restrict__ akey,
+    const u64* __restrict__ off, const u32* __restrict__ in_base32, const u64* __restrict__ in_base64,
+    u32 P, u32 Q, int low, const u64* __restrict__ akey,
     const u64* __restrict__ arval, const u64* __restrict__ asval, u64* __restrict__ bkey,
     u64* __restrict__ brval, u64* __restrict__ bsval) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -575,7 +669,8 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
   const int tid = threadIdx.x;
   const int bsh = low - OS_LOGB;  // bucket = key bits [low-12, low)
   for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
-    const u64 b = off[(u64)p * Q], L64 = off[((u64)p + 1) * Q] - b;
+    const u64 ob = off[(u64)p * Q], L64 = off[((u64)p + 1) * Q] - ob;  // output segment
+    const u64 b = in_base64 ? in_base64[p] : (in_base32 ? (u64)in_base32[p] : ob);  // input segment start
     if (L64 == 0) continue;
     bool slow = (L64 > OS_CAP) || (bsh < 0);
     const u32 L = slow ? 0u : (u32)L64;
@@ -630,12 +725,12 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
     if (slow) {  // uniform for the workgroup
       const u64 n = L64;
       for (u64 i = tid; i < n; i += OS_THREADS) {
-        bkey[b + i] = akey[b + i];
-        brval[b + i] = arval[b + i];
-        bsval[b + i] = asval[b + i];
+        bkey[ob + i] = akey[b + i];
+        brval[ob + i] = arval[b + i];
+        bsval[ob + i] = asval[b + i];
       }
       __syncthreads();
-      if (n >= 2 && n <= 0x7FFFFFFFull) order_network_global(bkey + b, brval + b, bsval + b, (u32)n, tid);
+      if (n >= 2 && n <= 0x7FFFFFFFull) order_network_global(bkey + ob, brval + ob, bsval + ob, (u32)n, tid);
       continue;
     }
 #pragma unroll
@@ -679,7 +774,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
 #pragma unroll
       for (int k = 0; k < OS_ROWS; k++) {
         const u32 i = k * OS_THREADS + tid;
-        if (i < L) outc[b + i] = sm.stage[i];
+        if (i < L) outc[ob + i] = sm.stage[i];
       }
       __syncthreads();
     }
@@ -702,21 +797,21 @@ static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int THREADS, int LOG_NB, bool PCOUNT, bool SLAB = false>
+template <int THREADS, int LOG_NB, bool PCOUNT, bool SLAB = false, int OUT = 0>
 static hipError_t launch_fast_t(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
                                 hipStream_t st) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB>),
+        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB, OUT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB>), dim3(grid), dim3(THREADS),
+  hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB, OUT>), dim3(grid), dim3(THREADS),
                      sizeof(Smem), st, a, irregular, n_irregular);
   return hipGetLastError();
 }
@@ -730,6 +825,23 @@ hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_ir
   }
   if (big) return launch_fast_t<1024, BIG_LOG_NB, false>(a, irregular, n_irregular, num_cus * 4, st);
   return launch_fast_t<512, 11, false>(a, irregular, n_irregular, num_cus * 3 * 4, st);
+}
+
+// unique-build-key write mode (ordered joins); slab or dense layout
+hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, hipStream_t st) {
+  if (slab) return launch_fast_t<1024, BIG_LOG_NB, false, true, 1>(a, nullptr, nullptr, num_cus * 4, st);
+  return launch_fast_t<1024, BIG_LOG_NB, false, false, 1>(a, nullptr, nullptr, num_cus * 4, st);
+}
+
+// np of every slab partition (sum of its 4 piece counts) as u64, for the exclusive scan that gives
+// each partition's first output slot in the unique-key write mode
+__global__ void slab_np_kernel(const u32* __restrict__ cnt, u32 P, u64* __restrict__ out) {
+  u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) out[p] = (u64)cnt[4 * (u64)p] + cnt[4 * (u64)p + 1] + cnt[4 * (u64)p + 2] + cnt[4 * (u64)p + 3];
+}
+hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st) {
+  hipLaunchKernelGGL(slab_np_kernel, dim3((P + 255) / 256), dim3(256), 0, st, cnt, P, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st) {
@@ -765,9 +877,9 @@ hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st) 
   return hipGetLastError();
 }
 
-hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, int low, const u64* akey,
-                        const u64* arval, const u64* asval, u64* bkey, u64* brval, u64* bsval,
-                        int grid, hipStream_t st) {
+hipError_t launch_order(const u64* part_out_off, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
+                        int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
+                        u64* bsval, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(order_kernel),
@@ -779,7 +891,7 @@ hipError_t launch_order(const u64* part_out_off, u32 P, u32 Q, int low, const u6
   if ((u32)grid > P) grid = (int)P;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off,
-                     P, Q, low, akey, arval, asval, bkey, brval, bsval);
+                     in_base32, in_base64, P, Q, low, akey, arval, asval, bkey, brval, bsval);
   return hipGetLastError();
 }
 

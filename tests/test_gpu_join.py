@@ -486,6 +486,51 @@ def test_slab_path_parity_and_fallback(ex, H, oracle):
     assert t["ms_hist"] > 0.0  # the exact path produced this result
 
 
+def test_ordered_unique_key_write_mode(ex, H, oracle):
+    # Ordered joins with unique build keys take the single-pass write mode (no count pass) on both
+    # partition layouts; duplicate build keys make it give up and the count/scan/write passes run.
+    fl = H.HMJ_ORDERED | H.HMJ_CHECKSUM
+
+    def run_out_cooldown():  # after meeting duplicate build keys the executor skips the attempt for 8 joins
+        for _ in range(8):
+            ex.join_device(to_dev(oracle.gen_build(50000)), to_dev(oracle.gen_probe(50000, 50000)), fl)
+
+    run_out_cooldown()
+    for nb, npb, miss in [(300000, 200000, 3), (300000, 400000, 0), ((1 << 22) + 4321, (1 << 22) + 99, 5),
+                          (1 << 22, 4500000, 0), (9000, 1000, 2)]:
+        B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=miss)
+        ck, rows = oracle.equijoin(B, P)
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), fl)
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        got = ex.columns_to_numpy(r, host=False)
+        assert r.checks() == ck
+        assert np.array_equal(got[:, 0], rows[:, 0])  # ascending keys, the reference's iteration order
+        assert np.array_equal(sorted_rows(got), rows)
+        assert t["ms_probe_count"] == 0.0 and t["ms_probe_write"] > 0.0  # really the single-pass mode
+        ex.release_result()
+    # duplicate build keys: same call, general passes, same rows
+    for nb in [200000, (1 << 22) + 17]:
+        B = oracle.gen_build(nb)
+        m = len(B[1::7])
+        B[1::7, 0] = B[0::7, 0][:m]  # every 7th key twice
+        P = oracle.gen_probe(nb // 2, nb)
+        ck, rows = oracle.equijoin(B, P)
+        for attempt in range(2):  # second run: the executor remembers and skips the attempt
+            ex.set_profiling(True)
+            r = ex.join_device(to_dev(B), to_dev(P), fl)
+            t = ex.last_timing()
+            ex.set_profiling(False)
+            got = ex.columns_to_numpy(r, host=False)
+            assert r.checks() == ck
+            assert np.array_equal(got[:, 0], rows[:, 0])
+            assert np.array_equal(sorted_rows(got), rows)
+            assert t["ms_probe_count"] > 0.0
+            ex.release_result()
+    run_out_cooldown()
+
+
 def test_prepared_build_side(ex, H, oracle):
     # hmj_prepare_build_u64_device: partition R ahead of the join (one-shot), for both partitioning paths
     for nb, npb in [(1 << 22, (1 << 22) + 999), (300000, 200000)]:
