@@ -344,8 +344,8 @@ constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-plann
 // of its own probe rows (no count pass), a scan of the per-partition row counts gives the final offsets,
 // and the ordered epilogue moves every partition to its place while sorting it.  Returns
 // kRetryNoFastWrite when the kernel met duplicate build keys or an oversized partition.
-int ordered_unique_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, int low, bool extra,
-                         int verify_prefix, u64 pfx_ref, bool to_host, hmj_result* out) {
+int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, int low, bool extra,
+                         int verify_prefix, u64 pfx_ref, bool ordered, bool to_host, hmj_result* out) {
   int rc;
   const u32 P = wa.P;
   const size_t cap_bytes = ((size_t)np + 8) * 8;  // at most one row per probe row
@@ -403,28 +403,37 @@ int ordered_unique_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 
   c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
   if (out->n_matches == 0) return HMJ_OK;
   const size_t bytes = (size_t)out->n_matches * 8;
-  if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
-  if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
-  if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
-  sp = span_begin(c, K_ORDER, -1);
-  HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, in_base32, in_base64, P, 1, low, wa.out_key,
-                            wa.out_rval, wa.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
-                            (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
-  span_end(c, sp);
+  // every probe row matched: the columns have no gaps, an unordered result is complete as it stands.
+  // Otherwise the ordered epilogue closes the gaps (and sorts, which an unordered caller may ignore).
+  const bool dense_out = !ordered && out->n_matches == (u64)np;
+  const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
+  if (!dense_out) {
+    if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
+    sp = span_begin(c, K_ORDER, -1);
+    HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, in_base32, in_base64, P, 1, low, wa.out_key,
+                              wa.out_rval, wa.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
+                              (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
+    span_end(c, sp);
+    rk = (const u64*)c->ord_key.p;
+    rr = (const u64*)c->ord_rval.p;
+    rs = (const u64*)c->ord_sval.p;
+  }
   if (to_host) {
     if ((rc = ensure_host(c, c->h_key, bytes)) != HMJ_OK) return rc;
     if ((rc = ensure_host(c, c->h_rval, bytes)) != HMJ_OK) return rc;
     if ((rc = ensure_host(c, c->h_sval, bytes)) != HMJ_OK) return rc;
     sp = span_begin(c, K_D2H, -1);
-    HIP_TRY(hipMemcpyAsync(c->h_key.p, c->ord_key.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_rval.p, c->ord_rval.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_sval.p, c->ord_sval.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_key.p, rk, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_rval.p, rr, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_sval.p, rs, bytes, hipMemcpyDeviceToHost, c->stream));
     span_end(c, sp);
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
-  out->key = to_host ? (const uint64_t*)c->h_key.p : (const uint64_t*)c->ord_key.p;
-  out->rval = to_host ? (const uint64_t*)c->h_rval.p : (const uint64_t*)c->ord_rval.p;
-  out->sval = to_host ? (const uint64_t*)c->h_sval.p : (const uint64_t*)c->ord_sval.p;
+  out->key = to_host ? (const uint64_t*)c->h_key.p : (const uint64_t*)rk;
+  out->rval = to_host ? (const uint64_t*)c->h_rval.p : (const uint64_t*)rr;
+  out->sval = to_host ? (const uint64_t*)c->h_sval.p : (const uint64_t*)rs;
   return HMJ_OK;
 }
 
@@ -488,15 +497,15 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;
   hmj::SlabGeom gr, gs;
-  // ordered joins whose build keys are unique take the unique-key write mode (one probe pass, no count
-  // pass); it works on either partition layout
-  if (c->uniq_cooldown > 0 && allow_fast_write && (flags & HMJ_ORDERED)) c->uniq_cooldown--;
+  // materialising joins whose build keys are unique take the unique-key write mode (one probe pass,
+  // no count pass); it works on either partition layout
+  if (c->uniq_cooldown > 0 && allow_fast_write && materialize) c->uniq_cooldown--;
   // the pipelined probe kernels hold one partition's probe rows in registers (5120 at most)
   const bool probe_fits = ((u64)np_plan >> B) <= 4608;
-  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && (flags & HMJ_ORDERED) && !first &&
+  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !first &&
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
-  if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && !first &&
-      (!extra || fast_write) && Q == 1 && probe_fits &&
+  if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
+      probe_fits &&
       passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && nb >= (1u << 22) && np_plan >= (1u << 22) &&
       hmj::slab_geometry(nb, pass_bits[0], pass_bits[1], &gr) &&
       hmj::slab_geometry(np_plan, pass_bits[0], pass_bits[1], &gs)) {
@@ -555,7 +564,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       wa.P = P;
       wa.Q = 1;
       wa.accum = acc;
-      return ordered_unique_write(c, wa, true, nb, np, low, extra, sampled ? prefix : 0, pfx_ref, to_host, out);
+      return unique_key_write(c, wa, true, nb, np, low, extra, sampled ? prefix : 0, pfx_ref,
+                                  (flags & HMJ_ORDERED) != 0, to_host, out);
     }
     hmj::ProbeArgs sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -570,7 +580,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     sa.accum = acc;
     if (const char* e = getenv("HMJ_DEBUG_ABLATE")) sa.debug = (u32)atoi(e);
     int sp = span_begin(c, K_PROBE_COUNT, -1);
-    HIP_TRY(hmj::launch_probe_count_slab(sa, c->num_cus, c->stream));
+    if (first || extra) {
+      sa.extra = (extra ? 1u : 0u) | (first ? 2u : 0u);
+      HIP_TRY(hmj::launch_probe_count_ext(sa, nullptr, nullptr, true, c->num_cus, c->stream));
+    } else {
+      HIP_TRY(hmj::launch_probe_count_slab(sa, c->num_cus, c->stream));
+    }
     span_end(c, sp);
     c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
     HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -582,6 +597,9 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     out->n_matches = hh[hmj::ACC_N];
     out->sum_r = hh[hmj::ACC_SUM_R];
     out->sum_s = hh[hmj::ACC_SUM_S];
+    out->xor_fold = hh[hmj::ACC_XOR];
+    out->mix_sum = hh[hmj::ACC_MIX];
+    out->sum_probe_all = hh[hmj::ACC_SUM_P];
     return HMJ_OK;
   }
 
@@ -623,7 +641,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     wa.P = P;
     wa.Q = 1;
     wa.accum = (u64*)c->accum.p;
-    rc = ordered_unique_write(c, wa, false, nb, np, low, extra, sampled ? prefix : 0, pfx_ref, to_host, out);
+    rc = unique_key_write(c, wa, false, nb, np, low, extra, sampled ? prefix : 0, pfx_ref,
+                                  (flags & HMJ_ORDERED) != 0, to_host, out);
     if (rc != kRetryNoFastWrite) return rc;
     // duplicate build keys: the partitions stay valid, carry on with the count / scan / write passes
     HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
@@ -666,6 +685,20 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     a2.item_list = irr;
     a2.n_item_list = n_irr;
     HIP_TRY(hmj::launch_probe(a2, materialize ? 1 : 0, false, false, c->num_cus, c->stream));
+  } else if (!materialize && Q == 1 && P >= 2) {
+    // count mode with checksums / first-wins: the pipelined kernel's extended variant, then the generic
+    // kernel (same flags) over the partitions it set aside
+    if ((rc = ensure_dev(c, c->irregular, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+    u32* n_irr = (u32*)c->irregular.p;
+    u32* irr = n_irr + 1;
+    HIP_TRY(hipMemsetAsync(n_irr, 0, 4, c->stream));
+    hmj::ProbeArgs ax = a;
+    ax.extra = (extra ? 1u : 0u) | (first ? 2u : 0u);
+    HIP_TRY(hmj::launch_probe_count_ext(ax, irr, n_irr, false, c->num_cus, c->stream));
+    hmj::ProbeArgs a2 = a;
+    a2.item_list = irr;
+    a2.n_item_list = n_irr;
+    HIP_TRY(hmj::launch_probe(a2, 0, first, extra, c->num_cus, c->stream));
   } else {
     HIP_TRY(hmj::launch_probe(a, materialize ? 1 : 0, first, extra, grid, c->stream));
   }

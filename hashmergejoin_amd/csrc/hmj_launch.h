@@ -64,6 +64,8 @@ struct ProbeArgs {
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
                         hipStream_t st);
 int probe_default_grid(int num_cus);
+hipError_t launch_probe_count_ext(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool slab,
+                                  int num_cus, hipStream_t st);
 hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st);
 hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, hipStream_t st);
 hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st);

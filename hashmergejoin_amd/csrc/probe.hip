@@ -432,10 +432,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
           const u32 j = k * THREADS + tid;
           cur[k] = NIL;
           cnt[k] = 0;
-          first[k] = 0;
+          first[k] = OUT == 2 ? NIL : 0;
           if (j < np) {
             if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-            if (OUT == 1 && a.extra) acc_p += pr[k].val;
+            if (OUT >= 1 && (a.extra & 1u)) acc_p += pr[k].val;
             const u32 hv = sm.head[fast_hash<LOG_NB>(pr[k].key)];
             cur[k] = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
           }
@@ -452,18 +452,38 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
               const u64 kk = sm.key[i], vv = sm.val[i];  // val read unconditionally: one LDS
               cur[k] = sm.next[i];                       // round trip per chain step, not two
               if (kk == pr[k].key) {
-                acc_n++;
-                acc_r += vv;
-                acc_s += pr[k].val;
-                if (OUT == 1) {
-                  if (cnt[k] == 0) first[k] = i;
-                  cnt[k]++;
-                  if (a.extra) {
+                if (OUT == 2 && (a.extra & 2u)) {  // first wins: smallest position = first in input order
+                  first[k] = i < first[k] ? i : first[k];
+                } else {
+                  acc_n++;
+                  acc_r += vv;
+                  acc_s += pr[k].val;
+                  if (OUT == 1) {
+                    if (cnt[k] == 0) first[k] = i;
+                    cnt[k]++;
+                  }
+                  if (OUT >= 1 && (a.extra & 1u)) {
                     const u64 m = tmix(kk, vv, pr[k].val);
                     acc_x ^= m;
                     acc_m += m;
                   }
                 }
+              }
+            }
+          }
+        }
+        if (OUT == 2 && (a.extra & 2u)) {
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            if (first[k] != NIL) {
+              const u64 vv = sm.val[first[k]];
+              acc_n++;
+              acc_r += vv;
+              acc_s += pr[k].val;
+              if (a.extra & 1u) {
+                const u64 m = tmix(pr[k].key, vv, pr[k].val);
+                acc_x ^= m;
+                acc_m += m;
               }
             }
           }
@@ -530,7 +550,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     } else {
       if ((PCOUNT || OUT == 1) && tid == 0 && !(nb && np)) a.part_count[p] = 0;  // empty side: no rows
       if (OUT == 1 && nb && np) giveup = true;  // does not fit the pipeline: general path
-      if (OUT == 1 && a.extra && !nb) {  // probe rows without a build partition still count in sum_probe_all
+      if (OUT >= 1 && (a.extra & 1u) && !nb) {  // probe rows without a build partition still count in sum_probe_all
         if (SLAB) {
           const Tup* base = S + (u64)p * 4 * a.s_cap;
           for (u32 j = tid; j < np; j += THREADS) {
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
           for (u32 j = tid; j < np; j += THREADS) acc_p += S[sb + j].val;
         }
       }
-      if (OUT == 0 && !SLAB && tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
+      if (OUT != 1 && !SLAB && tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
       if (regular2) {
         if (SLAB)
           fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
@@ -842,6 +862,13 @@ __global__ void slab_np_kernel(const u32* __restrict__ cnt, u32 P, u64* __restri
 hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st) {
   hipLaunchKernelGGL(slab_np_kernel, dim3((P + 255) / 256), dim3(256), 0, st, cnt, P, out);
   return hipGetLastError();
+}
+
+// count mode with checksums / sum of all probe payloads (a.extra bit 0) and first-wins (bit 1)
+hipError_t launch_probe_count_ext(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool slab,
+                                  int num_cus, hipStream_t st) {
+  if (slab) return launch_fast_t<1024, BIG_LOG_NB, false, true, 2>(a, nullptr, nullptr, num_cus * 4, st);
+  return launch_fast_t<1024, BIG_LOG_NB, false, false, 2>(a, irregular, n_irregular, num_cus * 4, st);
 }
 
 hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st) {

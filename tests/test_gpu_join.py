@@ -470,6 +470,22 @@ def test_slab_path_parity_and_fallback(ex, H, oracle):
         ex.set_profiling(False)
         assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"])
         assert t["ms_hist"] == 0.0 and t["n_scatter_launches"] == 4  # really the slab path: no histogram
+    # checksums, sum of all probe payloads and first-wins on the slab layout: duplicate build keys, so
+    # "first" must mean first in INPUT order although the slab partitioning has no global histogram
+    nb = (1 << 22) + 555
+    B = oracle.gen_build(nb)
+    m = len(B[3::5])
+    B[3::5, 0] = B[0::5, 0][:m]  # every 5th key appears twice, the later copy 3 rows down
+    P = oracle.gen_probe((1 << 22) + 11, nb, miss_mod=4)
+    for fw in (False, True):
+        ck, _ = oracle.equijoin(B, P, first_wins=fw, cap=0)
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE | (H.HMJ_FIRST_WINS if fw else 0))
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        assert r.checks() == ck
+        assert int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+        assert t["ms_hist"] == 0.0
     # skewed digits overflow a slab -> automatic fallback to the exact (histogram) path, same answer
     n = 1 << 22
     keys = oracle.gen_build(n)[:, 0]
@@ -509,6 +525,14 @@ def test_ordered_unique_key_write_mode(ex, H, oracle):
         assert np.array_equal(got[:, 0], rows[:, 0])  # ascending keys, the reference's iteration order
         assert np.array_equal(sorted_rows(got), rows)
         assert t["ms_probe_count"] == 0.0 and t["ms_probe_write"] > 0.0  # really the single-pass mode
+        # unordered materialise: same mode; no epilogue at all when every probe row matched
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM)
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        assert r.checks() == ck
+        assert np.array_equal(sorted_rows(ex.columns_to_numpy(r, host=False)), rows)
+        assert t["ms_probe_count"] == 0.0 and (t["ms_order"] == 0.0) == (miss == 0)
         ex.release_result()
     # duplicate build keys: same call, general passes, same rows
     for nb in [200000, (1 << 22) + 17]:
