@@ -1,7 +1,8 @@
 // Bucket-local build + probe for gfx950.  One workgroup per radix partition (grid-stride):
-//   build : the partition's R rows are copied into LDS and linked into a chained hash table
-//           (one ds atomic exchange per row) -- the GPU form of tables[p].insert(item),
-//           partitioned_hash.h:166-170 (partitioned_table_worker) / :173-215;
+//   build : the partition's R rows are copied into LDS and inserted into a chained hash table of
+//           DISTINCT keys (find-or-insert with one ds compare-and-swap; a row whose key is already
+//           there is folded into / listed under that key's first entry) -- the GPU form of
+//           tables[p].insert(item), partitioned_hash.h:166-170 (partitioned_table_worker) / :173-215;
 //   probe : the partition's S rows stream through in coalesced 16-byte loads and walk the chain
 //           -- the loop of hashjoin_bench.cc:92-96, which only ever meets table p with bucket p.
 // The rows it yields are the (key, rval, sval) of HashMergeJoin::iterator::operator*
@@ -21,11 +22,15 @@ struct ProbeSmem {
   u64 key[PB_CAP];
   u64 val[PB_CAP];
   u32 head[PB_NB];
+  u32 aux[PB_CAP];  // per distinct key: row count | first row | list of its other rows (by kernel mode)
   u16 next[PB_CAP];
   u32 scratch[PB_THREADS / kWave + 1];
   u64 pcount;
   u64 red[8];
+  u32 nslot;
 };
+constexpr u32 PB_BATCH = 2 * PB_THREADS;  // build rows inserted per step
+static_assert(PB_BATCH <= PB_CAP, "a batch must fit an empty table");
 
 __device__ __forceinline__ u32 tab_hash(u64 k) {
   u32 x = (u32)k ^ ((u32)(k >> 32) * 0x85EBCA6Bu);
@@ -48,8 +53,17 @@ __device__ __forceinline__ bool first_claim(u32* matched, bool multi, u32 row) {
 
 // MODE 0: count + sums.  MODE 1: also per-partition match counts.  MODE 2: write result columns.
 // FIRST: HMJ_FIRST_WINS.  EXTRA: HMJ_CHECKSUM / HMJ_SUM_PROBE accumulators.
+// The table holds one chain entry per DISTINCT key (skewed build sides put hundreds of thousands of
+// equal keys into one partition; chaining them all would make every probe of that bucket walk them).
+// What an entry knows about the other rows with its key depends on what the mode needs:
+//   AGG  (count modes without checksums): aux = number of rows, val = sum of their payloads;
+//   FIRST: aux = smallest row position in the partition (first in input order; its payload is read
+//          from the partition when a probe row pairs with it);
+//   else : aux threads a list through the rows with that key (enumerated per match: output-sized work).
 template <int MODE, bool FIRST, bool EXTRA>
 __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(ProbeArgs a) {
+  constexpr bool AGG = !FIRST && !EXTRA && MODE != 2;
+  constexpr bool PERSIST = AGG || FIRST;  // rows with a key already in the table take no slot
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ProbeSmem& sm = *reinterpret_cast<ProbeSmem*>(smem_raw);
   const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
@@ -75,36 +89,103 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
       if (MODE == 1 && tid == 0) a.part_count[w] = 0;
       continue;
     }
-    const bool multi = FIRST && nb > PB_CAP;  // first-wins across chunks: remember paired probe rows
+    const bool multi = FIRST && nb > PB_CAP;  // first-wins across tables: remember paired probe rows
     u64 pc = 0;                                   // this thread's matches in partition p
     u64 run = (MODE == 2) ? a.part_out_off[w] : 0;  // next output row of this item
 
-    for (u32 c0 = 0; c0 < nb; c0 += PB_CAP) {
-      const u32 cn = (nb - c0 < PB_CAP) ? nb - c0 : PB_CAP;
+    // The build rows go into the table in batches; a table is probed (and cleared) when the next batch
+    // might not fit.  PERSIST modes give a slot only to a key not yet in the table, so a partition
+    // of few distinct keys -- the skewed case -- is one table however many rows it has.
+    u32 c0 = 0;
+    bool first_table = true;
+    while (c0 < nb) {
       __syncthreads();
       for (u32 i = tid; i < PB_NB; i += PB_THREADS) sm.head[i] = NIL;
+      if (tid == 0) sm.nslot = 0;
       __syncthreads();
-      // ---- build: copy rows to LDS, push each on its chain
-      for (u32 i0 = 0; i0 < cn; i0 += PB_THREADS * 2) {
+      u32 used = 0;
+      while (c0 < nb) {
+        const u32 cn = (nb - c0 < PB_BATCH) ? nb - c0 : PB_BATCH;
+        if (used + cn > PB_CAP) break;
         Tup t[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          u32 i = i0 + k * PB_THREADS + tid;
+          const u32 i = k * PB_THREADS + tid;
           if (i < cn) t[k] = R[(u64)rb + c0 + i];
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          u32 i = i0 + k * PB_THREADS + tid;
-          if (i < cn) {
-            if (a.pfx_shift && (t[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-            sm.key[i] = t[k].key;
-            sm.val[i] = t[k].val;
-            u32 old = atomicExch(&sm.head[tab_hash(t[k].key)], i);
-            sm.next[i] = (u16)old;
+          const u32 i = k * PB_THREADS + tid;
+          bool valid = i < cn;
+          const u64 key = t[k].key;
+          u64 sumv = t[k].val;
+          u32 cntv = 1;
+          if (valid && a.pfx_shift && (key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+          if (PERSIST) {
+            // a wave whose rows all carry one key (the hot key of a skewed partition) sends one lane
+            const u64 vm = __ballot(valid);
+            if (__popcll(vm) > 1) {
+              const int leader = __ffsll((long long)vm) - 1;
+              const u64 k0 = __shfl(key, leader, kWave);
+              if (__all(!valid || key == k0)) {
+                if (AGG) {
+                  sumv = wave_sum_u64(valid ? sumv : 0);
+                  cntv = (u32)__popcll(vm);
+                }
+                valid = lane == leader;  // FIRST: the leader holds the smallest position
+              }
+            }
+          }
+          if (valid) {
+            const u32 pos = c0 + i;  // position in the partition = input order (stable partitioning)
+            u32 slot = PERSIST ? NIL : used + i;
+            if (!PERSIST) {
+              sm.key[slot] = key;
+              sm.val[slot] = sumv;
+              sm.aux[slot] = NIL;
+            }
+            u32* hp = &sm.head[tab_hash(key)];
+            u32 seen = NIL;  // entries from here on were already compared
+            for (;;) {
+              const u32 hd = __hip_atomic_load(hp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              u32 found = NIL;
+              for (u32 n = hd; n != seen; n = sm.next[n])
+                if (sm.key[n] == key) {
+                  found = n;
+                  break;
+                }
+              if (found != NIL) {
+                if (AGG) {
+                  atomicAdd(&sm.aux[found], cntv);
+                  atomicAdd(reinterpret_cast<unsigned long long*>(&sm.val[found]), (unsigned long long)sumv);
+                } else if (FIRST) {
+                  if (pos < __hip_atomic_load(&sm.aux[found], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    atomicMin(&sm.aux[found], pos);
+                } else {
+                  sm.aux[slot] = atomicExch(&sm.aux[found], slot);
+                }
+                break;
+              }
+              if (PERSIST && slot == NIL) {  // a key not seen so far: now it needs a slot
+                slot = atomicAdd(&sm.nslot, 1u);
+                sm.key[slot] = key;
+                if (AGG) sm.val[slot] = sumv;
+                sm.aux[slot] = AGG ? cntv : pos;
+              }
+              sm.next[slot] = (u16)hd;
+              u32 expect = hd;
+              if (__hip_atomic_compare_exchange_strong(hp, &expect, slot, __ATOMIC_RELEASE, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP))
+                break;
+              seen = hd;  // lost the race: only the entries pushed since then are new
+            }
           }
         }
+        c0 += cn;
+        __syncthreads();
+        used = PERSIST ? sm.nslot : used + cn;  // PERSIST: at most one slot per row, so <= used + cn
+        if (PERSIST) __syncthreads();           // everyone has read nslot before the next batch bumps it
       }
-      __syncthreads();
 
       // ---- probe
       if (MODE != 2) {
@@ -121,14 +202,20 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
             if (j < np) {
               const u64 key = t[k].key, sval = t[k].val;
               if (a.pfx_shift && (key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-              if (EXTRA && c0 == 0) acc_p += sval;
+              if (EXTRA && first_table) acc_p += sval;
               u32 i = sm.head[tab_hash(key)];
+              while (i != NIL && sm.key[i] != key) i = sm.next[i];
               u32 best = NIL;
-              while (i != NIL) {
-                if (sm.key[i] == key) {
-                  if (FIRST) {
-                    best = (i < best) ? i : best;
-                  } else {
+              if (i != NIL) {
+                if (AGG) {
+                  const u64 c = sm.aux[i];
+                  pc += c;
+                  acc_r += sm.val[i];
+                  acc_s += sval * c;
+                } else if (FIRST) {
+                  best = sm.aux[i];
+                } else {
+                  do {  // every build row with this key
                     const u64 rval = sm.val[i];
                     pc++;
                     acc_r += rval;
@@ -138,12 +225,12 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
                       acc_x ^= m;
                       acc_m += m;
                     }
-                  }
+                    i = sm.aux[i];
+                  } while (i != NIL);
                 }
-                i = sm.next[i];
               }
               if (FIRST && best != NIL && first_claim(a.matched, multi, sb + j)) {
-                const u64 rval = sm.val[best];
+                const u64 rval = R[(u64)rb + best].val;  // the row itself is not kept in LDS
                 pc++;
                 acc_r += rval;
                 acc_s += sval;
@@ -166,18 +253,16 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
             key = t.key;
             sval = t.val;
             u32 i = sm.head[tab_hash(key)];
-            while (i != NIL) {
-              if (sm.key[i] == key) {
-                if (FIRST) {
-                  first = (i < first) ? i : first;
-                } else {
-                  if (m == 0) first = i;
-                  m++;
-                }
+            while (i != NIL && sm.key[i] != key) i = sm.next[i];
+            if (i != NIL) {
+              if (FIRST) {
+                first = sm.aux[i];
+                m = first_claim(a.matched, multi, sb + j) ? 1u : 0u;
+              } else {
+                first = i;
+                for (u32 n = i; n != NIL; n = sm.aux[n]) m++;
               }
-              i = sm.next[i];
             }
-            if (FIRST) m = (first != NIL && first_claim(a.matched, multi, sb + j)) ? 1u : 0u;
           }
           u32 tot;
           const u32 off = block_excl_scan_u32<PB_THREADS>(m, sm.scratch, &tot);
@@ -185,24 +270,21 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
             u64 o = run + off;
             if (m == 1) {
               a.out_key[o] = key;
-              a.out_rval[o] = sm.val[first];
+              a.out_rval[o] = FIRST ? R[(u64)rb + first].val : sm.val[first];
               a.out_sval[o] = sval;
             } else {
-              u32 i = sm.head[tab_hash(key)];
-              while (i != NIL) {
-                if (sm.key[i] == key) {
-                  a.out_key[o] = key;
-                  a.out_rval[o] = sm.val[i];
-                  a.out_sval[o] = sval;
-                  o++;
-                }
-                i = sm.next[i];
+              for (u32 n = first; n != NIL; n = sm.aux[n]) {
+                a.out_key[o] = key;
+                a.out_rval[o] = sm.val[n];
+                a.out_sval[o] = sval;
+                o++;
               }
             }
           }
           run += tot;
         }
       }
+      first_table = false;
     }
 
     acc_n += pc;
