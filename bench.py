@@ -187,6 +187,24 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr,
                     "bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 4)}
 
+        # what a plain device-to-device copy reaches on this box (read + write bytes), for scale beside
+        # the spec peak: the scatter is a copy with a permutation
+        copy_gbs = None
+        try:
+            src = torch.empty(1 << 28, dtype=torch.int64, device=dev)  # 2 GiB
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = round(2 * src.numel() * 8 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except Exception:
+            copy_gbs = None
+
         line = {
             "metric": "probe-side tuples/s + achieved HBM GB/s, |R|=|S|=2^28 u64 keys",
             "value": n_total * K / dt,
@@ -199,7 +217,7 @@ def main():
                                                             "materialised columns" if a.materialize else "count+sum (hashjoin_bench.cc:131-133)"),
                        "rows_per_relation_per_gpu": n, "rows_per_relation_total": n_total,
                        "parallelism": "radix-sharded x%d" % world},
-            "roofline": dict(roof(sc_bytes, sc_ms, traffic), kernel="radix_scatter_kernel",
+            "roofline": dict(roof(sc_bytes, sc_ms, traffic), kernel="radix_scatter_kernel", device_copy_GBps=copy_gbs,
                              launches_per_step=launches // K, kernel_name="radix_slab_a_kernel / radix_slab_b_kernel (write-combining stable scatter, mean of the launches)"),
             "roofline_probe": dict(roof(pr_bytes, pr_ms), kernel="probe_kernel<count>",
                                    probe_tuples_per_s=round(n / (pr_ms * 1e-3)) if pr_ms > 0 else None),

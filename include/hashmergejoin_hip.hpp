@@ -78,7 +78,51 @@ struct is_hmj_relation_iter {
                                             typename std::iterator_traits<Iter>::iterator_category>::value;
 };
 
+// Join two relations given as {64-bit hash, row index} rows on the GPU and keep the pairs whose KEYS are
+// equal (eq(r_row, s_row)); inside a run of equal hashes the pairs are ordered by key (less(r_row_a,
+// r_row_b)), as the reference's sort does (radix_hash.h:86-109 breaks hash ties on the key).  Fills the
+// matching row indices in iteration order.
+template <typename Eq, typename Less>
+inline void join_hashed_rows(const std::vector<std::pair<std::uint64_t, std::uint64_t>>& hr,
+                             const std::vector<std::pair<std::uint64_t, std::uint64_t>>& hs, unsigned num_threads,
+                             Eq eq, Less less, std::vector<std::uint64_t>& ri, std::vector<std::uint64_t>& si) {
+  hmj_ctx* c = thread_ctx();
+  hmj_set_host_threads(c, num_threads > 16 ? 16 : (int)num_threads);
+  hmj_result res;
+  hmj_rows* rows = nullptr;
+  check(c, hmj_join_u64_rows(c, hr.empty() ? nullptr : hr.data(), hr.size(), hs.empty() ? nullptr : hs.data(),
+                             hs.size(), HMJ_MATERIALIZE | HMJ_ORDERED, &res, &rows), "hmj_join_u64_rows");
+  std::shared_ptr<hmj_rows> guard(rows, hmj_rows_free);
+  // rows are (hash, r index, s index) in ascending hash
+  const std::size_t n = (std::size_t)res.n_matches;
+  ri.reserve(n);
+  si.reserve(n);
+  std::size_t i = 0;
+  while (i < n) {
+    std::size_t j = i + 1;
+    while (j < n && res.key[j] == res.key[i]) j++;
+    const std::size_t first = ri.size();
+    for (std::size_t k = i; k < j; k++)
+      if (eq(res.rval[k], res.sval[k])) {
+        ri.push_back(res.rval[k]);
+        si.push_back(res.sval[k]);
+      }
+    if (ri.size() - first > 1) {  // several rows share this hash: order them by key
+      std::vector<std::pair<std::uint64_t, std::uint64_t>> grp;
+      for (std::size_t k = first; k < ri.size(); k++) grp.emplace_back(ri[k], si[k]);
+      std::stable_sort(grp.begin(), grp.end(),
+                       [&](const std::pair<std::uint64_t, std::uint64_t>& a,
+                           const std::pair<std::uint64_t, std::uint64_t>& b) { return less(a.first, b.first); });
+      for (std::size_t k = 0; k < grp.size(); k++) {
+        ri[first + k] = grp[k].first;
+        si[first + k] = grp[k].second;
+      }
+    }
+    i = j;
+  }
+}
 }  // namespace hmj_detail
+
 
 // Primary template.  Native == true : uint64_t keys with 8-byte payloads in contiguous storage go to the
 //                                       GPU as they are (the path BASELINE.json names).
@@ -233,44 +277,10 @@ class HashMergeJoin<RIter, SIter, false> {
     std::vector<std::pair<std::uint64_t, std::uint64_t>> hr, hs;
     hash_rows(r_begin, nr, hr, num_threads);
     hash_rows(s_begin, ns, hs, num_threads);
-    hmj_ctx* c = hmj_detail::thread_ctx();
-    hmj_set_host_threads(c, num_threads > 16 ? 16 : (int)num_threads);
-    hmj_result res;
-    hmj_rows* rows = nullptr;
-    hmj_detail::check(c, hmj_join_u64_rows(c, nr ? hr.data() : nullptr, nr, ns ? hs.data() : nullptr, ns,
-                                           HMJ_MATERIALIZE | HMJ_ORDERED, &res, &rows), "hmj_join_u64_rows");
-    std::shared_ptr<hmj_rows> guard(rows, hmj_rows_free);
-    // rows are (hash, r index, s index) in ascending (hash, r index, s index).  Keep the pairs whose
-    // KEYS are equal; inside a run of equal hashes order by key, as the reference's sort does
-    // (radix_hash.h:86-109 breaks hash ties on the key).
-    const std::size_t n = (std::size_t)res.n_matches;
-    _ri.reserve(n);
-    _si.reserve(n);
-    std::size_t i = 0;
-    while (i < n) {
-      std::size_t j = i + 1;
-      while (j < n && res.key[j] == res.key[i]) j++;
-      const std::size_t first = _ri.size();
-      for (std::size_t k = i; k < j; k++)
-        if (r_begin[res.rval[k]].first == s_begin[res.sval[k]].first) {
-          _ri.push_back(res.rval[k]);
-          _si.push_back(res.sval[k]);
-        }
-      if (_ri.size() - first > 1) {  // several rows share this hash: order them by key
-        std::vector<std::pair<std::uint64_t, std::uint64_t>> grp;
-        for (std::size_t k = first; k < _ri.size(); k++) grp.emplace_back(_ri[k], _si[k]);
-        std::stable_sort(grp.begin(), grp.end(),
-                         [&](const std::pair<std::uint64_t, std::uint64_t>& a,
-                             const std::pair<std::uint64_t, std::uint64_t>& b) {
-                           return r_begin[a.first].first < r_begin[b.first].first;
-                         });
-        for (std::size_t k = 0; k < grp.size(); k++) {
-          _ri[first + k] = grp[k].first;
-          _si[first + k] = grp[k].second;
-        }
-      }
-      i = j;
-    }
+    hmj_detail::join_hashed_rows(
+        hr, hs, num_threads,
+        [&](std::uint64_t r, std::uint64_t q) { return r_begin[r].first == s_begin[q].first; },
+        [&](std::uint64_t x, std::uint64_t y) { return r_begin[x].first < r_begin[y].first; }, _ri, _si);
   }
 
   class iterator : public std::iterator<std::input_iterator_tag, std::tuple<Key*, RValue*, SValue*>> {
@@ -313,6 +323,92 @@ class HashMergeJoin<RIter, SIter, false> {
   RIter _r;
   SIter _s;
   std::vector<std::uint64_t> _ri, _si;  // matching row indices into the caller's relations
+};
+
+// ---------------------------------------------------------------------------------------------------
+// HashMergeJoin2 (hashjoin.h:201-363): the relations arrive PRE-HASHED as std::tuple<size_t hash, Key,
+// Value> rows.  The reference sorts both buffers in place on (hash, key) (radix_inplace_par,
+// radix_hash.h:589-654) and merges them; here the GPU joins the {hash, row index} rows, the host keeps
+// the pairs whose keys are equal, and iteration runs in the same ascending (hash, key) order.
+// operator* points into the caller's buffers, as the reference's does.  One documented difference: the
+// caller's buffers are left as they are (the reference leaves them sorted as a side effect).
+// ---------------------------------------------------------------------------------------------------
+template <typename RIter, typename SIter>
+class HashMergeJoin2 {
+  static_assert(std::is_same<typename std::tuple_element<1, typename RIter::value_type>::type,
+                             typename std::tuple_element<1, typename SIter::value_type>::type>::value,
+                "RIter and SIter key type must be the same");
+  static_assert(std::is_same<typename RIter::difference_type, typename SIter::difference_type>::value,
+                "RIter and SIter difference type must be the same");
+  static_assert(std::is_base_of<std::random_access_iterator_tag,
+                                typename std::iterator_traits<RIter>::iterator_category>::value &&
+                    std::is_base_of<std::random_access_iterator_tag,
+                                    typename std::iterator_traits<SIter>::iterator_category>::value,
+                "random access iterators are required");
+
+  typedef typename std::tuple_element<1, typename RIter::value_type>::type Key;
+  typedef typename std::tuple_element<2, typename RIter::value_type>::type RValue;
+  typedef typename std::tuple_element<2, typename SIter::value_type>::type SValue;
+
+  template <typename Iter>
+  static void hash_column(Iter begin, std::size_t n, std::vector<std::pair<std::uint64_t, std::uint64_t>>& out) {
+    out.resize(n);
+    for (std::size_t i = 0; i < n; i++) out[i] = std::make_pair((std::uint64_t)std::get<0>(begin[i]), (std::uint64_t)i);
+  }
+
+ public:
+  HashMergeJoin2() = default;
+  HashMergeJoin2(RIter r_begin, RIter r_end, SIter s_begin, SIter s_end, unsigned int num_threads = 1)
+      : _r(r_begin), _s(s_begin) {
+    std::vector<std::pair<std::uint64_t, std::uint64_t>> hr, hs;
+    hash_column(r_begin, (std::size_t)std::distance(r_begin, r_end), hr);
+    hash_column(s_begin, (std::size_t)std::distance(s_begin, s_end), hs);
+    hmj_detail::join_hashed_rows(
+        hr, hs, num_threads,
+        [&](std::uint64_t r, std::uint64_t q) { return std::get<1>(r_begin[r]) == std::get<1>(s_begin[q]); },
+        [&](std::uint64_t x, std::uint64_t y) { return std::get<1>(r_begin[x]) < std::get<1>(r_begin[y]); }, _ri,
+        _si);
+  }
+
+  class iterator : public std::iterator<std::input_iterator_tag, std::tuple<Key*, RValue*, SValue*>> {
+   public:
+    iterator(HashMergeJoin2* owner, std::size_t pos) : _owner(owner), _pos(pos) {}
+    iterator& operator++() {
+      ++_pos;
+      return *this;
+    }
+    iterator operator++(int) {
+      iterator retval = *this;
+      ++(*this);
+      return retval;
+    }
+    bool operator==(iterator other) const { return _pos == other._pos; }
+    bool operator!=(iterator other) const { return _pos != other._pos; }
+    std::tuple<Key*, RValue*, SValue*>& operator*() {
+      typename RIter::value_type& rr = _owner->_r[_owner->_ri[_pos]];
+      typename SIter::value_type& ss = _owner->_s[_owner->_si[_pos]];
+      tmp_val = std::make_tuple(&std::get<1>(rr), &std::get<2>(rr), &std::get<2>(ss));
+      return tmp_val;
+    }
+
+   protected:
+    HashMergeJoin2* _owner;
+    std::size_t _pos;
+    std::tuple<Key*, RValue*, SValue*> tmp_val;
+  };
+
+  iterator begin() { return iterator(this, 0); }
+  iterator end() { return iterator(this, _ri.size()); }
+  void clear() {
+    _ri.clear();
+    _si.clear();
+  }
+  std::size_t size() const { return _ri.size(); }
+
+ protected:
+  RIter _r;
+  SIter _s;
+  std::vector<std::uint64_t> _ri, _si;  // matching row indices into the caller's buffers
 };
 
 // Convenience spelled the way BASELINE.json's north_star names the entry point.

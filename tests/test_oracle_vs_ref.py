@@ -46,6 +46,14 @@ def test_joins_match_reference(oracle, reference, nr, ns, dom):
     sh = np.stack([S[:, 0], S[:, 0], S[:, 1]], 1)
     a, b = oracle.hashmergejoin2(rh, sh), reference.hashmergejoin2(rh, sh, 1)
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+    # a poor pre-computed hash (many different keys share one): keys unique per relation, the domain of
+    # tests/cpp/test_dropin.cc's HashMergeJoin2 cases
+    Ru, Su = R[np.unique(R[:, 0], return_index=True)[1]], S[np.unique(S[:, 0], return_index=True)[1]]
+    for m in [7, 997]:
+        rh = np.stack([Ru[:, 0] % np.uint64(m), Ru[:, 0], Ru[:, 1]], 1)
+        sh = np.stack([Su[:, 0] % np.uint64(m), Su[:, 0], Su[:, 1]], 1)
+        a, b = oracle.hashmergejoin2(rh, sh), reference.hashmergejoin2(rh, sh, 1)
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
     for bits in [1, 4, 10]:
         assert oracle.partitioned_join_sum(S, R, bits) == reference.partitioned_join_sum(S, R, 1, bits)
         assert np.array_equal(oracle.partition_sizes(R, bits), reference.partition_only(R, 3, bits))
