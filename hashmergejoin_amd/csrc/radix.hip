@@ -108,7 +108,7 @@ __device__ __forceinline__ void load_tile(Tup (&t)[RP_ITEMS], const Tup* __restr
                                           u32 wbase, u32 tile_n) {
 #pragma unroll
   for (int r = 0; r < RP_ITEMS; r++)
-    if (FULL || wbase + r * 64 < tile_n) t[r] = src[wbase + r * 64];
+    if (FULL || wbase + r * 64 < tile_n) t[r] = load_stream(&src[wbase + r * 64]);
 }
 
 // FULL = true : workers that own only whole tiles (the bulk; no predication anywhere).
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
         const u32 i = (h * (RP_ITEMS / 2) + r) * RP_THREADS + tid;
         if (FULL || i < tile_n) {
           const u32 d = digit_of<HI>(v[r].key, shift, mask);
-          out[sm.delta[d] + i] = v[r];
+          store_stream(&out[sm.delta[d] + i], v[r]);
         }
       }
     }
@@ -394,7 +394,7 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
       const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu, cfd = sm.cf_tile[d];
       const u32 grow = (cfd & ~(u32)(WC_LINE - 1)) + (L - sm.line_off[d]) * WC_LINE + k;
       const u32 j = grow - cfd;  // wraps (huge) for the slots before an unaligned segment start
-      if (j < fl) out[grow] = (j < pd) ? sm.carry[d][j] : sm.stage[sm.tile_off[d] + j - pd];
+      if (j < fl) store_stream(&out[grow], (j < pd) ? sm.carry[d][j] : sm.stage[sm.tile_off[d] + j - pd]);
     }
   }
   // rows that stay behind (each digit's new partial line): stage -> registers
@@ -446,7 +446,7 @@ __device__ __forceinline__ void wc_flush_carry(WcSmem<THREADS, MAXD>& sm, Tup* _
 #pragma unroll
   for (int q = 0; q < WC_ITEMS; q++) {
     const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
-    if (d < D && k < sm.pend[d]) out[sm.cflush[d] + k] = sm.carry[d][k];
+    if (d < D && k < sm.pend[d]) store_stream(&out[sm.cflush[d] + k], sm.carry[d][k]);
   }
 }
 
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   Tup t[WC_ITEMS];
 #pragma unroll
   for (int r = 0; r < WC_ITEMS; r++)
-    if (FULL || begin + wbase + r * 64 < end) t[r] = in[begin + wbase + r * 64];
+    if (FULL || begin + wbase + r * 64 < end) t[r] = load_stream(&in[begin + wbase + r * 64]);
 
   bool ovf = false;
   for (u64 tile = begin; tile < end; tile += TILE) {
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
           if (FULL && tile + TILE < end) {
             const Tup* src = in + tile + TILE;
 #pragma unroll
-            for (int r = 0; r < WC_ITEMS; r++) t[r] = src[wbase + r * 64];
+            for (int r = 0; r < WC_ITEMS; r++) t[r] = load_stream(&src[wbase + r * 64]);
           }
         },
         nullptr, &ovf);
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 #pragma unroll
       for (int r = 0; r < WC_ITEMS; r++) {
         const u32 q = wbase + r * 64;
-        t[r] = in[begin + (q < tn ? q : tn - 1)];  // clamped, unpredicated: loads issue back to back
+        t[r] = load_stream(&in[begin + (q < tn ? q : tn - 1)]);  // clamped, unpredicated: loads issue back to back
       }
     }
     for (u64 tile = begin; tile < end; tile += TILE) {
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 #pragma unroll
               for (int r = 0; r < WC_ITEMS; r++) {
                 const u32 q = wbase + r * 64;
-                t[r] = src[q < tn ? q : tn - 1];
+                t[r] = load_stream(&src[q < tn ? q : tn - 1]);
               }
             }
           },
