@@ -215,7 +215,8 @@ void plan_bits(u64 n_build, int force, int* total, int* passes, int pass_bits[4]
   if (force >= 0) {
     B = force;
   } else {
-    u64 parts = (n_build + hmj::PB_TARGET_AVG - 1) / hmj::PB_TARGET_AVG;
+    const u64 avg_max = hmj::PB_TARGET_AVG + hmj::PB_PLAN_SLACK;
+    u64 parts = (n_build + avg_max - 1) / avg_max;
     while ((1ull << B) < parts) B++;
   }
   if (B > 27) B = 27;

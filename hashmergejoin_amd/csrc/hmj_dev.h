@@ -58,6 +58,8 @@ constexpr int PB_THREADS = 1024;       // generic kernel: 106 KiB LDS -> one 16-
 constexpr int PB_CAP = 5120;           // build rows resident in LDS per chunk
 constexpr int PB_LOG_NB = 12;          // 4096 chain heads
 constexpr int PB_TARGET_AVG = 4096;    // planner: average build rows per partition
+constexpr int PB_PLAN_SLACK = 256;     // planner: tolerated excess of that average before another bit is spent
+                                       // (a shard of 2^28 + a few rows after an exchange must not fall to 17 bits)
 // Measured at |R|=|S|=2^28 (tools/exp_bits.py): 16 bits (avg 4096 rows/partition, two 8-bit
 // write-combining passes) 12.45 ms per join vs 17 bits (avg 2048, 9+8) 13.02 ms, 18 bits 13.9 ms,
 // 15 bits 14.6 ms: fewer, larger partitions win as long as one still fits the LDS table.

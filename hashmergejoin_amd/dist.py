@@ -25,6 +25,64 @@ def split_counts_from_offsets(offsets):
     return [int(x) for x in (o[1:] - o[:-1]).tolist()]
 
 
+# RCCL (2.26) truncates a single all-to-all message of 2 GiB or more (seen on MI355X: a 2^27-row bucket
+# arrives half empty).  Buckets are therefore sent in rounds of at most MAX_MSG_BYTES per peer; the
+# receive side places every round's slice at its final position, so the received rows stay grouped by
+# source rank in shard order (= global input order, which HMJ_FIRST_WINS relies on).
+MAX_MSG_BYTES = 1 << 30
+
+
+class _Works:
+    """wait() for every queued round (they run in order on the communicator's stream)."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+def _starts(counts):
+    out, acc = [], 0
+    for c in counts:
+        out.append(acc)
+        acc += c
+    return out
+
+
+def _exchange_counts(parted, send_counts, group):
+    """All ranks learn the whole G x G count matrix (one tiny all-gather): returns (this rank's receive
+    counts, the largest single message of the exchange in rows) -- the latter so that every rank splits
+    the exchange into the same number of rounds."""
+    world = dist.get_world_size(group)
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=parted.device)
+    rows = [torch.empty(world, dtype=torch.int64, device=parted.device) for _ in range(world)]
+    dist.all_gather(rows, sc, group=group)
+    m = torch.stack(rows).cpu()  # m[src][dst]
+    me = dist.get_rank(group)
+    return [int(x) for x in m[:, me].tolist()], int(m.max().item())
+
+
+def _exchange_data(parted, send_counts, recv_counts, biggest_rows, group, async_op):
+    """Queue the data exchange; returns (rows, work or None)."""
+    parted = parted.contiguous()
+    row_bytes = parted.shape[1] * parted.element_size()
+    out = torch.empty((sum(recv_counts), parted.shape[1]), dtype=parted.dtype, device=parted.device)
+    rounds = max(1, -(-(biggest_rows * row_bytes) // MAX_MSG_BYTES))
+    if rounds == 1:
+        work = dist.all_to_all_single(out, parted, output_split_sizes=list(recv_counts),
+                                      input_split_sizes=list(send_counts), group=group, async_op=async_op)
+        return out, work
+    s0, r0 = _starts(send_counts), _starts(recv_counts)
+    works = []
+    for r in range(rounds):
+        ins = [parted[s0[g] + r * c // rounds: s0[g] + (r + 1) * c // rounds] for g, c in enumerate(send_counts)]
+        outs = [out[r0[g] + r * c // rounds: r0[g] + (r + 1) * c // rounds] for g, c in enumerate(recv_counts)]
+        works.append(dist.all_to_all(outs, ins, group=group, async_op=async_op))
+    return out, (_Works(works) if async_op else None)
+
+
 def exchange_rows(parted, send_counts, group=None):
     """parted: [n,2] int64 rows already grouped by owner (owner-major); send_counts[g] rows go to
     rank g.  Returns ([m,2] rows received, recv_counts).  Works on CPU tensors (gloo) and device
@@ -36,13 +94,13 @@ def exchange_rows(parted, send_counts, group=None):
         # stage through host memory.  The production path is RCCL on device tensors, below.
         rows, rc = exchange_rows(parted.cpu(), send_counts, group)
         return rows.to(parted.device), rc
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=parted.device)
-    rc = torch.empty(world, dtype=torch.int64, device=parted.device)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(x) for x in rc.tolist()]
-    out = torch.empty((sum(recv_counts), 2), dtype=parted.dtype, device=parted.device)
-    dist.all_to_all_single(out, parted.contiguous(), output_split_sizes=recv_counts,
-                           input_split_sizes=list(send_counts), group=group)
+    recv_counts, biggest = _exchange_counts(parted, send_counts, group)
+    if dist.get_backend(group) == "gloo":  # CPU tests: small, and gloo has no list all-to-all
+        out = torch.empty((sum(recv_counts), 2), dtype=parted.dtype, device=parted.device)
+        dist.all_to_all_single(out, parted.contiguous(), output_split_sizes=recv_counts,
+                               input_split_sizes=list(send_counts), group=group)
+        return out, recv_counts
+    out, _ = _exchange_data(parted, send_counts, recv_counts, biggest, group, async_op=False)
     return out, recv_counts
 
 
@@ -55,14 +113,8 @@ def exchange_rows_async(parted, send_counts, group=None):
     if dist.get_backend(group) != "nccl" or not parted.is_cuda:
         rows, _ = exchange_rows(parted, send_counts, group)
         return rows, None
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=parted.device)
-    rc = torch.empty(world, dtype=torch.int64, device=parted.device)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(x) for x in rc.tolist()]
-    out = torch.empty((sum(recv_counts), 2), dtype=parted.dtype, device=parted.device)
-    work = dist.all_to_all_single(out, parted.contiguous(), output_split_sizes=recv_counts,
-                                  input_split_sizes=list(send_counts), group=group, async_op=True)
-    return out, work
+    recv_counts, biggest = _exchange_counts(parted, send_counts, group)
+    return _exchange_data(parted, send_counts, recv_counts, biggest, group, async_op=True)
 
 
 def allreduce_checks(local, device, group=None):

@@ -47,7 +47,9 @@ def test_planner():
     # average build partition <= 4096 rows (LDS table of probe.hip), <= 9 bits per LSD pass
     assert H.plan(0) == (0, [])
     assert H.plan(4096) == (0, [])
-    assert H.plan(4097) == (1, [1])
+    assert H.plan(4097) == (0, [])  # up to 4096 + 256 rows per partition are tolerated
+    assert H.plan(4353) == (1, [1])
+    assert H.plan((1 << 28) + 100000) == (16, [8, 8])  # a shard slightly over 2^28 keeps the 2 x 8-bit plan
     assert H.plan(10 ** 6) == (8, [8])
     assert H.plan(1 << 26) == (14, [7, 7])
     assert H.plan(1 << 28) == (16, [8, 8])

@@ -461,7 +461,7 @@ def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
 def test_slab_path_parity_and_fallback(ex, H, oracle):
     # The histogram-free slab path (plain count joins, >= 2^22 rows per side) against the CPU oracle,
     # including ragged sizes, a probe side of a different size, and misses.
-    for nb, npb, miss in [(1 << 22, 1 << 22, 0), ((1 << 22) + 12345, (1 << 23) - 777, 3)]:
+    for nb, npb, miss in [(1 << 22, 1 << 22, 0), ((1 << 22) + 12345, 4500000 - 777, 3)]:
         B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=miss)
         ck, _ = oracle.equijoin(B, P, cap=0)
         ex.set_profiling(True)
