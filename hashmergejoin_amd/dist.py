@@ -64,6 +64,23 @@ def _exchange_counts(parted, send_counts, group):
     return [int(x) for x in m[:, me].tolist()], int(m.max().item())
 
 
+def _list_all_to_all(outs, ins, group, async_op):
+    """dist.all_to_all on tensor lists; gloo has none, so CPU tests get point-to-point transfers."""
+    if dist.get_backend(group) == "nccl":
+        return dist.all_to_all(outs, ins, group=group, async_op=async_op)
+    me, reqs = dist.get_rank(group), []
+    for g in range(dist.get_world_size(group)):
+        if g == me:
+            outs[g].copy_(ins[g])
+            continue
+        peer = g if group is None else dist.get_global_rank(group, g)
+        reqs.append(dist.isend(ins[g].contiguous(), dst=peer, group=group))
+        reqs.append(dist.irecv(outs[g], src=peer, group=group))
+    for q in reqs:
+        q.wait()
+    return None
+
+
 def _exchange_data(parted, send_counts, recv_counts, biggest_rows, group, async_op):
     """Queue the data exchange; returns (rows, work or None)."""
     parted = parted.contiguous()
@@ -79,8 +96,8 @@ def _exchange_data(parted, send_counts, recv_counts, biggest_rows, group, async_
     for r in range(rounds):
         ins = [parted[s0[g] + r * c // rounds: s0[g] + (r + 1) * c // rounds] for g, c in enumerate(send_counts)]
         outs = [out[r0[g] + r * c // rounds: r0[g] + (r + 1) * c // rounds] for g, c in enumerate(recv_counts)]
-        works.append(dist.all_to_all(outs, ins, group=group, async_op=async_op))
-    return out, (_Works(works) if async_op else None)
+        works.append(_list_all_to_all(outs, ins, group, async_op))
+    return out, (_Works(works) if async_op and works[0] is not None else None)
 
 
 def exchange_rows(parted, send_counts, group=None):
@@ -95,11 +112,6 @@ def exchange_rows(parted, send_counts, group=None):
         rows, rc = exchange_rows(parted.cpu(), send_counts, group)
         return rows.to(parted.device), rc
     recv_counts, biggest = _exchange_counts(parted, send_counts, group)
-    if dist.get_backend(group) == "gloo":  # CPU tests: small, and gloo has no list all-to-all
-        out = torch.empty((sum(recv_counts), 2), dtype=parted.dtype, device=parted.device)
-        dist.all_to_all_single(out, parted.contiguous(), output_split_sizes=recv_counts,
-                               input_split_sizes=list(send_counts), group=group)
-        return out, recv_counts
     out, _ = _exchange_data(parted, send_counts, recv_counts, biggest, group, async_op=False)
     return out, recv_counts
 

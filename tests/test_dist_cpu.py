@@ -32,6 +32,8 @@ p0, p1 = rank * npb // world, (rank + 1) * npb // world
 Bs = o.gen_build(b1 - b0, start=b0)
 Ps = o.gen_probe(p1 - p0, nb, start=p0, miss_mod=miss)
 bits = hdist.owner_bits(world)
+if os.environ.get("MAXMSG"):  # force the multi-round exchange (production: messages of 1 GiB and more)
+    hdist.MAX_MSG_BYTES = int(os.environ["MAXMSG"])
 recv = []
 for rel in (Bs, Ps):
     parted, off = o.stable_partition(rel, 64 - bits, bits)        # stand-in for hmj_partition_u64_device
@@ -41,6 +43,10 @@ for rel in (Bs, Ps):
     rows = rows.numpy().view(np.uint64)
     # every received row belongs to this rank's key range
     assert len(rows) == 0 or bool(np.all((rows[:, 0] >> np.uint64(64 - bits)) == np.uint64(rank)))
+    # and the rows arrive grouped by source rank in shard order = global input order
+    assert len(rows) == sum(rc)
+    if rel is Bs and len(rows):
+        assert bool(np.all(np.diff(rows[:, 1].astype(np.int64)) > 0))  # build payload = global row index
     recv.append(rows)
 ck, rows = o.equijoin(recv[0], recv[1])                            # stand-in for hmj_join_u64_device
 glob = hdist.allreduce_checks(ck, torch.device("cpu"))
@@ -60,13 +66,15 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,nb,npb,miss", [(2, 5000, 7000, 3), (4, 1 << 14, 1 << 14, 0)])
-def test_exchange_two_ranks_gloo(oracle, tmp_path, world, nb, npb, miss):
+@pytest.mark.parametrize("world,nb,npb,miss,maxmsg", [(2, 5000, 7000, 3, 0), (4, 1 << 14, 1 << 14, 0, 0),
+                                                        (2, 5000, 7000, 3, 4096), (4, 1 << 14, 3000, 2, 1000)])
+def test_exchange_two_ranks_gloo(oracle, tmp_path, world, nb, npb, miss, maxmsg):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HMJ_ROOT=ROOT, NB=str(nb), NP=str(npb), MISS=str(miss), OUT=str(tmp_path), OMP_NUM_THREADS="1")
+                   HMJ_ROOT=ROOT, NB=str(nb), NP=str(npb), MISS=str(miss), OUT=str(tmp_path), OMP_NUM_THREADS="1",
+                   MAXMSG=str(maxmsg) if maxmsg else "")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
