@@ -72,6 +72,8 @@ def load_library():
     L.hmj_reserve.argtypes = [vp, u, u, u, C.c_uint32]
     L.hmj_set_radix_bits.restype = i
     L.hmj_set_radix_bits.argtypes = [vp, i]
+    L.hmj_autotune_radix_bits.restype = i
+    L.hmj_autotune_radix_bits.argtypes = [vp, u, u, i, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.hmj_set_key_prefix_bits.restype = i
     L.hmj_set_key_prefix_bits.argtypes = [vp, i]
     L.hmj_plan.restype = i

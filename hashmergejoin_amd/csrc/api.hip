@@ -858,6 +858,56 @@ int hmj_set_radix_bits(hmj_ctx* c, int total_bits) {
   return HMJ_OK;
 }
 
+int hmj_autotune_radix_bits(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, int apply, int* best_bits,
+                            double ms[3]) {
+  if (!c || !best_bits) return HMJ_E_ARG;
+  if (n_build == 0 || n_probe == 0 || n_build >= (1ull << 32) || n_probe >= (1ull << 32))
+    return fail(c, HMJ_E_ARG, "autotune needs 0 < rows < 2^32 per relation");
+  HIP_TRY(hipSetDevice(c->device));
+  int B0, passes, pb[4];
+  plan_bits(n_build, -1, &B0, &passes, pb);
+  void *R = nullptr, *S = nullptr;
+  if (hipMalloc(&R, n_build * 16) != hipSuccess || hipMalloc(&S, n_probe * 16) != hipSuccess) {
+    if (R) (void)hipFree(R);
+    return fail(c, HMJ_E_OOM, "autotune: device memory for the synthetic relations");
+  }
+  const u64 seed = 0x243F6A8885A308D3ull;
+  int rc = HMJ_OK;
+  const int saved = c->force_bits;
+  double best = -1.0;
+  int best_b = B0;
+  if (hmj::launch_gen_build(R, n_build, 0, seed, c->stream) != hipSuccess ||
+      hmj::launch_gen_probe(S, n_probe, 0, n_build, seed, 0, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess)
+    rc = fail(c, HMJ_E_HIP, "autotune: generating the synthetic relations failed");
+  for (int k = 0; k < 3 && rc == HMJ_OK; k++) {
+    const int b = B0 - 1 + k;
+    if (ms) ms[k] = -1.0;
+    if (b < 0 || b > 27) continue;
+    c->force_bits = b;
+    double t_best = -1.0;
+    for (int rep = 0; rep < 3 && rc == HMJ_OK; rep++) {  // first run also pays for the workspace
+      hmj_result res;
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = join_device(c, R, n_build, S, n_probe, 0, &res, false);
+      const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (rc == HMJ_OK && res.n_matches != n_probe) rc = fail(c, HMJ_E_HIP, "autotune: wrong match count");
+      if (rep > 0 && (t_best < 0 || t < t_best)) t_best = t;
+    }
+    if (ms) ms[k] = t_best;
+    if (rc == HMJ_OK && (best < 0 || t_best < best)) {
+      best = t_best;
+      best_b = b;
+    }
+  }
+  (void)hipFree(R);
+  (void)hipFree(S);
+  c->force_bits = (rc == HMJ_OK && apply) ? best_b : saved;
+  c->prep.valid = false;
+  if (rc == HMJ_OK) *best_bits = best_b;
+  return rc;
+}
+
 int hmj_set_key_prefix_bits(hmj_ctx* c, int bits) {
   if (!c || bits < -1 || bits > 48) return HMJ_E_ARG;
   c->prefix_bits = bits;

@@ -155,12 +155,22 @@ class Executor:
                                                     C.c_void_p(off.data_ptr())))
         return out, off
 
-    def sort_device(self, rel):
-        """Full ascending-key sort of a device relation (hmj_sort_u64_device); returns a new tensor."""
+    def autotune(self, n_build, n_probe, apply=True):
+        """Time the join of synthetic relations with B-1, B, B+1 radix bits (hmj_autotune_radix_bits).
+        Returns (best_bits, {bits: ms}); apply=True keeps the fastest as this executor's plan."""
+        self._sync_stream()
+        best, ms = C.c_int(0), (C.c_double * 3)()
+        self._check(self.L.hmj_autotune_radix_bits(self.h, n_build, n_probe, 1 if apply else 0, C.byref(best), ms))
+        b0 = plan(n_build)[0]
+        return best.value, {b0 - 1 + k: ms[k] for k in range(3) if ms[k] >= 0}
+
+    def sort_device(self, rel, inplace=False):
+        """Full ascending-key sort of a device relation (hmj_sort_u64_device); returns a new tensor, or
+        sorts `rel` itself with inplace=True (the radix_int_inplace replacement)."""
         torch = self._torch
         self._sync_stream()
         ptr, n = _dev_ptr(rel)
-        out = torch.empty_like(rel)
+        out = rel if inplace else torch.empty_like(rel)
         self._check(self.L.hmj_sort_u64_device(self.h, C.c_void_p(ptr), n, C.c_void_p(out.data_ptr())))
         return out
 

@@ -106,6 +106,14 @@ int hmj_reserve(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, uint64_t max_m
 /* Override the planner (the reference's optimal_partition heuristic, radix_hash.h:38-57, is tuned
  * for CPU caches; ours targets LDS capacity).  total_bits < 0 restores automatic planning.       */
 int hmj_set_radix_bits(hmj_ctx* ctx, int total_bits);
+/* Measure the plan instead of trusting the heuristic (the reference tunes its k with
+ * find_k_bench.cc:116-129): joins synthetic relations of the given sizes (unique uniform keys, every
+ * probe row matching once -- the hmj_gen_* generators) with B-1, B and B+1 total radix bits, B being
+ * hmj_plan's choice, and reports the time of each (ms[0..2]; a candidate that does not exist is < 0).
+ * apply != 0 keeps the fastest as the forced plan of this ctx (as hmj_set_radix_bits would).  Needs
+ * 16*(n_build+n_probe) bytes of device memory beside the join's workspace.                         */
+int hmj_autotune_radix_bits(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, int apply, int* best_bits,
+                            double ms[3]);
 /* Tell the executor that the top `bits` key bits are equal in all rows of both relations (an outer
  * radix split already consumed them, e.g. the multi-GPU owner split): partitioning then starts
  * below them, as the reference's recursion masks off consumed bits (radix_hash.h:219-220).
@@ -175,8 +183,10 @@ int hmj_partition_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, i
  * (radix_sort.h:452-522) -- the call radix_bench_par.cc:126-127 times: rows sorted by key, ascending,
  * out of place.  Eight stable 8-bit LSD passes of the write-combining scatter; equal keys keep their
  * input order (the reference is stable in pass 1 only, so on duplicate keys its payload order may
- * differ; the key column and the multiset of rows are identical).  in/out: n x {key,val}, device,
- * must not overlap.                                                                               */
+ * differ; the key column and the multiset of rows are identical).  in/out: n x {key,val}, device.
+ * out == in sorts in place -- the replacement of radix_int_inplace<uint64_t,uint64_t>(begin, n,
+ * num_threads) (radix_sort.h:333-398; radix_bench_par.cc:96), which is unstable: same key column, same
+ * multiset of rows.  A partial overlap of in and out is not allowed.                               */
 int hmj_sort_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, void* out_aos_dev);
 
 /* ---- synthetic relations on device (same integer arithmetic as the oracle) ------- */

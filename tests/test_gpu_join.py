@@ -409,6 +409,37 @@ def test_full_radix_sort_matches_reference_sort(ex, oracle, n):
     assert np.array_equal(got2[:, 0], ref2[:, 0])  # key column equals the reference's
 
 
+def test_sort_in_place_replaces_radix_int_inplace(ex, oracle):
+    # hmj_sort_u64_device with out == in vs the restated radix_int_inplace (radix_sort.h:333-398; the call
+    # radix_bench_par.cc:96 times).  The reference's in-place sort is unstable: same rows, same key column.
+    for n in [1, 777, 12345, (1 << 20) + 3]:
+        rng = np.random.default_rng(n)
+        keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+        a = np.stack([keys, np.arange(n, dtype=np.uint64)], 1)
+        d = to_dev(a)
+        out = ex.sort_device(d, inplace=True)
+        assert out.data_ptr() == d.data_ptr()
+        assert np.array_equal(to_np(d), oracle.radix_int_inplace_t1(a))  # unique keys: one possible result
+
+
+def test_autotune_measures_the_neighbouring_plans(ex, H, oracle):
+    # the plan is measured (B-1, B, B+1), the fastest kept; joins stay exact under any of them
+    nb = npb = 1 << 22
+    b0 = H.plan(nb)[0]
+    best, ms = ex.autotune(nb, npb, apply=True)
+    try:
+        assert best in (b0 - 1, b0, b0 + 1) and set(ms) == {b0 - 1, b0, b0 + 1}
+        assert all(v > 0 for v in ms.values()) and ms[best] == min(ms.values())
+        B, P = oracle.gen_build(300000), oracle.gen_probe(200000, 300000, miss_mod=3)
+        ck, _ = oracle.equijoin(B, P, cap=0)
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
+        assert r.checks() == ck and ex.last_timing()["radix_bits"] == best
+    finally:
+        ex.set_radix_bits(None)
+    with pytest.raises(H.HmjError):
+        ex.autotune(0, 10)
+
+
 def test_full_radix_sort_golden(ex, G, golden_dir):
     # radix_sort_test.cc:48-68 shape with the committed random input; expected FNV from the
     # compiled reference (unique 64-bit keys -> one possible output)
