@@ -260,25 +260,35 @@ def test_full_size_closed_form(ex, H, log2n):
     assert int(r.n_matches) == n
     assert int(r.sum_r) == (n * (n - 1) // 2) & M64
     assert int(r.sum_s) == sum_xor_range(n, VAL_XOR)
-    if log2n <= 26:
-        r = ex.join_device(bd, pd, H.HMJ_ORDERED)
-        assert int(r.n_matches) == n
-        import ctypes as C
-        import torch
+    import torch
 
-        from hashmergejoin_amd.join import _memcpy_d2d
+    from hashmergejoin_amd.join import _memcpy_d2d
 
-        k = torch.empty(n, dtype=torch.int64, device="cuda")
-        _memcpy_d2d(torch, k, r.key, n * 8)
-        # ascending unsigned order == ascending after flipping the sign bit of the int64 view
-        ks = k ^ torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
-        assert bool((ks[1:] > ks[:-1]).all())
-        rv = torch.empty(n, dtype=torch.int64, device="cuda")
-        _memcpy_d2d(torch, rv, r.rval, n * 8)
-        # rval is the build row index i with key == mix64(i + seed): a permutation of [0,n)
-        assert int(rv.sum().item()) & M64 == (n * (n - 1) // 2) & M64
+    ck = ex.join_device(bd, pd, H.HMJ_CHECKSUM).checks()
+    assert ck["n_matches"] == n
+    sign = torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
+    vx = torch.tensor(VAL_XOR - (1 << 64), dtype=torch.int64, device="cuda")  # VAL_XOR as int64
+    for fl in (H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_ORDERED | H.HMJ_CHECKSUM):
+        r = ex.join_device(bd, pd, fl)
+        assert r.checks() == ck  # same multiset of (key, rval, sval) rows as the count-mode join saw
+        cols = []
+        for ptr in (r.key, r.rval, r.sval):
+            t = torch.empty(n, dtype=torch.int64, device="cuda")
+            _memcpy_d2d(torch, t, ptr, n * 8)
+            cols.append(t)
+        k, rv, sv = cols
+        # every row pairs a build row and a probe row that really carry its key
+        assert bool((bd[rv, 0] == k).all()) and bool((bd[rv, 1] == rv).all())
+        j = sv ^ vx
+        assert bool((pd[j, 0] == k).all()) and bool((pd[j, 1] == sv).all())
+        # rval is a permutation of [0,n): every build row exactly once
         assert int(rv.min().item()) == 0 and int(rv.max().item()) == n - 1
-    ex.release_result()
+        assert int(rv.sum().item()) & M64 == (n * (n - 1) // 2) & M64
+        if fl & H.HMJ_ORDERED:  # ascending unsigned keys == ascending after flipping the int64 sign bit
+            ks = k ^ sign
+            assert bool((ks[1:] > ks[:-1]).all())
+        del cols, k, rv, sv, j
+        ex.release_result()
 
 
 def test_cpp_dropin_operator(G):
