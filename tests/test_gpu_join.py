@@ -20,7 +20,11 @@ def ex():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     import hashmergejoin_amd as H
 
+    # the histogram-free slab path is chosen from 2^25 rows per relation on; the CPU oracle cannot check
+    # joins of that size in seconds, so the tests lower the threshold and exercise it from 2^22 rows
+    os.environ["HMJ_SLAB_MIN_LOG2"] = "22"
     e = H.Executor(0)
+    del os.environ["HMJ_SLAB_MIN_LOG2"]
     yield e
     e.close()
 
