@@ -2,6 +2,7 @@
 // driver that sequences the gfx950 kernels on one HIP stream.  No CPU compute path exists here:
 // every entry point either runs the HIP kernels or returns an error code.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,7 @@ struct DevBuf {
 struct HostBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool pinned = true;  // false: pageable memory on transparent huge pages (the result columns)
 };
 
 enum Kind {
@@ -65,6 +67,7 @@ struct hmj_ctx {
   int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
   u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
+  bool staged_upload = false;  // HMJ_UPLOAD=staged
   u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
                                  // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
@@ -117,8 +120,12 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
   return HMJ_OK;
 }
 
-// Pinned host memory is expensive to create (page pinning), so released buffers go to a process-wide
-// pool and are handed out again (smallest fit within 2x).
+// Host memory is expensive to create, so released buffers go to a process-wide pool and are handed out
+// again (smallest fit within 2x).  Two kinds (measured on the MI355X box, tools/micro/alloc_cost*.hip):
+//   pinned   (hipHostMalloc): 0.15-0.2 ms per MiB to create -- only the small staging slots use it;
+//   pageable on transparent huge pages: the result columns.  A device-to-host copy into FRESH such
+//   memory runs at 24 GB/s, into memory used before at 54 GB/s -- the same as into pinned memory --
+//   so a one-shot join of 2^26 rows gets its 1.5 GiB of result columns in 64 ms instead of 258 ms.
 std::mutex g_pool_mu;
 std::vector<HostBuf> g_pool;
 
@@ -130,11 +137,11 @@ void pool_give(HostBuf& b) {
   b.cap = 0;
 }
 
-bool pool_take(size_t bytes, HostBuf* out) {
+bool pool_take(size_t bytes, bool pinned, HostBuf* out) {
   std::lock_guard<std::mutex> g(g_pool_mu);
   int best = -1;
   for (int i = 0; i < (int)g_pool.size(); i++)
-    if (g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + (1u << 20) &&
+    if (g_pool[i].pinned == pinned && g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + (1u << 20) &&
         (best < 0 || g_pool[i].cap < g_pool[best].cap))
       best = i;
   if (best < 0) return false;
@@ -143,16 +150,25 @@ bool pool_take(size_t bytes, HostBuf* out) {
   return true;
 }
 
-int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes) {
+int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes, bool pinned = true) {
   if (bytes <= b.cap) return HMJ_OK;
   pool_give(b);
-  if (pool_take(bytes, &b)) return HMJ_OK;
+  if (pool_take(bytes, pinned, &b)) return HMJ_OK;
   size_t want = bytes + (bytes >> 4) + 256;
-  hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
-  if (e != hipSuccess) {
-    b.p = nullptr;
-    (void)hipGetLastError();
-    return fail(c, HMJ_E_OOM, "hipHostMalloc", e);
+  b.pinned = pinned;
+  if (pinned) {
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      b.p = nullptr;
+      (void)hipGetLastError();
+      return fail(c, HMJ_E_OOM, "hipHostMalloc", e);
+    }
+  } else {
+    const size_t huge = 2u << 20;
+    want = (want + huge - 1) & ~(huge - 1);
+    b.p = aligned_alloc(huge, want);
+    if (!b.p) return fail(c, HMJ_E_OOM, "host memory for the result columns");
+    (void)madvise(b.p, want, MADV_HUGEPAGE);  // advisory: plain pages work too, only slower to fault in
   }
   b.cap = want;
   return HMJ_OK;
@@ -286,7 +302,10 @@ int upload_host(hmj_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
   if (c->host_threads <= 0 && T > 8) T = 8;
   const size_t nchunks = (bytes + kUpChunk - 1) / kUpChunk;
   if (T > (int)nchunks) T = (int)nchunks;
-  if (T <= 1 || bytes < 4 * kUpChunk) {
+  // One hipMemcpy from the caller's pageable memory moves 54 GB/s on the MI355X box (2 GiB in 38 ms), as fast
+  // as from pinned memory, so that is the default; HMJ_UPLOAD=staged selects the multi-threaded pinned
+  // staging below for hosts whose runtime stages pageable copies slowly through one thread.
+  if (!c->staged_upload || T <= 1 || bytes < 4 * kUpChunk) {
     HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
     return HMJ_OK;
   }
@@ -424,9 +443,9 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     rs = (const u64*)c->ord_sval.p;
   }
   if (to_host) {
-    if ((rc = ensure_host(c, c->h_key, bytes)) != HMJ_OK) return rc;
-    if ((rc = ensure_host(c, c->h_rval, bytes)) != HMJ_OK) return rc;
-    if ((rc = ensure_host(c, c->h_sval, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_host(c, c->h_key, bytes, false)) != HMJ_OK) return rc;
+    if ((rc = ensure_host(c, c->h_rval, bytes, false)) != HMJ_OK) return rc;
+    if ((rc = ensure_host(c, c->h_sval, bytes, false)) != HMJ_OK) return rc;
     sp = span_begin(c, K_D2H, -1);
     HIP_TRY(hipMemcpyAsync(c->h_key.p, rk, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_rval.p, rr, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -751,9 +770,9 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       a.out_sval = (u64*)c->ord_sval.p;
     }
     if (to_host) {
-      if ((rc = ensure_host(c, c->h_key, bytes)) != HMJ_OK) return rc;
-      if ((rc = ensure_host(c, c->h_rval, bytes)) != HMJ_OK) return rc;
-      if ((rc = ensure_host(c, c->h_sval, bytes)) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_key, bytes, false)) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_rval, bytes, false)) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_sval, bytes, false)) != HMJ_OK) return rc;
       s = span_begin(c, K_D2H, -1);
       HIP_TRY(hipMemcpyAsync(c->h_key.p, a.out_key, bytes, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipMemcpyAsync(c->h_rval.p, a.out_rval, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -808,6 +827,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
+  if (const char* e = getenv("HMJ_UPLOAD")) c->staged_upload = std::strcmp(e, "staged") == 0;
   if (const char* e = getenv("HMJ_SLAB_MIN_LOG2")) {
     const int l = atoi(e);
     if (l >= 16 && l <= 31) c->slab_min_rows = 1u << l;
