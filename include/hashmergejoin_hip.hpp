@@ -164,7 +164,7 @@ class HashMergeJoin<RIter, SIter, true> {
     hmj_rows* rows = nullptr;
     hmj_detail::check(c, hmj_join_u64_rows(c, r_ptr, (uint64_t)r_size, s_ptr, (uint64_t)s_size,
                                            HMJ_MATERIALIZE | HMJ_ORDERED, &res, &rows), "hmj_join_u64_rows");
-    _rows = std::shared_ptr<hmj_rows>(rows, hmj_rows_free);  // the result columns (pinned host memory)
+    _rows = std::shared_ptr<hmj_rows>(rows, hmj_rows_free);  // the result columns (host memory)
     _n = (std::size_t)res.n_matches;
     _key = const_cast<Key*>(res.key);
     _rval = reinterpret_cast<RValue*>(const_cast<uint64_t*>(res.rval));
@@ -209,7 +209,7 @@ class HashMergeJoin<RIter, SIter, true> {
   std::size_t size() const { return _n; }
 
  protected:
-  // Result columns live in pinned host memory owned by _rows (shared by copies of this object, as
+  // Result columns live in host memory owned by _rows (shared by copies of this object, as
   // the reference's copies share nothing but are equally valid while they live).
   std::shared_ptr<hmj_rows> _rows;
   std::size_t _n = 0;

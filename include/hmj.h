@@ -37,7 +37,7 @@ typedef struct hmj_ctx hmj_ctx;
 #define HMJ_OK 0
 #define HMJ_E_ARG (-1)         /* bad argument / size beyond 2^32-1 tuples per call */
 #define HMJ_E_NODEV (-2)       /* no usable HIP device */
-#define HMJ_E_OOM (-3)         /* device or pinned-host allocation failed */
+#define HMJ_E_OOM (-3)         /* device or host allocation failed */
 #define HMJ_E_HIP (-4)         /* HIP runtime error, see hmj_last_error() */
 #define HMJ_E_UNSUPPORTED (-5) /* reserved: flag combination not supported for this input      */
 
@@ -61,7 +61,7 @@ typedef struct {
   uint64_t sum_probe_all; /* sum of val over ALL probe rows              (HMJ_SUM_PROBE)          */
   /* Result columns, n_matches entries each, NULL unless HMJ_MATERIALIZE.  Owned by the ctx,
    * valid until the next hmj_join_* / hmj_release_result / hmj_destroy on it.
-   * hmj_join_u64_device: device pointers.  hmj_join_u64: host pointers (pinned).              */
+   * hmj_join_u64_device: device pointers.  hmj_join_u64: host pointers.                       */
   const uint64_t* key;
   const uint64_t* rval;
   const uint64_t* sval;
