@@ -154,19 +154,22 @@ int hmj_join_u64(hmj_ctx* ctx, const void* build_aos_host, uint64_t n_build,
                  const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out);
 void hmj_release_result(hmj_ctx* ctx);
 
-/* Host-resident join whose result columns are DETACHED from the ctx: *rows owns the three pinned
+/* Host-resident join whose result columns are DETACHED from the ctx: *rows owns the three
  * host columns (out->key/rval/sval point into them) until hmj_rows_free, independent of later joins
  * on the ctx or of the ctx's lifetime -- the ownership HashMergeJoin's _r_sorted/_s_sorted vectors
- * have in the reference (hashjoin.h:197-198).  Freed buffers return to a process-wide pool of pinned
- * memory, so a construct/clear loop like hashjoin_bench.cc:120-134 does not re-pin every iteration.
+ * have in the reference (hashjoin.h:197-198).  Freed buffers return to a process-wide pool of
+ * huge-page host memory, so a construct/clear loop like hashjoin_bench.cc:120-134 does not fault its
+ * result memory in again every iteration.
  * Implies HMJ_MATERIALIZE.  hmj_rows_free(NULL) is a no-op; it may be called from any thread.     */
 typedef struct hmj_rows hmj_rows;
 int hmj_join_u64_rows(hmj_ctx* ctx, const void* build_aos_host, uint64_t n_build,
                       const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out,
                       hmj_rows** rows);
 void hmj_rows_free(hmj_rows* rows);
-/* Host threads used to stage pageable input memory into pinned chunks for the PCIe copy (the
- * reference ctor's num_threads argument, hashjoin.h:58, maps to this).  Default min(8, cores).    */
+/* Host threads of the optional staged upload (pageable input -> pinned chunks -> PCIe), used only
+ * with HMJ_UPLOAD=staged in the environment; by default each relation goes up in one copy straight
+ * from the caller's memory (54 GB/s on the MI355X box).  The reference ctor's num_threads argument,
+ * hashjoin.h:58, maps to this.  Default min(8, cores).                                            */
 int hmj_set_host_threads(hmj_ctx* ctx, int n);
 
 /* ---- one radix pass ---------------------------------------------------------------------------- */
