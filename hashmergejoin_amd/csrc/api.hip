@@ -68,6 +68,7 @@ struct hmj_ctx {
   u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged
+  bool window_mode = true;     // HMJ_WINDOW=0: always partition right below the shared key prefix
   u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
                                  // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
@@ -513,9 +514,30 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     prefix = hs[0] ? __builtin_clzll(hs[0]) : 64;
     pfx_ref = hs[1];
     sampled = prefix > 0;
+    if (prefix + B > 64) prefix = 64 - B;
+    if (!(flags & HMJ_ORDERED) && !c->prepare_only && c->window_mode) {
+      // hs[0] has a 1 wherever two sampled keys differ.  Keys with structure (a tag in the top bits,
+      // zeros below it, an id in the low bits) vary in few of the B bits right under the shared prefix;
+      // any B-bit window is a valid partition function for an unordered result, so take the highest
+      // one that covers the most varying bits.  (Ordered results need partitions to be key ranges.)
+      const u64 M = hs[0], wmask = (B >= 64) ? ~0ull : ((1ull << B) - 1);
+      int best_low = 64 - prefix - B, best_pop = __builtin_popcountll((M >> best_low) & wmask);
+      for (int l = best_low - 1; l >= 0 && best_pop < B; l--) {
+        const int pop = __builtin_popcountll((M >> l) & wmask);
+        if (pop > best_pop) {
+          best_pop = pop;
+          best_low = l;
+        }
+      }
+      if (best_low != 64 - prefix - B) {
+        prefix = 64 - B - best_low;  // "prefix" now only positions the window; nothing relies on it
+        sampled = false;
+      }
+    }
   }
   if (prefix + B > 64) prefix = 64 - B;
   const int low = 64 - prefix - B;  // partition id = (key >> low) & (P - 1)
+  const bool verify_pfx = sampled && prefix > 0 && (flags & HMJ_ORDERED);  // ordered output relies on it
   // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;
   hmj::SlabGeom gr, gs;
@@ -586,7 +608,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       wa.P = P;
       wa.Q = 1;
       wa.accum = acc;
-      return unique_key_write(c, wa, true, nb, np, low, extra, sampled ? prefix : 0, pfx_ref,
+      return unique_key_write(c, wa, true, nb, np, low, extra, verify_pfx ? prefix : 0, pfx_ref,
                                   (flags & HMJ_ORDERED) != 0, to_host, out);
     }
     hmj::ProbeArgs sa;
@@ -663,7 +685,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     wa.P = P;
     wa.Q = 1;
     wa.accum = (u64*)c->accum.p;
-    rc = unique_key_write(c, wa, false, nb, np, low, extra, sampled ? prefix : 0, pfx_ref,
+    rc = unique_key_write(c, wa, false, nb, np, low, extra, verify_pfx ? prefix : 0, pfx_ref,
                                   (flags & HMJ_ORDERED) != 0, to_host, out);
     if (rc != kRetryNoFastWrite) return rc;
     // duplicate build keys: the partitions stay valid, carry on with the count / scan / write passes
@@ -678,7 +700,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   a.P = P;
   a.Q = Q;
   a.accum = (u64*)c->accum.p;
-  if (sampled && prefix > 0 && (flags & HMJ_ORDERED)) {  // ordered output relies on the prefix: verify it
+  if (verify_pfx) {
     a.pfx_shift = (u32)(64 - prefix);
     a.pfx_val = pfx_ref >> (64 - prefix);
   }
@@ -827,6 +849,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
+  if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_UPLOAD")) c->staged_upload = std::strcmp(e, "staged") == 0;
   if (const char* e = getenv("HMJ_SLAB_MIN_LOG2")) {
     const int l = atoi(e);

@@ -205,8 +205,10 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
               if (EXTRA && first_table) acc_p += sval;
               u32 i = sm.head[tab_hash(key)];
               while (i != NIL && sm.key[i] != key) i = sm.next[i];
-              u32 best = NIL;
+              u32 best = 0;
+              bool hit = false;  // FIRST: `best` is a position in the partition, any 32-bit value is a valid one
               if (i != NIL) {
+                hit = true;
                 if (AGG) {
                   const u64 c = sm.aux[i];
                   pc += c;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
                   } while (i != NIL);
                 }
               }
-              if (FIRST && best != NIL && first_claim(a.matched, multi, sb + j)) {
+              if (FIRST && hit && first_claim(a.matched, multi, sb + j)) {
                 const u64 rval = R[(u64)rb + best].val;  // the row itself is not kept in LDS
                 pc++;
                 acc_r += rval;

@@ -202,6 +202,25 @@ def test_forced_radix_bits_and_overflow_chunks(ex, H, oracle, bits):
         ex.set_radix_bits(None)
 
 
+def test_first_wins_in_a_partition_of_more_than_65535_rows(ex, H, oracle):
+    # Regression (found by the randomized stress with other seeds): first-wins keeps the POSITION of a key's
+    # first row in its partition; position 65535 once collided with the 16-bit "no entry" marker of the
+    # LDS chains and that row's matches were dropped.  One partition of 70 000 rows, every row probed.
+    nb = 70000
+    B, P = oracle.gen_build(nb), oracle.gen_probe(nb, nb)
+    for fw_flags in (H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, H.HMJ_FIRST_WINS | H.HMJ_ORDERED | H.HMJ_CHECKSUM):
+        ck, rows = oracle.equijoin(B, P, first_wins=True)
+        for bits in (0, 1):
+            ex.set_radix_bits(bits)
+            try:
+                r = ex.join_device(to_dev(B), to_dev(P), fw_flags)
+                assert r.checks() == ck and int(r.n_matches) == nb
+                if fw_flags & H.HMJ_ORDERED:
+                    assert np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+            finally:
+                ex.set_radix_bits(None)
+
+
 def test_skewed_build_side(ex, H, oracle):
     # Zipf(0.9) build side with heavy duplicates, uniform probe over the same domain
     # (BASELINE configs[4] shape, scaled down): chained table + overflow chunks
@@ -654,9 +673,14 @@ def test_argument_errors(ex, H):
 def test_randomized_shapes_and_flags(ex, H, oracle):
     # seeded sweep over sizes around the tile / table / slice boundaries, key distributions (uniform,
     # dense, duplicate-heavy, sorted, clustered in few digits) and every flag combination
-    rng = np.random.default_rng(20251003)
+    # (HMJ_STRESS_ITERS / HMJ_STRESS_SEED: longer offline runs with other seeds; they also draw sizes that
+    #  reach the slab partitioning and the single-pass write mode)
+    iters = int(os.environ.get("HMJ_STRESS_ITERS", "70"))
+    rng = np.random.default_rng(int(os.environ.get("HMJ_STRESS_SEED", "20251003")))
     sizes = [1, 2, 63, 64, 65, 511, 2047, 2048, 2049, 4095, 4096, 4097, 5119, 5120, 5121, 8191, 10240, 12288,
              20000, 65535, 65536, 65537, 100000, 262144, 300001]
+    if iters > 70 or os.environ.get("HMJ_STRESS_BIG"):
+        sizes += [(1 << 22) + 5, 4500000]
     flag_sets = [0, H.HMJ_CHECKSUM, H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_ORDERED | H.HMJ_CHECKSUM,
                  H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, H.HMJ_FIRST_WINS | H.HMJ_ORDERED,
                  H.HMJ_ORDERED | H.HMJ_SUM_PROBE]
@@ -674,7 +698,7 @@ def test_randomized_shapes_and_flags(ex, H, oracle):
         # clustered: only a few values of the top bits occur
         return (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(61)) | rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
 
-    for it in range(70):
+    for it in range(iters):
         nb, npb = int(rng.choice(sizes)), int(rng.choice(sizes))
         kind = str(rng.choice(["uniform", "dense", "dups", "sorted", "clustered"]))
         dom = int(rng.choice([97, 5000, 1 << 20]))
@@ -685,11 +709,15 @@ def test_randomized_shapes_and_flags(ex, H, oracle):
         P = np.stack([kp, rng.integers(0, 1 << 62, size=npb, dtype=np.uint64)], 1)
         fl = int(rng.choice(flag_sets))
         first = bool(fl & H.HMJ_FIRST_WINS)
-        ck, rows = oracle.equijoin(B, P, first_wins=first)
+        ck, _ = oracle.equijoin(B, P, first_wins=first, cap=0)  # count first: a cross product can be huge
         if ck["n_matches"] > 30_000_000:
             continue
+        ck, rows = oracle.equijoin(B, P, first_wins=first)
         r = ex.join_device(to_dev(B), to_dev(P), fl)
         tag = (it, nb, npb, kind, dom, fl)
+        if os.environ.get("HMJ_STRESS_DUMP") and int(r.n_matches) != ck["n_matches"]:  # keep the failing relations
+            np.save(os.path.join(os.environ["HMJ_STRESS_DUMP"], "fail_B.npy"), B)
+            np.save(os.path.join(os.environ["HMJ_STRESS_DUMP"], "fail_P.npy"), P)
         assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), tag
         if fl & H.HMJ_CHECKSUM:
             assert r.checks() == ck, tag
