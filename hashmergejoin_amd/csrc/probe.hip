@@ -335,6 +335,7 @@ struct FastSmem {
   u64 red[8];
   u32 itemcnt[2];  // per-partition match count, double-buffered by partition parity
   u64 wscan[THREADS / kWave + 1];  // OUT == 1: packed 64-bit block scan
+  u32 wdup[THREADS / kWave + 1];   // OUT == 1: wave saw a probe row with two matches
 };
 
 template <int LOG_NB>
@@ -574,7 +575,9 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
         }
         if (OUT == 1) {
           // compact this partition's result rows in probe order: one packed block scan gives every
-          // thread the offsets of its five rows (12 bits per row slot k; bit 60+: "a row matched twice")
+          // thread the offsets of its five rows (12 bits per row slot k).  "A row matched twice" is
+          // OR-ed per wave beside it (summing such flags in the packed word would wrap: 16 of them
+          // already overflow bit 60).
           u64 packed = 0;
           bool cx = false;
 #pragma unroll
@@ -582,25 +585,30 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
             cx |= cnt[k] > 1;
             packed |= (u64)(cnt[k] ? 1u : 0u) << (12 * k);
           }
-          packed |= (u64)(cx ? 1u : 0u) << 60;
           const int lane = tid & 63, wv = tid >> 6;
+          const bool wave_dup = __any(cx);
           u64 incl = packed;
 #pragma unroll
           for (int o = 1; o < kWave; o <<= 1) {
             u64 t = __shfl_up(incl, o, kWave);
             if (lane >= o) incl += t;
           }
-          if (lane == 63) sm.wscan[wv] = incl;
+          if (lane == 63) {
+            sm.wscan[wv] = incl;
+            sm.wdup[wv] = wave_dup ? 1u : 0u;
+          }
           lds_barrier();
           u64 pre = 0, tot = 0;
+          u32 dup = 0;
 #pragma unroll
           for (int q = 0; q < THREADS / kWave; q++) {
             const u64 ws = sm.wscan[q];
+            dup |= sm.wdup[q];
             if (q < wv) pre += ws;
             tot += ws;
           }
           const u64 ex = pre + incl - packed;
-          if (tot >> 60) {
+          if (dup) {
             giveup = true;  // duplicate build keys here: not the unique-key case
           } else {
             u64 o = SLAB ? a.item_base[p] : (u64)sb;

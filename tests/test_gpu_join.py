@@ -202,6 +202,28 @@ def test_forced_radix_bits_and_overflow_chunks(ex, H, oracle, bits):
         ex.set_radix_bits(None)
 
 
+def test_every_build_key_duplicated_takes_the_general_materialise_path(ex, H, oracle):
+    # Regression (found by the randomized stress with other seeds): the single-pass write mode must give
+    # up when a probe row matches twice.  Its per-thread "matched twice" flags were once SUMMED in a packed
+    # word, so 16 (or 1024) of them wrapped to zero and heavily duplicated build sides slipped through.
+    rng = np.random.default_rng(3)
+    for nb, npb, nk in [(5121, 8191, 100), (20000, 20000, 400), (300000, 200000, 150000)]:
+        kb = rng.integers(0, nk, size=nb, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        kp = rng.integers(0, nk, size=npb, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        B = np.stack([kb, rng.integers(0, 1 << 62, size=nb, dtype=np.uint64)], 1)
+        P = np.stack([kp, rng.integers(0, 1 << 62, size=npb, dtype=np.uint64)], 1)
+        ck, rows = oracle.equijoin(B, P)
+        for fl in (H.HMJ_ORDERED | H.HMJ_CHECKSUM, H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM):
+            for attempt in range(2):  # with and without the executor's "skip the attempt" memory
+                r = ex.join_device(to_dev(B), to_dev(P), fl)
+                assert r.checks() == ck
+                got = ex.columns_to_numpy(r, host=False)
+                assert np.array_equal(got if fl & H.HMJ_ORDERED else sorted_rows(got), rows)
+            for _ in range(8):  # run the cool-down out so the next size tries the single-pass mode again
+                ex.join_device(to_dev(oracle.gen_build(50000)), to_dev(oracle.gen_probe(50000, 50000)), H.HMJ_MATERIALIZE)
+        ex.release_result()
+
+
 def test_first_wins_in_a_partition_of_more_than_65535_rows(ex, H, oracle):
     # Regression (found by the randomized stress with other seeds): first-wins keeps the POSITION of a key's
     # first row in its partition; position 65535 once collided with the 16-bit "no entry" marker of the
@@ -709,12 +731,20 @@ def test_randomized_shapes_and_flags(ex, H, oracle):
         P = np.stack([kp, rng.integers(0, 1 << 62, size=npb, dtype=np.uint64)], 1)
         fl = int(rng.choice(flag_sets))
         first = bool(fl & H.HMJ_FIRST_WINS)
-        ck, _ = oracle.equijoin(B, P, first_wins=first, cap=0)  # count first: a cross product can be huge
-        if ck["n_matches"] > 30_000_000:
+        # size of the cross product first (the oracle enumerates every pair): skip the huge ones
+        ub, cb = np.unique(kb, return_counts=True)
+        up, cp = np.unique(kp, return_counts=True)
+        _, ib, ip = np.intersect1d(ub, up, assume_unique=True, return_indices=True)
+        if int((cb[ib].astype(np.int64) * cp[ip].astype(np.int64)).sum()) > 30_000_000:
             continue
         ck, rows = oracle.equijoin(B, P, first_wins=first)
+        import time as _time
+
+        _t0 = _time.perf_counter()
         r = ex.join_device(to_dev(B), to_dev(P), fl)
         tag = (it, nb, npb, kind, dom, fl)
+        if iters > 70:  # offline runs: progress (pytest -s), also keeps a long run from looking hung
+            print("stress", tag, "matches", ck["n_matches"], "join %.1f ms" % ((_time.perf_counter() - _t0) * 1e3), flush=True)
         if os.environ.get("HMJ_STRESS_DUMP") and int(r.n_matches) != ck["n_matches"]:  # keep the failing relations
             np.save(os.path.join(os.environ["HMJ_STRESS_DUMP"], "fail_B.npy"), B)
             np.save(os.path.join(os.environ["HMJ_STRESS_DUMP"], "fail_P.npy"), P)
