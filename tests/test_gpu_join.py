@@ -759,3 +759,64 @@ def test_randomized_shapes_and_flags(ex, H, oracle):
                 assert np.array_equal(got, rows), tag
             else:
                 assert np.array_equal(sorted_rows(got), rows), tag
+
+
+def test_randomized_partition_sort_prepare_host(ex, H, oracle):
+    # seeded sweep over the other entry points: one radix pass (any shift / width, incl. skewed digits),
+    # the full sort (out of place and in place), the prepared build side and the host-resident join
+    iters = int(os.environ.get("HMJ_STRESS_ITERS", "40"))
+    rng = np.random.default_rng(int(os.environ.get("HMJ_STRESS_SEED", "77")) + 1000)
+    sizes = [1, 2, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 20000, 65537, 100000, 300001]
+    if iters > 40:
+        sizes += [(1 << 21) + 3, (1 << 22) + 5]
+
+    def keys(n):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            return rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+        if kind == 1:
+            return rng.integers(0, 1 << int(rng.integers(1, 40)), size=n, dtype=np.uint64)
+        if kind == 2:  # few values of the digit field: heavily skewed radix digits
+            return (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(int(rng.integers(0, 62)))) | rng.integers(0, 1 << 20, size=n, dtype=np.uint64)
+        return np.sort(rng.integers(0, 1 << 63, size=n, dtype=np.uint64))
+
+    for it in range(iters):
+        n = int(rng.choice(sizes))
+        a = np.stack([keys(n), np.arange(n, dtype=np.uint64)], 1)
+        what = int(rng.integers(0, 4))
+        tag = (it, n, what)
+        if what == 0:  # one stable radix pass == the reference's pass 1
+            bits = int(rng.integers(1, 10))
+            shift = int(rng.integers(0, 65 - bits))
+            out, off = ex.partition_device(to_dev(a), shift, bits)
+            ref, roff = oracle.stable_partition(a, shift, bits, threads=int(rng.integers(1, 5)))
+            assert np.array_equal(to_np(out), ref), tag + (shift, bits)
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), roff), tag + (shift, bits)
+        elif what == 1:  # full sort: stable LSD order
+            inplace = bool(rng.integers(0, 2))
+            got = to_np(ex.sort_device(to_dev(a), inplace=inplace))
+            assert np.array_equal(got, a[np.argsort(a[:, 0], kind="stable")]), tag + (inplace,)
+        elif what == 2:  # prepared build side: same answer as the plain join, for either partition layout
+            m = int(rng.choice(sizes))
+            kb = a[:, 0]
+            kp = np.where(rng.random(m) < 0.5, kb[rng.integers(0, n, size=m)], keys(m))
+            P = np.stack([kp, rng.integers(0, 1 << 62, size=m, dtype=np.uint64)], 1)
+            bd, pd = to_dev(a), to_dev(P)
+            want = ex.join_device(bd, pd, 0)
+            want = (int(want.n_matches), int(want.sum_r), int(want.sum_s))
+            ex.prepare_build(bd, m)
+            got = ex.join_device(bd, pd, 0)
+            assert (int(got.n_matches), int(got.sum_r), int(got.sum_s)) == want, tag + (m,)
+        else:  # host-resident entry point, ordered rows back on the host
+            if n > 300001:
+                continue
+            m = int(rng.choice([s for s in sizes if s <= 300001]))
+            kb = np.unique(a[:, 0])  # unique build keys: ordered rows are exactly the oracle's
+            Bh = np.stack([kb, rng.integers(0, 1 << 62, size=len(kb), dtype=np.uint64)], 1)
+            kp = np.where(rng.random(m) < 0.5, kb[rng.integers(0, len(kb), size=m)], keys(m))
+            Ph = np.stack([kp, rng.integers(0, 1 << 62, size=m, dtype=np.uint64)], 1)
+            ck, rows = oracle.equijoin(Bh, Ph)
+            r = ex.join_host(Bh, Ph, H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+            assert r.checks() == ck, tag + (m,)
+            assert np.array_equal(ex.columns_to_numpy(r, host=True), rows), tag + (m,)
+    ex.release_result()
