@@ -359,6 +359,7 @@ int check_rel(hmj_ctx* c, const void* p, uint64_t n, const char* name) {
   return HMJ_OK;
 }
 
+constexpr int kRetryNoWinOrdered = 1003;  // internal: window + sort ordered path cannot index the result -> prefix rule
 constexpr int kRetryNoFastWrite = 1002;  // internal: unique-key write mode gave up -> general materialise
 constexpr int kRetryNoSlab = 1001;    // internal: the slab path gave up (skew) -> exact path
 constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-planned without the sampled prefix
@@ -462,7 +463,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
 
 int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                      uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix,
-                     bool allow_slab, bool allow_fast_write) {
+                     bool allow_slab, bool allow_fast_write, bool allow_win_ordered) {
   int rc;
   if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
   std::memset(out, 0, sizeof(*out));
@@ -502,7 +503,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
   const void *Rp, *Sp;
   int prefix = c->prefix_bits < 0 ? 0 : c->prefix_bits;
-  bool sampled = false;
+  bool sampled = false, win_ordered = false;
   u64 pfx_ref = 0;
   if (c->prefix_bits < 0 && allow_auto_prefix && B > 0 && (u64)nb + np > 0) {
     // dense / small-integer keys: skip the top bits every (sampled) key shares
@@ -515,11 +516,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     pfx_ref = hs[1];
     sampled = prefix > 0;
     if (prefix + B > 64) prefix = 64 - B;
-    if (!(flags & HMJ_ORDERED) && !c->prepare_only && c->window_mode) {
+    if (!c->prepare_only && c->window_mode && (!(flags & HMJ_ORDERED) || allow_win_ordered)) {
       // hs[0] has a 1 wherever two sampled keys differ.  Keys with structure (a tag in the top bits,
       // zeros below it, an id in the low bits) vary in few of the B bits right under the shared prefix;
-      // any B-bit window is a valid partition function for an unordered result, so take the highest
-      // one that covers the most varying bits.  (Ordered results need partitions to be key ranges.)
+      // any B-bit window is a valid partition function, so take the highest one that covers the most
+      // varying bits.  (Partitions are then no key ranges: an ordered result gets a final sort by key.)
       const u64 M = hs[0], wmask = (B >= 64) ? ~0ull : ((1ull << B) - 1);
       int best_low = 64 - prefix - B, best_pop = __builtin_popcountll((M >> best_low) & wmask);
       for (int l = best_low - 1; l >= 0 && best_pop < B; l--) {
@@ -532,6 +533,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       if (best_low != 64 - prefix - B) {
         prefix = 64 - B - best_low;  // "prefix" now only positions the window; nothing relies on it
         sampled = false;
+        // an ordered result is then finished by a stable sort of the rows on the whole key (below)
+        win_ordered = (flags & HMJ_ORDERED) != 0;
       }
     }
   }
@@ -546,7 +549,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   if (c->uniq_cooldown > 0 && allow_fast_write && materialize) c->uniq_cooldown--;
   // the pipelined probe kernels hold one partition's probe rows in registers (5120 at most)
   const bool probe_fits = ((u64)np_plan >> B) <= 4608;
-  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !first &&
+  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !first && !win_ordered &&
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
   if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
       probe_fits &&
@@ -790,6 +793,29 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       a.out_key = (u64*)c->ord_key.p;
       a.out_rval = (u64*)c->ord_rval.p;
       a.out_sval = (u64*)c->ord_sval.p;
+      if (win_ordered) {
+        // The partitions are not key ranges here (window partitioning of keys with structure).  Every
+        // partition is sorted, and all rows of one key sit together in (rval, sval) order, so a STABLE
+        // sort of the rows by key finishes the job: eight 8-bit LSD passes over {key, row index}, then a
+        // gather of the payload columns.
+        const u64 n = out->n_matches;
+        if (n > 0xFFFFFFFFull) return kRetryNoWinOrdered;
+        c->prep.valid = false;
+        if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
+        if ((rc = ensure_dev(c, c->rbuf[1], (size_t)n * 16)) != HMJ_OK) return rc;
+        s = span_begin(c, K_ORDER, -1);
+        HIP_TRY(hmj::launch_key_idx(a.out_key, n, c->rbuf[0].p, c->stream));
+        for (int pass = 0; pass < 8; pass++)
+          if ((rc = radix_pass(c, c->rbuf[pass & 1].p, c->rbuf[(pass & 1) ^ 1].p, (u32)n, 8 * pass, 8, -1,
+                               nullptr)) != HMJ_OK)
+            return rc;
+        HIP_TRY(hmj::launch_gather3(c->rbuf[0].p, n, a.out_rval, a.out_sval, (u64*)c->out_key.p,
+                                    (u64*)c->out_rval.p, (u64*)c->out_sval.p, c->stream));
+        span_end(c, s);
+        a.out_key = (u64*)c->out_key.p;
+        a.out_rval = (u64*)c->out_rval.p;
+        a.out_sval = (u64*)c->out_sval.p;
+      }
     }
     if (to_host) {
       if ((rc = ensure_host(c, c->h_key, bytes, false)) != HMJ_OK) return rc;
@@ -811,10 +837,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
 
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
-  bool auto_prefix = true, slab = true, fast_write = true;
-  for (int attempt = 0; attempt < 4; attempt++) {
-    int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab, fast_write);
-    if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite) {
+  bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true;
+  for (int attempt = 0; attempt < 5; attempt++) {
+    int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab, fast_write,
+                              win_ordered);
+    if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite || rc == kRetryNoWinOrdered) {
       // forget the abandoned attempt's phase spans (the enclosing total / h2d spans stay)
       std::vector<Span> keep;
       for (const Span& sp : c->spans)
@@ -823,6 +850,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
       std::memset(&c->timing, 0, sizeof(c->timing));
       if (rc == kRetryNoSlab) slab = false;
       else if (rc == kRetryNoFastWrite) fast_write = false;
+      else if (rc == kRetryNoWinOrdered) win_ordered = false;
       else auto_prefix = false;
       continue;
     }

@@ -95,4 +95,36 @@ hipError_t launch_gen_uniform_domain(void* out, u64 n, u64 start, u64 domain, u6
   return hipGetLastError();
 }
 
+// ---- ordered results of keys with structure (api.hip, "window + sort") -----------------------------
+// rows {key[i], i}: the sortable handle of result row i
+__global__ void key_idx_kernel(const u64* __restrict__ key, u64 n, Tup* __restrict__ out) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    Tup t;
+    t.key = key[i];
+    t.val = i;
+    out[i] = t;
+  }
+}
+// result columns in the order of the sorted handles
+__global__ void gather3_kernel(const Tup* __restrict__ sorted, u64 n, const u64* __restrict__ rval,
+                               const u64* __restrict__ sval, u64* __restrict__ okey, u64* __restrict__ orval,
+                               u64* __restrict__ osval) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    const Tup t = sorted[i];
+    okey[i] = t.key;
+    orval[i] = rval[t.val];
+    osval[i] = sval[t.val];
+  }
+}
+hipError_t launch_key_idx(const u64* key, u64 n, void* out, hipStream_t st) {
+  hipLaunchKernelGGL(key_idx_kernel, dim3(2048), dim3(256), 0, st, key, n, static_cast<Tup*>(out));
+  return hipGetLastError();
+}
+hipError_t launch_gather3(const void* sorted, u64 n, const u64* rval, const u64* sval, u64* okey, u64* orval,
+                          u64* osval, hipStream_t st) {
+  hipLaunchKernelGGL(gather3_kernel, dim3(2048), dim3(256), 0, st, static_cast<const Tup*>(sorted), n, rval, sval,
+                     okey, orval, osval);
+  return hipGetLastError();
+}
+
 }  // namespace hmj

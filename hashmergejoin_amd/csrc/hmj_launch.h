@@ -83,6 +83,9 @@ hipError_t launch_gen_probe(void* out, u64 n, u64 start, u64 n_build, u64 seed, 
                             hipStream_t st);
 hipError_t launch_gen_from_cdf(void* out, u64 n, u64 start, const u64* thr, u64 domain, u64 seed,
                                u64 zseed, hipStream_t st);
+hipError_t launch_key_idx(const u64* key, u64 n, void* out, hipStream_t st);
+hipError_t launch_gather3(const void* sorted, u64 n, const u64* rval, const u64* sval, u64* okey, u64* orval,
+                          u64* osval, hipStream_t st);
 hipError_t launch_gen_uniform_domain(void* out, u64 n, u64 start, u64 domain, u64 seed, u64 zseed,
                                      hipStream_t st);
 }  // namespace hmj
