@@ -46,7 +46,7 @@ struct hmj_ctx {
   int device = 0, num_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
-      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched,
+      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
       slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int host_threads = 0;  // staging threads for pageable input (0 = default)
@@ -68,6 +68,7 @@ struct hmj_ctx {
   u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged
+  bool split_mode = true;      // HMJ_SPLIT=0: never split oversized probe partitions
   bool window_mode = true;     // HMJ_WINDOW=0: always partition right below the shared key prefix
   u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
                                  // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
@@ -436,7 +437,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
     sp = span_begin(c, K_ORDER, -1);
-    HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, in_base32, in_base64, P, 1, low, wa.out_key,
+    HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, nullptr, in_base32, in_base64, P, 1, low, wa.out_key,
                               wa.out_rval, wa.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
                               (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
     span_end(c, sp);
@@ -678,7 +679,42 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   HIP_TRY(hmj::launch_part_offsets(Sp, np, low, B, (u32*)c->s_off.p, c->stream));
   span_end(c, s);
 
-  if (fast_write) {
+  // Skewed probe side (a hot foreign key): partitions with far more probe rows than the rest are cut into
+  // virtual partitions so that no single workgroup is left with millions of rows (probe.hip,
+  // split_*_kernel).  Pi = number of (virtual) partitions the probe kernels iterate over.
+  u32 Pi = P;
+  const u32 *v_start = nullptr, *vr_beg = nullptr, *vr_end = nullptr, *vs_beg = nullptr, *vs_end = nullptr;
+  if (Q == 1 && P >= 1024 && np > 0 && c->split_mode) {
+    const u32 avg = np / P + 1;
+    u32 thr = probe_fits ? 5120u : 4u * avg, slice = probe_fits ? 4096u : avg;
+    if (!probe_fits && thr < 32768u) thr = 32768u;
+    if (!probe_fits && slice < 16384u) slice = 16384u;
+    const u32 cap_v = P + np / slice + 1;  // every split partition adds at most np_p / slice virtual ones
+    if ((rc = ensure_dev(c, c->vparts, ((size_t)cap_v * 4 + P + 3) * 4)) != HMJ_OK) return rc;
+    u32* vp = (u32*)c->vparts.p;
+    u32 *d_vstart = vp, *d_nv = vp + P + 1, *d_rb = vp + P + 2, *d_re = d_rb + cap_v, *d_sb = d_re + cap_v,
+        *d_se = d_sb + cap_v;
+    HIP_TRY(hmj::launch_split_parts((const u32*)c->r_off.p, (const u32*)c->s_off.p, P, thr, slice, cap_v, d_vstart,
+                                    d_rb, d_re, d_sb, d_se, d_nv, c->stream));
+    u32* hnv = (u32*)c->h_accum.p;
+    HIP_TRY(hipMemcpyAsync(hnv, d_nv, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*hnv > P && *hnv <= cap_v) {
+      Pi = *hnv;
+      v_start = d_vstart;
+      vr_beg = d_rb;
+      vr_end = d_re;
+      vs_beg = d_sb;
+      vs_end = d_se;
+      if (materialize) {
+        if ((rc = ensure_dev(c, c->part_count, (size_t)Pi * 8)) != HMJ_OK) return rc;
+        if ((rc = ensure_dev(c, c->part_out_off, ((size_t)Pi + 1) * 8)) != HMJ_OK) return rc;
+      }
+    }
+  }
+  const bool split = Pi != P;
+
+  if (fast_write && !split) {  // (with split partitions a partition's rows are not in one piece: general passes)
     hmj::ProbeArgs wa;
     std::memset(&wa, 0, sizeof(wa));
     wa.R = Rp;
@@ -697,10 +733,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   hmj::ProbeArgs a;
   std::memset(&a, 0, sizeof(a));
   a.R = Rp;
-  a.r_off = (const u32*)c->r_off.p;
+  a.r_off = split ? vr_beg : (const u32*)c->r_off.p;
+  a.r_end = vr_end;
   a.S = Sp;
-  a.s_off = (const u32*)c->s_off.p;
-  a.P = P;
+  a.s_off = split ? vs_beg : (const u32*)c->s_off.p;
+  a.s_end = vs_end;
+  a.P = Pi;
   a.Q = Q;
   a.accum = (u64*)c->accum.p;
   if (verify_pfx) {
@@ -719,10 +757,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   }
 
   s = span_begin(c, K_PROBE_COUNT, -1);
-  if (!first && !extra && Q == 1 && P >= 2) {
+  if (!first && !extra && Q == 1 && Pi >= 2) {
     // pipelined count kernel (with per-partition counts when materialising), then the generic
     // kernel over the partitions it set aside
-    if ((rc = ensure_dev(c, c->irregular, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->irregular, ((size_t)Pi + 1) * 4)) != HMJ_OK) return rc;
     u32* n_irr = (u32*)c->irregular.p;
     u32* irr = n_irr + 1;
     HIP_TRY(hipMemsetAsync(n_irr, 0, 4, c->stream));
@@ -732,10 +770,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     a2.item_list = irr;
     a2.n_item_list = n_irr;
     HIP_TRY(hmj::launch_probe(a2, materialize ? 1 : 0, false, false, c->num_cus, c->stream));
-  } else if (!materialize && Q == 1 && P >= 2) {
+  } else if (!materialize && Q == 1 && Pi >= 2) {
     // count mode with checksums / first-wins: the pipelined kernel's extended variant, then the generic
     // kernel (same flags) over the partitions it set aside
-    if ((rc = ensure_dev(c, c->irregular, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->irregular, ((size_t)Pi + 1) * 4)) != HMJ_OK) return rc;
     u32* n_irr = (u32*)c->irregular.p;
     u32* irr = n_irr + 1;
     HIP_TRY(hipMemsetAsync(n_irr, 0, 4, c->stream));
@@ -753,8 +791,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
   if (materialize) {
     s = span_begin(c, K_OUT_SCAN, -1);
-    HIP_TRY(hmj::launch_scan_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p, (u32)items,
-                                 c->stream));
+    HIP_TRY(hmj::launch_scan_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p,
+                                 split ? Pi : (u32)items, c->stream));
     span_end(c, s);
   }
   u64* h = (u64*)c->h_accum.p;
@@ -786,7 +824,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
       if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
       s = span_begin(c, K_ORDER, -1);
-      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, nullptr, nullptr, P, Q, low, a.out_key, a.out_rval,
+      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, v_start, nullptr, nullptr, P, Q, low, a.out_key, a.out_rval,
                                 a.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
                                 (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
       span_end(c, s);
@@ -878,6 +916,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   c->device = device_id;
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
   if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_UPLOAD")) c->staged_upload = std::strcmp(e, "staged") == 0;
   if (const char* e = getenv("HMJ_SLAB_MIN_LOG2")) {
     const int l = atoi(e);
@@ -909,7 +948,7 @@ void hmj_destroy(hmj_ctx* c) {
   DevBuf* devs[] = {&c->rbuf[0], &c->rbuf[1], &c->sbuf[0], &c->sbuf[1], &c->in_r, &c->in_s,
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
-                    &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched,
+                    &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched, &c->vparts,
                     &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};

@@ -54,6 +54,8 @@ struct ProbeArgs {
   const u32* s_cnt;
   u32 r_cap, s_cap;
   const u64* item_base;    // unique-key write mode, slab layout: first output slot of partition p
+  const u32* r_end;        // optional: end of partition p's build rows (NULL: r_off[p + 1]); with s_end this lets
+  const u32* s_end;        // several "virtual" partitions share one build range (oversized probe partitions are split)
   u32 extra;               // unique-key write mode: also accumulate checksums / sum_probe_all
   u32 pfx_shift;           // ordered mode: verify (key >> pfx_shift) == pfx_val for every row (0 = off)
   u64 pfx_val;
@@ -73,7 +75,7 @@ hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st);
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
                                    bool per_partition_counts, int num_cus, hipStream_t st);
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
-hipError_t launch_order(const u64* part_out_off, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
+hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
                         int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
                         u64* bsval, int grid, hipStream_t st);
 
@@ -83,6 +85,10 @@ hipError_t launch_gen_probe(void* out, u64 n, u64 start, u64 n_build, u64 seed, 
                             hipStream_t st);
 hipError_t launch_gen_from_cdf(void* out, u64 n, u64 start, const u64* thr, u64 domain, u64 seed,
                                u64 zseed, hipStream_t st);
+// split oversized probe partitions into virtual partitions (api.hip, skewed probe sides)
+hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr_rows, u32 slice_rows, u32 cap_v,
+                              u32* vstart, u32* vr_beg, u32* vr_end, u32* vs_beg, u32* vs_end, u32* nv_out,
+                              hipStream_t st);
 hipError_t launch_key_idx(const u64* key, u64 n, void* out, hipStream_t st);
 hipError_t launch_gather3(const void* sorted, u64 n, const u64* rval, const u64* sval, u64* okey, u64* orval,
                           u64* osval, hipStream_t st);

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
   for (u64 wi = blockIdx.x; wi < items; wi += gridDim.x) {
     const u64 w = a.item_list ? (u64)a.item_list[wi] : wi;
     const u32 p = (u32)(w / a.Q), q = (u32)(w % a.Q);
-    const u32 rb = a.r_off[p], nb = a.r_off[p + 1] - rb;
-    const u32 sb0 = a.s_off[p], np0 = a.s_off[p + 1] - sb0;
+    const u32 rb = a.r_off[p], nb = (a.r_end ? a.r_end[p] : a.r_off[p + 1]) - rb;
+    const u32 sb0 = a.s_off[p], np0 = (a.s_end ? a.s_end[p] : a.s_off[p + 1]) - sb0;
     const u32 lo = (u32)((u64)np0 * q / a.Q), hi = (u32)((u64)np0 * (q + 1) / a.Q);
     const u32 sb = sb0 + lo, np = hi - lo;  // this item's slice of partition p's probe rows
     if (nb == 0 || np == 0) {
@@ -392,6 +392,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
   const Tup* __restrict__ S = static_cast<const Tup*>(a.S);
   const u32* __restrict__ r_off = a.r_off;
   const u32* __restrict__ s_off = a.s_off;
+  // end of partition p: the next partition's start, unless oversized probe partitions were split into
+  // virtual partitions that share a build range (then explicit end arrays are passed)
+  const u32* __restrict__ r_end = (SLAB || a.r_end == nullptr) ? a.r_off + 1 : a.r_end;
+  const u32* __restrict__ s_end = (SLAB || a.s_end == nullptr) ? a.s_off + 1 : a.s_end;
   const u32 P = a.P;
   const int tid = threadIdx.x;
   u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
@@ -419,8 +423,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       s1 = sc[0]; s2 = s1 + sc[1]; s3 = s2 + sc[2]; np = s3 + sc[3];
       if (nb > CAP || np > CAP) slab_bad = true;
     } else {
-      rb = r_off[p]; nb = r_off[p + 1] - rb;
-      sb = s_off[p]; np = s_off[p + 1] - sb;
+      rb = r_off[p]; nb = r_end[p] - rb;
+      sb = s_off[p]; np = s_end[p] - sb;
     }
     regular = nb && np && nb <= CAP && np <= CAP;
     if (regular) {
@@ -445,8 +449,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
         s1n = sc[0]; s2n = s1n + sc[1]; s3n = s2n + sc[2]; np2 = s3n + sc[3];
         if (nb2 > CAP || np2 > CAP) slab_bad = true;
       } else {
-        rb2 = r_off[pn]; nb2 = r_off[pn + 1] - rb2;
-        sb2 = s_off[pn]; np2 = s_off[pn + 1] - sb2;
+        rb2 = r_off[pn]; nb2 = r_end[pn] - rb2;
+        sb2 = s_off[pn]; np2 = s_end[pn] - sb2;
       }
       regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
     }
@@ -772,7 +776,8 @@ __device__ __forceinline__ void order_network_global(u64* k, u64* r, u64* s, u32
 // laid out like the output (in_base32 == in_base64 == NULL); the unique-key write mode passes where
 // each partition's rows were written (slot of its first probe row) and their count.
 __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
-    const u64* __restrict__ off, const u32* __restrict__ in_base32, const u64* __restrict__ in_base64,
+    const u64* __restrict__ off, const u32* __restrict__ vstart, const u32* __restrict__ in_base32,
+    const u64* __restrict__ in_base64,
     u32 P, u32 Q, int low, const u64* __restrict__ akey,
     const u64* __restrict__ arval, const u64* __restrict__ asval, u64* __restrict__ bkey,
     u64* __restrict__ brval, u64* __restrict__ bsval) {
@@ -781,7 +786,10 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
   const int tid = threadIdx.x;
   const int bsh = low - OS_LOGB;  // bucket = key bits [low-12, low)
   for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
-    const u64 ob = off[(u64)p * Q], L64 = off[((u64)p + 1) * Q] - ob;  // output segment
+    // output segment: partition p's items are off[p*Q .. (p+1)*Q), or -- when oversized probe partitions
+    // were split into virtual partitions -- the virtual partitions vstart[p] .. vstart[p+1]
+    const u64 i0 = vstart ? (u64)vstart[p] : (u64)p * Q, i1 = vstart ? (u64)vstart[p + 1] : ((u64)p + 1) * Q;
+    const u64 ob = off[i0], L64 = off[i1] - ob;
     const u64 b = in_base64 ? in_base64[p] : (in_base32 ? (u64)in_base32[p] : ob);  // input segment start
     if (L64 == 0) continue;
     bool slow = (L64 > OS_CAP) || (bsh < 0);
@@ -894,6 +902,73 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Skewed probe sides: a partition with far more probe rows than the others would keep ONE workgroup
+// busy long after the rest of the grid has drained.  Such partitions are cut into slices of
+// slice_rows probe rows; every slice becomes a "virtual partition" with the same build range, so the
+// kernels above treat it like any other partition (the table is rebuilt per slice: small next to
+// the probe rows it serves).  vstart[p] = first virtual partition of partition p (P + 1 entries).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void split_count_kernel(const u32* __restrict__ s_off, u32 P, u32 thr_rows,
+                                                           u32 slice_rows, u32* __restrict__ vstart,
+                                                           u32* __restrict__ nv_out) {
+  __shared__ u32 scratch[17];
+  __shared__ u32 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (u32 base = 0; base < P; base += 1024) {
+    const u32 p = base + threadIdx.x;
+    u32 ns = 0;
+    if (p < P) {
+      const u32 np = s_off[p + 1] - s_off[p];
+      ns = (np > thr_rows) ? (np + slice_rows - 1) / slice_rows : 1u;
+    }
+    u32 tot;
+    const u32 ex = block_excl_scan_u32<1024>(ns, scratch, &tot);
+    if (p < P) vstart[p] = carry_s + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    vstart[P] = carry_s;
+    *nv_out = carry_s;
+  }
+}
+__global__ void split_fill_kernel(const u32* __restrict__ r_off, const u32* __restrict__ s_off, u32 P,
+                                  u32 slice_rows, u32 cap_v, const u32* __restrict__ vstart,
+                                  u32* __restrict__ vr_beg, u32* __restrict__ vr_end, u32* __restrict__ vs_beg,
+                                  u32* __restrict__ vs_end) {
+  const u32 nv = vstart[P];
+  for (u32 v = blockIdx.x * blockDim.x + threadIdx.x; v < nv && v < cap_v; v += gridDim.x * blockDim.x) {
+    u32 lo = 0, hi = P;  // last p with vstart[p] <= v
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) >> 1;
+      if (vstart[mid] <= v) lo = mid; else hi = mid;
+    }
+    const u32 p = lo, q = v - vstart[p], ns = vstart[p + 1] - vstart[p];
+    const u32 sb = s_off[p], np = s_off[p + 1] - sb;
+    vr_beg[v] = r_off[p];
+    vr_end[v] = r_off[p + 1];
+    if (ns == 1) {
+      vs_beg[v] = sb;
+      vs_end[v] = sb + np;
+    } else {
+      const u32 b = q * slice_rows, e = (b + slice_rows < np) ? b + slice_rows : np;
+      vs_beg[v] = sb + b;
+      vs_end[v] = sb + e;
+    }
+  }
+}
+hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr_rows, u32 slice_rows, u32 cap_v,
+                              u32* vstart, u32* vr_beg, u32* vr_end, u32* vs_beg, u32* vs_end, u32* nv_out,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(split_count_kernel, dim3(1), dim3(1024), 0, st, s_off, P, thr_rows, slice_rows, vstart, nv_out);
+  hipLaunchKernelGGL(split_fill_kernel, dim3((cap_v + 255) / 256), dim3(256), 0, st, r_off, s_off, P, slice_rows,
+                     cap_v, vstart, vr_beg, vr_end, vs_beg, vs_end);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int MODE, bool FIRST, bool EXTRA>
 static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
   static bool attr_set = false;
@@ -996,7 +1071,7 @@ hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st) 
   return hipGetLastError();
 }
 
-hipError_t launch_order(const u64* part_out_off, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
+hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
                         int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
                         u64* bsval, int grid, hipStream_t st) {
   static bool attr_set = false;
@@ -1009,7 +1084,7 @@ hipError_t launch_order(const u64* part_out_off, const u32* in_base32, const u64
   }
   if ((u32)grid > P) grid = (int)P;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off,
+  hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off, vstart,
                      in_base32, in_base64, P, Q, low, akey, arval, asval, bkey, brval, bsval);
   return hipGetLastError();
 }

@@ -202,6 +202,38 @@ def test_forced_radix_bits_and_overflow_chunks(ex, H, oracle, bits):
         ex.set_radix_bits(None)
 
 
+def test_skewed_probe_side_is_split_into_virtual_partitions(ex, H, oracle):
+    # Foreign-key shape: unique build keys, Zipf-skewed probe side.  The hot keys' partitions hold far more
+    # probe rows than the rest and are cut into virtual partitions (probe.hip split_*_kernel); results must be
+    # those of the unsplit plan, in every mode, and the hot partition must not serialise on one workgroup.
+    import torch
+
+    nb, npb = (1 << 22) + 1000, 1 << 23
+    thr = _zipf_thresholds(nb, theta=1.1)
+    R = ex.gen_build(nb)
+    S = ex.gen_from_cdf(npb, torch.from_numpy(thr.view(np.int64).copy()).cuda())
+    Rn, Sn = to_np(R), to_np(S)
+    ck, rows = oracle.equijoin(Rn, Sn)
+    assert ck["n_matches"] == npb
+    ckf, _ = oracle.equijoin(Rn, Sn, first_wins=True, cap=0)
+    for fl in (0, H.HMJ_CHECKSUM, H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM,
+               H.HMJ_ORDERED | H.HMJ_CHECKSUM):
+        ex.set_profiling(True)
+        r = ex.join_device(R, S, fl)
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        want = ckf if fl & H.HMJ_FIRST_WINS else ck
+        if fl & (H.HMJ_CHECKSUM):
+            assert r.checks() == want, fl
+        else:
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (want["n_matches"], want["sum_r"], want["sum_s"])
+        if fl & (H.HMJ_MATERIALIZE | H.HMJ_ORDERED):
+            got = ex.columns_to_numpy(r, host=False)
+            assert np.array_equal(got if fl & H.HMJ_ORDERED else sorted_rows(got), rows), fl
+        assert t["ms_probe_count"] < 3.0 and t["ms_probe_write"] < 6.0, (fl, t)  # unsplit: 10x that
+    ex.release_result()
+
+
 def test_keys_with_structure_tag_gap_id(ex, H, oracle):
     # Keys like (tag << 61) | id: the bits right under the shared prefix are almost constant.  Unordered
     # joins partition on the id bits instead; ordered joins do the same and finish with a stable sort of the
