@@ -804,9 +804,19 @@ def test_randomized_shapes_and_flags(ex, H, oracle):
         ck, rows = oracle.equijoin(B, P, first_wins=first)
         import time as _time
 
+        # now and then force the plan (fewer / more radix bits than the planner would take): chunked
+        # tables, probe slices and tiny partitions get their share of the sweep
+        forced = None
+        if rng.random() < 0.3:
+            forced = int(rng.integers(0, H.plan(max(nb, 1))[0] + 3))
+            ex.set_radix_bits(forced)
         _t0 = _time.perf_counter()
-        r = ex.join_device(to_dev(B), to_dev(P), fl)
-        tag = (it, nb, npb, kind, dom, fl)
+        try:
+            r = ex.join_device(to_dev(B), to_dev(P), fl)
+        finally:
+            if forced is not None:
+                ex.set_radix_bits(None)
+        tag = (it, nb, npb, kind, dom, fl, forced)
         if iters > 70:  # offline runs: progress (pytest -s), also keeps a long run from looking hung
             print("stress", tag, "matches", ck["n_matches"], "join %.1f ms" % ((_time.perf_counter() - _t0) * 1e3), flush=True)
         if os.environ.get("HMJ_STRESS_DUMP") and int(r.n_matches) != ck["n_matches"]:  # keep the failing relations
