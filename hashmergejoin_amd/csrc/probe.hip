@@ -733,10 +733,12 @@ constexpr int OS_THREADS = 1024, OS_ROWS = 5, OS_CAP = OS_THREADS * OS_ROWS, OS_
 constexpr int OS_NB = 1 << OS_LOGB, OS_MAXBUCKET = 48;
 
 struct OrderSmem {
-  u64 stage[OS_CAP];  // keys while ranking, then one column at a time while copying out
+  u64 stage[OS_CAP];  // the segment's three columns: unsorted while ranking (rows of one key are ranked on
+  u64 srv[OS_CAP];    // (rval, sval) -- a foreign-key join has many per key -- without going back to global
+  u64 ssv[OS_CAP];    // memory), then sorted for the coalesced copy-out
   u16 sidx[OS_CAP];   // row indices grouped by bucket
-  u32 bstart[OS_NB + 1];
-  u32 bcur[OS_NB];
+  u16 bstart[OS_NB + 2];
+  u32 bcur[OS_NB];    // bucket counts, then insertion cursors
   u32 scratch[OS_THREADS / kWave + 1];
   u32 fallback;
 };
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
     u32 bk[OS_ROWS], dest[OS_ROWS];
     if (!slow) {
       __syncthreads();
-      for (u32 i = tid; i <= (u32)OS_NB; i += OS_THREADS) sm.bstart[i] = 0;
+      for (u32 i = tid; i < (u32)OS_NB; i += OS_THREADS) sm.bcur[i] = 0;
       if (tid == 0) sm.fallback = 0;
 #pragma unroll
       for (int k = 0; k < OS_ROWS; k++) {
@@ -816,7 +818,9 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
         if (i < L) {
           bk[k] = (u32)(key[k] >> bsh) & (OS_NB - 1);
           sm.stage[i] = key[k];
-          atomicAdd(&sm.bstart[bk[k]], 1u);
+          sm.srv[i] = rv[k];
+          sm.ssv[i] = sv[k];
+          atomicAdd(&sm.bcur[bk[k]], 1u);
         }
       }
       __syncthreads();
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
         u32 c[4], sum = 0, mx = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          c[q] = sm.bstart[tid * 4 + q];
+          c[q] = sm.bcur[tid * 4 + q];
           sum += c[q];
           mx = c[q] > mx ? c[q] : mx;
         }
@@ -833,11 +837,11 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
         u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          sm.bstart[tid * 4 + q] = ex;
+          sm.bstart[tid * 4 + q] = (u16)ex;
           sm.bcur[tid * 4 + q] = ex;
           ex += c[q];
         }
-        if (tid == 0) sm.bstart[OS_NB] = L;
+        if (tid == 0) sm.bstart[OS_NB] = (u16)L;
       }
       __syncthreads();
       slow = sm.fallback != 0;
@@ -872,7 +876,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
           const u64 ok = sm.stage[o];
           bool less = ok < key[k];
           if (ok == key[k]) {  // duplicate key: order by (rval, sval), then by position
-            const u64 orv = arval[b + o], osv = asval[b + o];
+            const u64 orv = sm.srv[o], osv = sm.ssv[o];
             less = (orv != rv[k]) ? (orv < rv[k]) : (osv != sv[k]) ? (osv < sv[k]) : (o < i);
           }
           rank += less ? 1u : 0u;
@@ -881,23 +885,27 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
       }
     }
     __syncthreads();
-    // stage each column in sorted order, copy out coalesced
+    // the three columns in sorted order (the unsorted copies are no longer needed), copied out coalesced
 #pragma unroll
-    for (int col = 0; col < 3; col++) {
-#pragma unroll
-      for (int k = 0; k < OS_ROWS; k++) {
-        const u32 i = k * OS_THREADS + tid;
-        if (i < L) sm.stage[dest[k]] = (col == 0) ? key[k] : (col == 1) ? rv[k] : sv[k];
+    for (int k = 0; k < OS_ROWS; k++) {
+      const u32 i = k * OS_THREADS + tid;
+      if (i < L) {
+        sm.stage[dest[k]] = key[k];
+        sm.srv[dest[k]] = rv[k];
+        sm.ssv[dest[k]] = sv[k];
       }
-      __syncthreads();
-      u64* outc = (col == 0) ? bkey : (col == 1) ? brval : bsval;
-#pragma unroll
-      for (int k = 0; k < OS_ROWS; k++) {
-        const u32 i = k * OS_THREADS + tid;
-        if (i < L) outc[ob + i] = sm.stage[i];
-      }
-      __syncthreads();
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < OS_ROWS; k++) {
+      const u32 i = k * OS_THREADS + tid;
+      if (i < L) {
+        bkey[ob + i] = sm.stage[i];
+        brval[ob + i] = sm.srv[i];
+        bsval[ob + i] = sm.ssv[i];
+      }
+    }
+    __syncthreads();
   }
 }
 
