@@ -774,9 +774,117 @@ __device__ __forceinline__ void order_network_global(u64* k, u64* r, u64* s, u32
   }
 }
 
+// Sort L <= OS_CAP rows held in registers (row i = k * OS_THREADS + tid in key[k], rv[k], sv[k]) by
+// (key, rval, sval) and store them at bkey/brval/bsval[ob ..).  One bucket pass on key bits [bsh, bsh+12)
+// (all rows must agree in the bits above), then every row ranks itself among the rows of its bucket.
+// Returns false -- nothing stored -- if a bucket holds more than OS_MAXBUCKET rows (duplicate-heavy keys).
+__device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const u64 (&key)[OS_ROWS],
+                                                     const u64 (&rv)[OS_ROWS], const u64 (&sv)[OS_ROWS], int bsh,
+                                                     u64 ob, u64* __restrict__ bkey, u64* __restrict__ brval,
+                                                     u64* __restrict__ bsval, int tid) {
+  u32 bk[OS_ROWS], dest[OS_ROWS];
+  __syncthreads();
+  for (u32 i = tid; i < (u32)OS_NB; i += OS_THREADS) sm.bcur[i] = 0;
+  if (tid == 0) sm.fallback = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < OS_ROWS; k++) {
+    const u32 i = k * OS_THREADS + tid;
+    bk[k] = 0;
+    if (i < L) {
+      bk[k] = (u32)(key[k] >> bsh) & (OS_NB - 1);
+      sm.stage[i] = key[k];
+      sm.srv[i] = rv[k];
+      sm.ssv[i] = sv[k];
+      atomicAdd(&sm.bcur[bk[k]], 1u);
+    }
+  }
+  __syncthreads();
+  {  // exclusive scan of the 4096 bucket counts, 4 per thread
+    u32 c[4], sum = 0, mx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      c[q] = sm.bcur[tid * 4 + q];
+      sum += c[q];
+      mx = c[q] > mx ? c[q] : mx;
+    }
+    if (mx > OS_MAXBUCKET) sm.fallback = 1;
+    u32 tot;
+    u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      sm.bstart[tid * 4 + q] = (u16)ex;
+      sm.bcur[tid * 4 + q] = ex;
+      ex += c[q];
+    }
+    if (tid == 0) sm.bstart[OS_NB] = (u16)L;
+  }
+  __syncthreads();
+  if (sm.fallback != 0) return false;  // uniform for the workgroup
+#pragma unroll
+  for (int k = 0; k < OS_ROWS; k++) {
+    const u32 i = k * OS_THREADS + tid;
+    if (i < L) sm.sidx[atomicAdd(&sm.bcur[bk[k]], 1u)] = (u16)i;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < OS_ROWS; k++) {
+    const u32 i = k * OS_THREADS + tid;
+    dest[k] = 0;
+    if (i < L) {
+      const u32 s0 = sm.bstart[bk[k]], e0 = sm.bstart[bk[k] + 1];
+      u32 rank = 0;
+      for (u32 j = s0; j < e0; j++) {
+        const u32 o = sm.sidx[j];
+        if (o == i) continue;
+        const u64 ok = sm.stage[o];
+        bool less = ok < key[k];
+        if (ok == key[k]) {  // duplicate key: order by (rval, sval), then by position
+          const u64 orv = sm.srv[o], osv = sm.ssv[o];
+          less = (orv != rv[k]) ? (orv < rv[k]) : (osv != sv[k]) ? (osv < sv[k]) : (o < i);
+        }
+        rank += less ? 1u : 0u;
+      }
+      dest[k] = s0 + rank;
+    }
+  }
+  __syncthreads();
+  // the three columns in sorted order (the unsorted copies are no longer needed), copied out coalesced
+#pragma unroll
+  for (int k = 0; k < OS_ROWS; k++) {
+    const u32 i = k * OS_THREADS + tid;
+    if (i < L) {
+      sm.stage[dest[k]] = key[k];
+      sm.srv[dest[k]] = rv[k];
+      sm.ssv[dest[k]] = sv[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < OS_ROWS; k++) {
+    const u32 i = k * OS_THREADS + tid;
+    if (i < L) {
+      bkey[ob + i] = sm.stage[i];
+      brval[ob + i] = sm.srv[i];
+      bsval[ob + i] = sm.ssv[i];
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
 // Segment p: input rows A[in_base(p) .. + len(p)), output rows B[off[p*Q] ..).  By default the input is
 // laid out like the output (in_base32 == in_base64 == NULL); the unique-key write mode passes where
 // each partition's rows were written (slot of its first probe row) and their count.
+//   L <= OS_CAP            : one in-LDS sort;
+//   L <= OS_CHUNKS * chunk : (a many-to-many join: more result rows than probe rows) the 4096 buckets are
+//                            counted over the whole segment, consecutive buckets are grouped into chunks of
+//                            at most OS_CAP rows, and every chunk is gathered from the segment and sorted in
+//                            LDS -- the segment's keys are re-read once per chunk;
+//   otherwise, or when one bucket holds more than OS_MAXBUCKET rows: the global bitonic network.
+constexpr u32 OS_CHUNK_ROWS = OS_CAP - OS_MAXBUCKET;  // a chunk = the buckets that START inside one such window
+constexpr u32 OS_CHUNKS = 16;
+
 __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
     const u64* __restrict__ off, const u32* __restrict__ vstart, const u32* __restrict__ in_base32,
     const u64* __restrict__ in_base64,
@@ -794,37 +902,33 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
     const u64 ob = off[i0], L64 = off[i1] - ob;
     const u64 b = in_base64 ? in_base64[p] : (in_base32 ? (u64)in_base32[p] : ob);  // input segment start
     if (L64 == 0) continue;
-    bool slow = (L64 > OS_CAP) || (bsh < 0);
-    const u32 L = slow ? 0u : (u32)L64;
+    bool done = false;
     u64 key[OS_ROWS], rv[OS_ROWS], sv[OS_ROWS];
-    u32 bk[OS_ROWS], dest[OS_ROWS];
-    if (!slow) {
-      __syncthreads();
-      for (u32 i = tid; i < (u32)OS_NB; i += OS_THREADS) sm.bcur[i] = 0;
-      if (tid == 0) sm.fallback = 0;
+    if (bsh >= 0 && L64 <= OS_CAP) {
+      const u32 L = (u32)L64;
 #pragma unroll
       for (int k = 0; k < OS_ROWS; k++) {
         const u32 i = k * OS_THREADS + tid;
+        key[k] = rv[k] = sv[k] = 0;
         if (i < L) {
           key[k] = akey[b + i];
           rv[k] = arval[b + i];
           sv[k] = asval[b + i];
         }
       }
+      done = order_sort_registers(sm, L, key, rv, sv, bsh, ob, bkey, brval, bsval, tid);
+    } else if (bsh >= 0 && L64 <= (u64)OS_CHUNKS * OS_CHUNK_ROWS) {
+      const u32 L = (u32)L64;
+      // bucket counts of the whole segment -> bucket starts (kept in bstart32, aliased on sidx + bstart:
+      // they are free until a chunk is sorted, so the starts are rebuilt per chunk from the counts instead)
       __syncthreads();
-#pragma unroll
-      for (int k = 0; k < OS_ROWS; k++) {
-        const u32 i = k * OS_THREADS + tid;
-        if (i < L) {
-          bk[k] = (u32)(key[k] >> bsh) & (OS_NB - 1);
-          sm.stage[i] = key[k];
-          sm.srv[i] = rv[k];
-          sm.ssv[i] = sv[k];
-          atomicAdd(&sm.bcur[bk[k]], 1u);
-        }
-      }
+      for (u32 i = tid; i < (u32)OS_NB; i += OS_THREADS) sm.bcur[i] = 0;
+      if (tid == 0) sm.fallback = 0;
       __syncthreads();
-      {  // exclusive scan of the 4096 bucket counts, 4 per thread
+      for (u32 i = tid; i < L; i += OS_THREADS) atomicAdd(&sm.bcur[(u32)(akey[b + i] >> bsh) & (OS_NB - 1)], 1u);
+      __syncthreads();
+      u32 st[4];  // start of this thread's four buckets in the sorted segment
+      {
         u32 c[4], sum = 0, mx = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -837,17 +941,73 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
         u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          sm.bstart[tid * 4 + q] = (u16)ex;
-          sm.bcur[tid * 4 + q] = ex;
+          st[q] = ex;
           ex += c[q];
         }
-        if (tid == 0) sm.bstart[OS_NB] = (u16)L;
       }
       __syncthreads();
-      slow = sm.fallback != 0;
+      if (sm.fallback == 0) {
+        // chunk c = the buckets whose start lies in [c * OS_CHUNK_ROWS, (c+1) * OS_CHUNK_ROWS): at most
+        // OS_CHUNK_ROWS + OS_MAXBUCKET = OS_CAP rows.  chunk_of[bucket] goes to sidx (u16, free here).
+#pragma unroll
+        for (int q = 0; q < 4; q++) sm.sidx[tid * 4 + q] = (u16)(st[q] / OS_CHUNK_ROWS);
+        const u32 nchunks = (L + OS_CHUNK_ROWS - 1) / OS_CHUNK_ROWS;
+        for (u32 cnk = 0; cnk < nchunks; cnk++) {
+          __syncthreads();
+          if (tid == 0) {
+            sm.scratch[0] = 0;        // rows gathered so far
+            sm.scratch[1] = 0xFFFFFFFFu;  // smallest bucket start of the chunk = where its rows begin
+          }
+          __syncthreads();
+          // first row of the chunk in the sorted segment: the smallest start among its non-empty buckets
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (st[q] / OS_CHUNK_ROWS == cnk && sm.bcur[tid * 4 + q] != 0) atomicMin(&sm.scratch[1], st[q]);
+          // gather the chunk's rows (any order) into LDS
+          for (u32 i0r = 0; i0r < L; i0r += OS_THREADS) {
+            const u32 i = i0r + tid;
+            if (i < L) {
+              const u64 kk = akey[b + i];
+              if (sm.sidx[(u32)(kk >> bsh) & (OS_NB - 1)] == (u16)cnk) {
+                const u32 slot = atomicAdd(&sm.scratch[0], 1u);
+                sm.stage[slot] = kk;
+                sm.srv[slot] = arval[b + i];
+                sm.ssv[slot] = asval[b + i];
+              }
+            }
+          }
+          __syncthreads();
+          const u32 n_c = sm.scratch[0], base_c = sm.scratch[1];
+          __syncthreads();
+          if (n_c == 0) continue;
+#pragma unroll
+          for (int k = 0; k < OS_ROWS; k++) {
+            const u32 i = k * OS_THREADS + tid;
+            key[k] = rv[k] = sv[k] = 0;
+            if (i < n_c) {
+              key[k] = sm.stage[i];
+              rv[k] = sm.srv[i];
+              sv[k] = sm.ssv[i];
+            }
+          }
+          // (the sort below overwrites sidx and bcur: chunk_of and the counts are rebuilt from st[] / c after it)
+          u32 cnt_keep[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) cnt_keep[q] = sm.bcur[tid * 4 + q];
+          order_sort_registers(sm, n_c, key, rv, sv, bsh, ob + base_c, bkey, brval, bsval, tid);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            sm.sidx[tid * 4 + q] = (u16)(st[q] / OS_CHUNK_ROWS);
+            sm.bcur[tid * 4 + q] = cnt_keep[q];
+          }
+        }
+        __syncthreads();
+        done = true;
+      }
     }
-    if (slow) {  // uniform for the workgroup
+    if (!done) {  // uniform for the workgroup
       const u64 n = L64;
+      __syncthreads();
       for (u64 i = tid; i < n; i += OS_THREADS) {
         bkey[ob + i] = akey[b + i];
         brval[ob + i] = arval[b + i];
@@ -855,57 +1015,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
       }
       __syncthreads();
       if (n >= 2 && n <= 0x7FFFFFFFull) order_network_global(bkey + ob, brval + ob, bsval + ob, (u32)n, tid);
-      continue;
     }
-#pragma unroll
-    for (int k = 0; k < OS_ROWS; k++) {
-      const u32 i = k * OS_THREADS + tid;
-      if (i < L) sm.sidx[atomicAdd(&sm.bcur[bk[k]], 1u)] = (u16)i;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < OS_ROWS; k++) {
-      const u32 i = k * OS_THREADS + tid;
-      dest[k] = 0;
-      if (i < L) {
-        const u32 s0 = sm.bstart[bk[k]], e0 = sm.bstart[bk[k] + 1];
-        u32 rank = 0;
-        for (u32 j = s0; j < e0; j++) {
-          const u32 o = sm.sidx[j];
-          if (o == i) continue;
-          const u64 ok = sm.stage[o];
-          bool less = ok < key[k];
-          if (ok == key[k]) {  // duplicate key: order by (rval, sval), then by position
-            const u64 orv = sm.srv[o], osv = sm.ssv[o];
-            less = (orv != rv[k]) ? (orv < rv[k]) : (osv != sv[k]) ? (osv < sv[k]) : (o < i);
-          }
-          rank += less ? 1u : 0u;
-        }
-        dest[k] = s0 + rank;
-      }
-    }
-    __syncthreads();
-    // the three columns in sorted order (the unsorted copies are no longer needed), copied out coalesced
-#pragma unroll
-    for (int k = 0; k < OS_ROWS; k++) {
-      const u32 i = k * OS_THREADS + tid;
-      if (i < L) {
-        sm.stage[dest[k]] = key[k];
-        sm.srv[dest[k]] = rv[k];
-        sm.ssv[dest[k]] = sv[k];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < OS_ROWS; k++) {
-      const u32 i = k * OS_THREADS + tid;
-      if (i < L) {
-        bkey[ob + i] = sm.stage[i];
-        brval[ob + i] = sm.srv[i];
-        bsval[ob + i] = sm.ssv[i];
-      }
-    }
-    __syncthreads();
   }
 }
 

@@ -234,6 +234,28 @@ def test_skewed_probe_side_is_split_into_virtual_partitions(ex, H, oracle):
     ex.release_result()
 
 
+def test_ordered_many_to_many_uses_the_chunked_epilogue(ex, H, oracle):
+    # Every key about twice on both sides: four result rows per key, so a partition's result is several times
+    # the LDS sort's capacity.  The ordered epilogue then sorts it in chunks of consecutive key buckets (not
+    # with the global bitonic network, which took 5x longer); exact rows in (key, rval, sval) order.
+    rng = np.random.default_rng(17)
+    for n, nk in [(200000, 100000), (1 << 20, 300000)]:
+        kb = rng.integers(0, nk, size=n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        kp = rng.integers(0, nk, size=n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        B = np.stack([kb, rng.integers(0, 1 << 62, size=n, dtype=np.uint64)], 1)
+        P = np.stack([kp, rng.integers(0, 1 << 62, size=n, dtype=np.uint64)], 1)
+        ck, rows = oracle.equijoin(B, P)
+        assert ck["n_matches"] > 1.9 * n
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        assert r.checks() == ck
+        assert np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+        assert t["ms_order"] < 3.0, t["ms_order"]  # the bitonic fallback needs tens of ms here
+        ex.release_result()
+
+
 def test_keys_with_structure_tag_gap_id(ex, H, oracle):
     # Keys like (tag << 61) | id: the bits right under the shared prefix are almost constant.  Unordered
     # joins partition on the id bits instead; ordered joins do the same and finish with a stable sort of the

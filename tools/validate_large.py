@@ -65,9 +65,11 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(42)
     bad = 0
     for kb_kind, kp_kind in [("uniform", "uniform"), ("dup2", "dup2"), ("dense", "dense"), ("tagged", "tagged"), ("uniform", "hot"),
-                             ("hot", "uniform"), ("sorted", "uniform")]:
-        B = gen(kb_kind, n, g)
+                             ("hot", "uniform"), ("sorted", "uniform"), ("fk", "uniform")]:
+        B = gen(kb_kind, n if kb_kind != "fk" else n // 8, g) if kb_kind != "fk" else gen("uniform", n // 8, g)
         P = gen(kp_kind, n, g)
+        if kb_kind == "fk":  # foreign-key shape: every probe row carries one of the (n/8) build keys
+            P[:, 0] = B[torch.randint(0, B.shape[0], (n,), device=dev, generator=g), 0]
         if kp_kind in ("uniform", "hot", "sorted") and kb_kind in ("uniform", "hot", "sorted"):
             # make about half of the probe rows match something
             idx = torch.randint(0, n, (n // 2,), device=dev, generator=g)
