@@ -478,24 +478,29 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
 
   int B, passes, pass_bits[4];
   plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
-  if (materialize && c->force_bits < 0 && !c->prepare_only && n_probe > n_build) {
-    // Result rows are written (and, ordered, sorted) partition by partition: with a probe side larger than
-    // the build side -- a foreign-key join with fan-out -- size the partitions by the PROBE rows, so that a
-    // partition's result fits the LDS sort of the ordered epilogue and the single-pass write mode (up to
-    // 18 bits: still two passes, the same number as before for these sizes).
+  if (c->force_bits < 0 && np_plan > nb && nb > 0) {
+    // A probe side larger than the build side (a foreign-key join with fan-out f): size the partitions by the
+    // PROBE rows where that pays.  A partition's probe rows vary with the number of build keys it happens to
+    // hold, times f: sigma ~ sqrt(f * avg); spend another bit while avg + 5 sigma would not fit the 5120-row
+    // pipelines.
+    //  * materialising joins: result rows are written and (ordered) sorted partition by partition, so the
+    //    probe rows of a partition must fit the single-pass write mode and the LDS sort (up to 18 bits: still
+    //    two passes, the same number as before for these sizes);
+    //  * count joins: only when that makes the histogram-free slab partitioning applicable (both relations
+    //    large, two passes of at most 8 bits): 2^26 x 2^28 rows 8.3 -> 6.0 ms.  Otherwise the build-side plan
+    //    with its big probe partitions is the faster one (one table serves tens of thousands of probe rows).
     int Bp, passes_p, pb_p[4];
-    plan_bits(n_probe, -1, &Bp, &passes_p, pb_p);
-    // A partition's probe rows vary with the number of build keys it happens to hold, times the fan-out f:
-    // sigma ~ sqrt(f * avg).  Spend another bit while avg + 5 sigma would not fit the 5120-row pipeline.
-    const double f = (double)n_probe / (double)(n_build ? n_build : 1);
+    plan_bits(np_plan, -1, &Bp, &passes_p, pb_p);
+    const double f = (double)np_plan / (double)nb;
     while (Bp < 18) {
-      const double avg = (double)n_probe / (double)(1ull << Bp);
-      if (avg + 5.0 * __builtin_sqrt(f * avg) <= 4864.0) break;
+      const double avg = (double)np_plan / (double)(1ull << Bp);
+      if (avg + 5.0 * __builtin_sqrt(f * avg) <= 5056.0) break;
       Bp++;
     }
-    if (Bp > B && Bp <= 18) {
+    const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && nb >= c->slab_min_rows &&
+                         np_plan >= c->slab_min_rows;
+    if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 16 && slab_ok)))
       plan_bits(0, Bp, &B, &passes, pass_bits);  // the pass split of Bp bits
-    }
   }
   const u32 P = 1u << B;
   // probe slices: when there are few partitions, several workgroups share one partition's table
