@@ -248,6 +248,15 @@ void plan_bits(u64 n_build, int force, int* total, int* passes, int pass_bits[4]
   *passes = np;
 }
 
+// Sizes for which the histogram-free slab partitioning pays: the larger relation has at least slab_min_rows
+// rows (2^25) and the smaller one at least a quarter-million tiles' worth (2^22; its share of the time is
+// small either way).  Below that the exact path is faster.
+static inline bool slab_sizes_ok(const hmj_ctx* c, u64 nb, u64 np) {
+  const u64 big = nb > np ? nb : np, small = nb > np ? np : nb;
+  const u64 small_min = c->slab_min_rows < (1u << 22) ? c->slab_min_rows : (1u << 22);
+  return big >= c->slab_min_rows && small >= small_min;
+}
+
 // one stable LSD pass src -> dst
 int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bits, int rel,
                u64* offsets_out) {
@@ -497,8 +506,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       if (avg + 5.0 * __builtin_sqrt(f * avg) <= 5056.0) break;
       Bp++;
     }
-    const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && nb >= c->slab_min_rows &&
-                         np_plan >= c->slab_min_rows;
+    const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 16 && slab_ok)))
       plan_bits(0, Bp, &B, &passes, pass_bits);  // the pass split of Bp bits
   }
@@ -578,7 +586,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
   if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
       probe_fits &&
-      passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && nb >= c->slab_min_rows && np_plan >= c->slab_min_rows &&
+      passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && slab_sizes_ok(c, nb, np_plan) &&
       hmj::slab_geometry(nb, pass_bits[0], pass_bits[1], &gr) &&
       hmj::slab_geometry(np_plan, pass_bits[0], pass_bits[1], &gs)) {
     const bool reuse = c->prep.valid && c->prep.slab && c->prep.ptr == R && c->prep.n == nb &&
@@ -1123,7 +1131,7 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
     }
   } else if (c->slab_mode && passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8) {
     hmj::SlabGeom gr, gs;  // plain count joins of large relations take the slab path
-    if (n_build >= c->slab_min_rows && n_probe >= c->slab_min_rows &&
+    if (slab_sizes_ok(c, n_build, n_probe) &&
         hmj::slab_geometry((u32)n_build, pass_bits[0], pass_bits[1], &gr) &&
         hmj::slab_geometry((u32)n_probe, pass_bits[0], pass_bits[1], &gs)) {
       const u64 rows_a = gr.rows_a > gs.rows_a ? gr.rows_a : gs.rows_a;

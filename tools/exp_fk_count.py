@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hashmergejoin_amd as H
 ex = H.Executor(0); ex.set_profiling(True)
-for log2b, log2p in [(25, 26), (25, 27), (25, 28), (26, 28), (27, 28), (24, 28)]:
+for log2b, log2p in [(24, 26), (24, 27), (23, 26), (25, 26), (25, 27), (25, 28), (26, 28), (27, 28), (24, 28)]:
     R = ex.gen_build(1 << log2b)
     S = ex.gen_uniform_domain(1 << log2p, 1 << log2b)
     for bits in [None, H.plan(1 << log2p)[0]]:
