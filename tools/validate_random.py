@@ -94,4 +94,5 @@ def main():
     print("ALL OK" if bad == 0 else "%d MISMATCHES" % bad)
     sys.exit(1 if bad else 0)
 
-main()
+if __name__ == "__main__":
+    main()
