@@ -374,6 +374,61 @@ constexpr int kRetryNoFastWrite = 1002;  // internal: unique-key write mode gave
 constexpr int kRetryNoSlab = 1001;    // internal: the slab path gave up (skew) -> exact path
 constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-planned without the sampled prefix
 
+// The ordered epilogue.  order_kernel sorts every partition's rows from the unsorted columns (c->out_*) into
+// c->ord_*; a segment too large for its in-LDS paths (hundreds of thousands of rows of a few keys) is only
+// copied and flagged, and the whole result is then sorted by (key, rval, sval) with three stable LSD sorts
+// over {column value, row index} handles (sval, then rval, then key).  `by_key_only`: the partitions are not
+// key ranges (window partitioning of keys with structure) but internally sorted -- one stable sort by key
+// finishes the order.  On return *rk/*rr/*rs are the ordered columns.
+int order_rows(hmj_ctx* c, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q, int low,
+               u64 n, bool by_key_only, const u64** rk, const u64** rr, const u64** rs, int* retry_code) {
+  int rc;
+  const size_t bytes = (size_t)n * 8;
+  if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
+  const bool can_sort = n <= 0xFFFFFFFFull;  // row indices of the global sorts are 32-bit
+  if (by_key_only && !can_sort) {
+    *retry_code = kRetryNoWinOrdered;
+    return HMJ_OK;
+  }
+  int sp = span_begin(c, K_ORDER, -1);
+  HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, vstart, in_base32, in_base64, P, Q, low,
+                            (const u64*)c->out_key.p, (const u64*)c->out_rval.p, (const u64*)c->out_sval.p,
+                            (u64*)c->ord_key.p, (u64*)c->ord_rval.p, (u64*)c->ord_sval.p, (u64*)c->accum.p,
+                            can_sort ? 65536u : 0u, c->num_cus * 4, c->stream));
+  span_end(c, sp);
+  u64* h = (u64*)c->h_accum.p;
+  HIP_TRY(hipMemcpyAsync(&h[hmj::ACC_ERR], (u64*)c->accum.p + hmj::ACC_ERR, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const bool deferred = (h[hmj::ACC_ERR] & hmj::ERR_ORDER_DEFER) != 0;
+  *rk = (const u64*)c->ord_key.p;
+  *rr = (const u64*)c->ord_rval.p;
+  *rs = (const u64*)c->ord_sval.p;
+  if (!deferred && !by_key_only) return HMJ_OK;
+  c->prep.valid = false;  // the partition buffers become the sort's ping-pong pair
+  if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->rbuf[1], (size_t)n * 16)) != HMJ_OK) return rc;
+  sp = span_begin(c, K_ORDER, -1);
+  const u64* cols[3] = {*rs, *rr, *rk};  // least significant sort key first
+  for (int kcol = deferred ? 0 : 2; kcol < 3; kcol++) {
+    if (kcol == (deferred ? 0 : 2))
+      HIP_TRY(hmj::launch_key_idx(cols[kcol], n, c->rbuf[0].p, c->stream));
+    else
+      HIP_TRY(hmj::launch_rekey(c->rbuf[0].p, n, cols[kcol], c->stream));
+    for (int pass = 0; pass < 8; pass++)  // eight passes end in rbuf[0] again
+      if ((rc = radix_pass(c, c->rbuf[pass & 1].p, c->rbuf[(pass & 1) ^ 1].p, (u32)n, 8 * pass, 8, -1, nullptr)) != HMJ_OK)
+        return rc;
+  }
+  HIP_TRY(hmj::launch_gather3(c->rbuf[0].p, n, *rr, *rs, (u64*)c->out_key.p, (u64*)c->out_rval.p,
+                              (u64*)c->out_sval.p, c->stream));
+  span_end(c, sp);
+  *rk = (const u64*)c->out_key.p;
+  *rr = (const u64*)c->out_rval.p;
+  *rs = (const u64*)c->out_sval.p;
+  return HMJ_OK;
+}
+
 // Ordered join, unique-build-key fast path: ONE probe pass writes each partition's rows into the slots
 // of its own probe rows (no count pass), a scan of the per-partition row counts gives the final offsets,
 // and the ordered epilogue moves every partition to its place while sorting it.  Returns
@@ -442,17 +497,10 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   const bool dense_out = !ordered && out->n_matches == (u64)np;
   const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
   if (!dense_out) {
-    if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
-    if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
-    if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
-    sp = span_begin(c, K_ORDER, -1);
-    HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, nullptr, in_base32, in_base64, P, 1, low, wa.out_key,
-                              wa.out_rval, wa.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
-                              (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
-    span_end(c, sp);
-    rk = (const u64*)c->ord_key.p;
-    rr = (const u64*)c->ord_rval.p;
-    rs = (const u64*)c->ord_sval.p;
+    int retry = 0;
+    if ((rc = order_rows(c, nullptr, in_base32, in_base64, P, 1, low, out->n_matches, false, &rk, &rr, &rs, &retry)) !=
+        HMJ_OK)
+      return rc;
   }
   if (to_host) {
     if ((rc = ensure_host(c, c->h_key, bytes, false)) != HMJ_OK) return rc;
@@ -851,41 +899,16 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     HIP_TRY(hmj::launch_probe(a, 2, first, false, grid, c->stream));
     span_end(c, s);
     c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
-    if (flags & HMJ_ORDERED) {  // out of place: unsorted columns -> sorted columns
-      if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
-      s = span_begin(c, K_ORDER, -1);
-      HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, v_start, nullptr, nullptr, P, Q, low, a.out_key, a.out_rval,
-                                a.out_sval, (u64*)c->ord_key.p, (u64*)c->ord_rval.p,
-                                (u64*)c->ord_sval.p, c->num_cus * 4, c->stream));
-      span_end(c, s);
-      a.out_key = (u64*)c->ord_key.p;
-      a.out_rval = (u64*)c->ord_rval.p;
-      a.out_sval = (u64*)c->ord_sval.p;
-      if (win_ordered) {
-        // The partitions are not key ranges here (window partitioning of keys with structure).  Every
-        // partition is sorted, and all rows of one key sit together in (rval, sval) order, so a STABLE
-        // sort of the rows by key finishes the job: eight 8-bit LSD passes over {key, row index}, then a
-        // gather of the payload columns.
-        const u64 n = out->n_matches;
-        if (n > 0xFFFFFFFFull) return kRetryNoWinOrdered;
-        c->prep.valid = false;
-        if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
-        if ((rc = ensure_dev(c, c->rbuf[1], (size_t)n * 16)) != HMJ_OK) return rc;
-        s = span_begin(c, K_ORDER, -1);
-        HIP_TRY(hmj::launch_key_idx(a.out_key, n, c->rbuf[0].p, c->stream));
-        for (int pass = 0; pass < 8; pass++)
-          if ((rc = radix_pass(c, c->rbuf[pass & 1].p, c->rbuf[(pass & 1) ^ 1].p, (u32)n, 8 * pass, 8, -1,
-                               nullptr)) != HMJ_OK)
-            return rc;
-        HIP_TRY(hmj::launch_gather3(c->rbuf[0].p, n, a.out_rval, a.out_sval, (u64*)c->out_key.p,
-                                    (u64*)c->out_rval.p, (u64*)c->out_sval.p, c->stream));
-        span_end(c, s);
-        a.out_key = (u64*)c->out_key.p;
-        a.out_rval = (u64*)c->out_rval.p;
-        a.out_sval = (u64*)c->out_sval.p;
-      }
+    if (flags & HMJ_ORDERED) {  // out of place: unsorted columns -> sorted columns (order_rows)
+      const u64 *rk = nullptr, *rr = nullptr, *rs = nullptr;
+      int retry = 0;
+      if ((rc = order_rows(c, v_start, nullptr, nullptr, P, Q, low, out->n_matches, win_ordered, &rk, &rr, &rs,
+                           &retry)) != HMJ_OK)
+        return rc;
+      if (retry) return retry;
+      a.out_key = const_cast<u64*>(rk);
+      a.out_rval = const_cast<u64*>(rr);
+      a.out_sval = const_cast<u64*>(rs);
     }
     if (to_host) {
       if ((rc = ensure_host(c, c->h_key, bytes, false)) != HMJ_OK) return rc;

@@ -127,4 +127,17 @@ hipError_t launch_gather3(const void* sorted, u64 n, const u64* rval, const u64*
   return hipGetLastError();
 }
 
+// handles {., idx} -> {col[idx], idx}, in place: the next key of a multi-key LSD sort
+__global__ void rekey_kernel(Tup* __restrict__ pairs, u64 n, const u64* __restrict__ col) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    Tup t = pairs[i];
+    t.key = col[t.val];
+    pairs[i] = t;
+  }
+}
+hipError_t launch_rekey(void* pairs, u64 n, const u64* col, hipStream_t st) {
+  hipLaunchKernelGGL(rekey_kernel, dim3(2048), dim3(256), 0, st, static_cast<Tup*>(pairs), n, col);
+  return hipGetLastError();
+}
+
 }  // namespace hmj

@@ -67,6 +67,7 @@ constexpr int PB_PLAN_SLACK = 256;     // planner: tolerated excess of that aver
 // accumulator slots (global u64[8])
 enum { ACC_N = 0, ACC_SUM_R, ACC_SUM_S, ACC_XOR, ACC_MIX, ACC_SUM_P, ACC_ERR, ACC_PAD };
 constexpr u64 ERR_SLAB = 2;    // slab path: a slab overflowed or a partition does not fit -> exact path
+constexpr u64 ERR_ORDER_DEFER = 16;  // ordered epilogue left a very large segment unsorted: the host sorts the result
 constexpr u64 ERR_FASTPATH = 8;  // unique-key write mode met duplicate build keys / an oversized partition
 constexpr u64 ERR_PREFIX = 4;  // a key does not carry the sampled common prefix (ordered mode re-plans)
 

@@ -890,7 +890,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
     const u64* __restrict__ in_base64,
     u32 P, u32 Q, int low, const u64* __restrict__ akey,
     const u64* __restrict__ arval, const u64* __restrict__ asval, u64* __restrict__ bkey,
-    u64* __restrict__ brval, u64* __restrict__ bsval) {
+    u64* __restrict__ brval, u64* __restrict__ bsval, u64* __restrict__ accum, u32 defer_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   OrderSmem& sm = *reinterpret_cast<OrderSmem*>(smem_raw);
   const int tid = threadIdx.x;
@@ -1014,7 +1014,13 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
         bsval[ob + i] = asval[b + i];
       }
       __syncthreads();
-      if (n >= 2 && n <= 0x7FFFFFFFull) order_network_global(bkey + ob, brval + ob, bsval + ob, (u32)n, tid);
+      if (defer_rows && n > defer_rows) {
+        // hundreds of thousands of rows of few keys: a bitonic network run by one workgroup would take
+        // seconds.  Leave the segment as copied; the host sorts the whole result instead (api.hip).
+        if (tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_ORDER_DEFER);
+      } else if (n >= 2 && n <= 0x7FFFFFFFull) {
+        order_network_global(bkey + ob, brval + ob, bsval + ob, (u32)n, tid);
+      }
     }
   }
 }
@@ -1191,7 +1197,7 @@ hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st) 
 
 hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
                         int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
-                        u64* bsval, int grid, hipStream_t st) {
+                        u64* bsval, u64* accum, u32 defer_rows, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(order_kernel),
@@ -1203,7 +1209,7 @@ hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* i
   if ((u32)grid > P) grid = (int)P;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off, vstart,
-                     in_base32, in_base64, P, Q, low, akey, arval, asval, bkey, brval, bsval);
+                     in_base32, in_base64, P, Q, low, akey, arval, asval, bkey, brval, bsval, accum, defer_rows);
   return hipGetLastError();
 }
 

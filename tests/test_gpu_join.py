@@ -234,6 +234,32 @@ def test_skewed_probe_side_is_split_into_virtual_partitions(ex, H, oracle):
     ex.release_result()
 
 
+def test_ordered_rows_of_very_few_keys(ex, H, oracle):
+    # Hundreds of thousands of result rows per key: no in-LDS path of the ordered epilogue applies, and a
+    # bitonic network run by one workgroup took seconds.  Such segments are deferred to three stable LSD sorts
+    # of the whole result on (sval, rval, key); exact rows in (key, rval, sval) order.
+    rng = np.random.default_rng(23)
+    kb = np.unique(rng.integers(0, 1 << 63, size=7, dtype=np.uint64))
+    B = np.stack([kb, rng.integers(0, 1 << 62, size=len(kb), dtype=np.uint64)], 1)
+    n = 1 << 20
+    P = np.stack([kb[rng.integers(0, len(kb), size=n)], rng.integers(0, 1 << 62, size=n, dtype=np.uint64)], 1)
+    ck, rows = oracle.equijoin(B, P)
+    assert ck["n_matches"] == n
+    for bits in (None, 3):  # default plan (probe slices of one partition) and a forced multi-partition plan
+        ex.set_radix_bits(bits)
+        try:
+            ex.set_profiling(True)
+            r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+            t = ex.last_timing()
+            ex.set_profiling(False)
+        finally:
+            ex.set_radix_bits(None)
+        assert r.checks() == ck
+        assert np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+        assert t["ms_order"] < 20.0, t["ms_order"]  # the one-workgroup bitonic network: hundreds of ms
+    ex.release_result()
+
+
 def test_ordered_many_to_many_uses_the_chunked_epilogue(ex, H, oracle):
     # Every key about twice on both sides: four result rows per key, so a partition's result is several times
     # the LDS sort's capacity.  The ordered epilogue then sorts it in chunks of consecutive key buckets (not
