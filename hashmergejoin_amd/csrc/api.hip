@@ -521,7 +521,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
 
 int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                      uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix,
-                     bool allow_slab, bool allow_fast_write, bool allow_win_ordered) {
+                     bool allow_slab, bool allow_fast_write, bool allow_win_ordered, bool prefix_unsafe) {
   int rc;
   if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
   std::memset(out, 0, sizeof(*out));
@@ -617,6 +617,13 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
         // an ordered result is then finished by a stable sort of the rows on the whole key (below)
         win_ordered = (flags & HMJ_ORDERED) != 0;
       }
+    }
+    if (prefix_unsafe && (flags & HMJ_ORDERED) && allow_win_ordered && sampled) {
+      // a first attempt found rows outside the sampled prefix (a few outliers above an otherwise dense key
+      // range): keep the plan -- dropping the prefix would put every row into one partition -- but stop
+      // relying on partitions being key ranges: the result gets the final stable sort by key
+      sampled = false;
+      win_ordered = true;
     }
   }
   if (prefix + B > 64) prefix = 64 - B;
@@ -769,13 +776,21 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     u32 thr = probe_fits ? 5120u : 4u * avg, slice = probe_fits ? 4096u : avg;
     if (!probe_fits && thr < 32768u) thr = 32768u;
     if (!probe_fits && slice < 16384u) slice = 16384u;
-    const u32 cap_v = P + np / slice + 1;  // every split partition adds at most np_p / slice virtual ones
+    // modes that enumerate every pair (materialise, checksums) and are not first-wins also cut partitions with
+    // thousands of copies of a key on the build side: the cross product of a hot key is then written by many
+    // workgroups (each build slice meets every probe slice of the partition)
+    // (not with HMJ_SUM_PROBE: a probe row would be added once per build slice)
+    const bool enumerating = (materialize || extra) && !first && !(flags & HMJ_SUM_PROBE);
+    const u32 build_thr = enumerating ? 16384u : 0u, build_slice = 4096u;
+    // virtual partitions: at most P + np / slice from probe slices; build slices multiply a partition's count,
+    // bounded by giving the table room for 8x that (a larger total makes the split be ignored)
+    const u32 cap_v = (P + np / slice + 1) * (enumerating ? 8u : 1u);
     if ((rc = ensure_dev(c, c->vparts, ((size_t)cap_v * 4 + P + 3) * 4)) != HMJ_OK) return rc;
     u32* vp = (u32*)c->vparts.p;
     u32 *d_vstart = vp, *d_nv = vp + P + 1, *d_rb = vp + P + 2, *d_re = d_rb + cap_v, *d_sb = d_re + cap_v,
         *d_se = d_sb + cap_v;
-    HIP_TRY(hmj::launch_split_parts((const u32*)c->r_off.p, (const u32*)c->s_off.p, P, thr, slice, cap_v, d_vstart,
-                                    d_rb, d_re, d_sb, d_se, d_nv, c->stream));
+    HIP_TRY(hmj::launch_split_parts((const u32*)c->r_off.p, (const u32*)c->s_off.p, P, thr, slice, build_thr, build_slice,
+                                    cap_v, d_vstart, d_rb, d_re, d_sb, d_se, d_nv, c->stream));
     u32* hnv = (u32*)c->h_accum.p;
     HIP_TRY(hipMemcpyAsync(hnv, d_nv, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -930,10 +945,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
 
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
-  bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true;
-  for (int attempt = 0; attempt < 5; attempt++) {
+  bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true, prefix_unsafe = false;
+  for (int attempt = 0; attempt < 6; attempt++) {
     int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab, fast_write,
-                              win_ordered);
+                              win_ordered, prefix_unsafe);
     if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite || rc == kRetryNoWinOrdered) {
       // forget the abandoned attempt's phase spans (the enclosing total / h2d spans stay)
       std::vector<Span> keep;
@@ -944,6 +959,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
       if (rc == kRetryNoSlab) slab = false;
       else if (rc == kRetryNoFastWrite) fast_write = false;
       else if (rc == kRetryNoWinOrdered) win_ordered = false;
+      else if (!prefix_unsafe && win_ordered) prefix_unsafe = true;  // outliers: same plan + final sort by key
       else auto_prefix = false;
       continue;
     }

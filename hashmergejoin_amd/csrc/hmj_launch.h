@@ -87,9 +87,9 @@ hipError_t launch_gen_probe(void* out, u64 n, u64 start, u64 n_build, u64 seed, 
 hipError_t launch_gen_from_cdf(void* out, u64 n, u64 start, const u64* thr, u64 domain, u64 seed,
                                u64 zseed, hipStream_t st);
 // split oversized probe partitions into virtual partitions (api.hip, skewed probe sides)
-hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr_rows, u32 slice_rows, u32 cap_v,
-                              u32* vstart, u32* vr_beg, u32* vr_end, u32* vs_beg, u32* vs_end, u32* nv_out,
-                              hipStream_t st);
+hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr_rows, u32 slice_rows, u32 build_thr,
+                              u32 build_slice, u32 cap_v, u32* vstart, u32* vr_beg, u32* vr_end, u32* vs_beg,
+                              u32* vs_end, u32* nv_out, hipStream_t st);
 hipError_t launch_key_idx(const u64* key, u64 n, void* out, hipStream_t st);
 hipError_t launch_gather3(const void* sorted, u64 n, const u64* rval, const u64* sval, u64* okey, u64* orval,
                           u64* osval, hipStream_t st);

@@ -1032,8 +1032,19 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
 // kernels above treat it like any other partition (the table is rebuilt per slice: small next to
 // the probe rows it serves).  vstart[p] = first virtual partition of partition p (P + 1 entries).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void split_count_kernel(const u32* __restrict__ s_off, u32 P, u32 thr_rows,
-                                                           u32 slice_rows, u32* __restrict__ vstart,
+// build_thr != 0 (modes that enumerate every matching pair, not first-wins): a partition with more than
+// build_thr build rows -- thousands of copies of a key -- is cut on the BUILD side too (slices of build_slice
+// rows, each joined with all of the partition's probe slices), so that one hot key's cross product is written
+// by many workgroups.
+__device__ __forceinline__ void split_shape(const u32* r_off, const u32* s_off, u32 p, u32 thr_rows, u32 slice_rows,
+                                            u32 build_thr, u32 build_slice, u32* ns, u32* nbs) {
+  const u32 np = s_off[p + 1] - s_off[p], nb = r_off[p + 1] - r_off[p];
+  *ns = (np > thr_rows) ? (np + slice_rows - 1) / slice_rows : 1u;
+  *nbs = (build_thr && nb > build_thr && np) ? (nb + build_slice - 1) / build_slice : 1u;
+}
+__global__ __launch_bounds__(1024) void split_count_kernel(const u32* __restrict__ r_off, const u32* __restrict__ s_off,
+                                                           u32 P, u32 thr_rows, u32 slice_rows, u32 build_thr,
+                                                           u32 build_slice, u32 cap_v, u32* __restrict__ vstart,
                                                            u32* __restrict__ nv_out) {
   __shared__ u32 scratch[17];
   __shared__ u32 carry_s;
@@ -1043,8 +1054,10 @@ __global__ __launch_bounds__(1024) void split_count_kernel(const u32* __restrict
     const u32 p = base + threadIdx.x;
     u32 ns = 0;
     if (p < P) {
-      const u32 np = s_off[p + 1] - s_off[p];
-      ns = (np > thr_rows) ? (np + slice_rows - 1) / slice_rows : 1u;
+      u32 a, b;
+      split_shape(r_off, s_off, p, thr_rows, slice_rows, build_thr, build_slice, &a, &b);
+      const unsigned long long prod = (unsigned long long)a * b;
+      ns = prod > cap_v ? cap_v + 1 : (u32)prod;  // (an overflowing total makes the host ignore the split)
     }
     u32 tot;
     const u32 ex = block_excl_scan_u32<1024>(ns, scratch, &tot);
@@ -1058,8 +1071,9 @@ __global__ __launch_bounds__(1024) void split_count_kernel(const u32* __restrict
     *nv_out = carry_s;
   }
 }
-__global__ void split_fill_kernel(const u32* __restrict__ r_off, const u32* __restrict__ s_off, u32 P,
-                                  u32 slice_rows, u32 cap_v, const u32* __restrict__ vstart,
+__global__ void split_fill_kernel(const u32* __restrict__ r_off, const u32* __restrict__ s_off, u32 P, u32 thr_rows,
+                                  u32 slice_rows, u32 build_thr, u32 build_slice, u32 cap_v,
+                                  const u32* __restrict__ vstart,
                                   u32* __restrict__ vr_beg, u32* __restrict__ vr_end, u32* __restrict__ vs_beg,
                                   u32* __restrict__ vs_end) {
   const u32 nv = vstart[P];
@@ -1069,26 +1083,36 @@ __global__ void split_fill_kernel(const u32* __restrict__ r_off, const u32* __re
       const u32 mid = (lo + hi) >> 1;
       if (vstart[mid] <= v) lo = mid; else hi = mid;
     }
-    const u32 p = lo, q = v - vstart[p], ns = vstart[p + 1] - vstart[p];
-    const u32 sb = s_off[p], np = s_off[p + 1] - sb;
-    vr_beg[v] = r_off[p];
-    vr_end[v] = r_off[p + 1];
+    const u32 p = lo, q = v - vstart[p];
+    u32 ns, nbs;
+    split_shape(r_off, s_off, p, thr_rows, slice_rows, build_thr, build_slice, &ns, &nbs);
+    const u32 qb = q / ns, qs = q % ns;  // build slice major, probe slice minor
+    const u32 sb = s_off[p], np = s_off[p + 1] - sb, rb = r_off[p], nb = r_off[p + 1] - rb;
+    if (nbs == 1) {
+      vr_beg[v] = rb;
+      vr_end[v] = rb + nb;
+    } else {
+      const u32 b = qb * build_slice, e = (b + build_slice < nb) ? b + build_slice : nb;
+      vr_beg[v] = rb + b;
+      vr_end[v] = rb + e;
+    }
     if (ns == 1) {
       vs_beg[v] = sb;
       vs_end[v] = sb + np;
     } else {
-      const u32 b = q * slice_rows, e = (b + slice_rows < np) ? b + slice_rows : np;
+      const u32 b = qs * slice_rows, e = (b + slice_rows < np) ? b + slice_rows : np;
       vs_beg[v] = sb + b;
       vs_end[v] = sb + e;
     }
   }
 }
-hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr_rows, u32 slice_rows, u32 cap_v,
-                              u32* vstart, u32* vr_beg, u32* vr_end, u32* vs_beg, u32* vs_end, u32* nv_out,
-                              hipStream_t st) {
-  hipLaunchKernelGGL(split_count_kernel, dim3(1), dim3(1024), 0, st, s_off, P, thr_rows, slice_rows, vstart, nv_out);
-  hipLaunchKernelGGL(split_fill_kernel, dim3((cap_v + 255) / 256), dim3(256), 0, st, r_off, s_off, P, slice_rows,
-                     cap_v, vstart, vr_beg, vr_end, vs_beg, vs_end);
+hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr_rows, u32 slice_rows, u32 build_thr,
+                              u32 build_slice, u32 cap_v, u32* vstart, u32* vr_beg, u32* vr_end, u32* vs_beg,
+                              u32* vs_end, u32* nv_out, hipStream_t st) {
+  hipLaunchKernelGGL(split_count_kernel, dim3(1), dim3(1024), 0, st, r_off, s_off, P, thr_rows, slice_rows, build_thr,
+                     build_slice, cap_v, vstart, nv_out);
+  hipLaunchKernelGGL(split_fill_kernel, dim3((cap_v + 255) / 256), dim3(256), 0, st, r_off, s_off, P, thr_rows,
+                     slice_rows, build_thr, build_slice, cap_v, vstart, vr_beg, vr_end, vs_beg, vs_end);
   return hipGetLastError();
 }
 

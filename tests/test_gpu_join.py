@@ -647,6 +647,20 @@ def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
     assert r.checks() == ck2 and np.array_equal(ex.columns_to_numpy(r, host=False), rows2)
     r = ex.join_device(to_dev(B2), to_dev(P2), H.HMJ_CHECKSUM)
     assert r.checks() == ck2
+    # the common way to get such outliers: dense keys 0..N-1 with N slightly above a power of two (the sample
+    # misses the few keys >= 2^k).  The plan is kept and the ordered result finished by a sort on the key; once
+    # this dropped the prefix instead and joined ONE partition of millions of rows (minutes at 2^25 rows).
+    n3 = (1 << 21) + 900
+    k3 = rng.permutation(n3).astype(np.uint64)
+    B3 = np.stack([k3, np.arange(n3, dtype=np.uint64)], 1)
+    P3 = np.stack([rng.permutation(n3).astype(np.uint64), np.arange(n3, dtype=np.uint64) + np.uint64(3)], 1)
+    ck3, rows3 = oracle.equijoin(B3, P3)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(B3), to_dev(P3), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    ex.set_profiling(False)
+    assert r.checks() == ck3 and np.array_equal(ex.columns_to_numpy(r, host=False), rows3)
+    assert t["ms_probe_count"] + t["ms_probe_write"] < 10.0
     # reference known-answer shape: radix_hash_test.cc:82-93 keys 12345..1 (descending ints)
     k = np.arange(12345, 0, -1, dtype=np.uint64)
     D = np.stack([k, k], 1)

@@ -62,7 +62,13 @@ def main():
         else:  # fk: every probe row references a build key
             kb = r(M63, nb) * 2 + r(2, nb); kp = kb[r(nb, npb)]
         B = torch.stack([kb, r(M63, nb)], 1).contiguous(); P = torch.stack([kp, r(M63, npb)], 1).contiguous()
+        if it < int(os.environ.get("VR_START", "0")):
+            continue
+        if os.environ.get("VR_VERBOSE"):
+            print("   config", it, kind, nb, npb, flush=True)
         want = reference(B, P)
+        if os.environ.get("VR_VERBOSE"):
+            print("   reference done: matches", want["n"], flush=True)
         res = ex.join_device(B, P, 0)
         ok = (int(res.n_matches), s64(int(res.sum_r)), s64(int(res.sum_s))) == (want["n"], want["sum_r"], want["sum_s"])
         f = ex.join_device(B, P, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE)
@@ -71,6 +77,8 @@ def main():
         if want["n"] <= (1 << 26):
             c = ex.join_device(B, P, H.HMJ_CHECKSUM).checks()
             for fl in (H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_ORDERED | H.HMJ_CHECKSUM, H.HMJ_FIRST_WINS | H.HMJ_ORDERED):
+                if os.environ.get("VR_VERBOSE"):
+                    print("   flags", fl, flush=True)
                 m = ex.join_device(B, P, fl)
                 if fl & H.HMJ_FIRST_WINS:
                     ok3 = ok3 and int(m.n_matches) == want["fw_n"] and s64(int(m.sum_r)) == want["fw_sum_r"]
