@@ -4,6 +4,7 @@ random sizes (2^16 .. 2^25 rows per side, independently), key distributions, fan
 Usage: tools/validate_random.py [iters] [seed]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import time
 import torch
 import hashmergejoin_amd as H
 from hashmergejoin_amd.join import _memcpy_d2d
@@ -40,10 +41,19 @@ def main():
     r = lambda hi, size: torch.randint(0, hi, (size,), dtype=torch.int64, device=dev, generator=g)
     ex = H.Executor(0)
     bad = 0
+    slow = []
+    _join = ex.join_device
+    def timed_join(B, P, fl):
+        t0 = time.perf_counter(); r_ = _join(B, P, fl); dt = time.perf_counter() - t0
+        if dt > 1.0:
+            slow.append((dt, fl))
+        return r_
+    ex.join_device = timed_join
     for it in range(iters):
-        nb, npb = 1 << ri(16, 26), 1 << ri(16, 26)
+        lo_, hi_ = int(os.environ.get("VR_MINLOG", "16")), int(os.environ.get("VR_MAXLOG", "25")) + 1
+        nb, npb = 1 << ri(lo_, hi_), 1 << ri(lo_, hi_)
         nb += ri(0, 5000); npb += ri(0, 5000)
-        kind = ["uniform", "dups", "dense", "tagged", "hotprobe", "hotbuild", "fk"][ri(0, 7)]
+        kind = ["uniform", "dups", "dense", "tagged", "hotprobe", "hotbuild", "fk", "densepow2", "fewkeys", "strided"][ri(0, 10)]
         if kind == "uniform":
             kb = r(M63, nb) * 2 + r(2, nb); kp = r(M63, npb) * 2
             m = npb // 2; kp[:m] = kb[r(nb, m)]
@@ -59,6 +69,17 @@ def main():
         elif kind == "hotbuild":
             kb = r(M63, nb) * 2 + 1; kb[r(nb, min(nb // 20, 200000))] = 0x1234567890ABCDEF; kp = kb[r(nb, npb)]
             kp[: npb // 2] = r(M63, npb // 2) * 2  # half of the probes miss (keeps the cross product finite)
+        elif kind == "densepow2":  # dense 0..N-1, N just above a power of two: a few keys beyond the sampled prefix
+            N = (1 << (nb.bit_length() - 1)) + ri(1, 2000)
+            kb = torch.randperm(N, device=dev, generator=g)[: min(nb, N)]; nb = kb.numel()
+            kp = r(N, npb)
+        elif kind == "fewkeys":    # a handful of keys on both sides: giant cross products / giant equal-key groups
+            pool = r(M63, ri(1, 40)) * 2 + 1
+            kb = pool[r(pool.numel(), min(nb, 1 << 18))]; nb = kb.numel()
+            kp = r(M63, npb) * 2; m = ri(0, 3000); kp[:m] = pool[r(pool.numel(), m)] if m else kp[:0]
+        elif kind == "strided":    # keys = i * stride: varying bits spread out
+            st = [3, 0x1111, 1 << 20, (1 << 33) + 1][ri(0, 4)]
+            kb = (torch.randperm(nb, device=dev, generator=g) * st) & M63; kp = (r(2 * nb, npb) * st) & M63
         else:  # fk: every probe row references a build key
             kb = r(M63, nb) * 2 + r(2, nb); kp = kb[r(nb, npb)]
         B = torch.stack([kb, r(M63, nb)], 1).contiguous(); P = torch.stack([kp, r(M63, npb)], 1).contiguous()
@@ -95,8 +116,10 @@ def main():
                     # sums over the materialised rows equal the reported sums
                     ok3 = ok3 and s64(int(cols[1].sum().item())) == s64(int(m.sum_r)) and s64(int(cols[2].sum().item())) == s64(int(m.sum_s))
                 ex.release_result()
-        print("it %3d %-9s nb=%9d np=%9d matches %12d : count %s first-wins %s rows %s" % (
-            it, kind, nb, npb, want["n"], "OK" if ok else "WRONG", "OK" if ok2 else "WRONG", "OK" if ok3 else "WRONG"), flush=True)
+        print("it %3d %-9s nb=%9d np=%9d matches %12d : count %s first-wins %s rows %s%s" % (
+            it, kind, nb, npb, want["n"], "OK" if ok else "WRONG", "OK" if ok2 else "WRONG", "OK" if ok3 else "WRONG",
+            "  SLOW " + ", ".join("%.1fs(flags %d)" % x for x in slow) if slow else ""), flush=True)
+        del slow[:]
         bad += (not ok) + (not ok2) + (not ok3)
         del B, P
     print("ALL OK" if bad == 0 else "%d MISMATCHES" % bad)
