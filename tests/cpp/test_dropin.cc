@@ -198,6 +198,16 @@ int main() {
   fails += run_prehashed_case(300000, 200000, 0, 1);
   fails += run_prehashed_case(5000, 3000, 3, 2);
   fails += run_prehashed_case(1 << 16, 1 << 16, 2, 2);
+  {  // seeded sweep over sizes around the executor's tile / table boundaries
+    uint64_t x = 88172645463325252ull;
+    auto next = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    const uint64_t sizes[] = {1, 2, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 5119, 5120, 5121, 8191, 20000, 65537, 150001};
+    for (int it = 0; it < 40; it++) {
+      const uint64_t nb = sizes[next() % 18], np = sizes[next() % 18];
+      fails += run_case(nb, np > nb ? nb : np, next() % 4, false);  // unique probe keys need np <= nb
+      if (it % 4 == 0) fails += run_prehashed_case(nb, np > nb ? nb : np, next() % 4, 1);
+    }
+  }
   run_string_case(1000, 1000, 1);
   run_string_case(5000, 3000, 2);
   run_string_case(200000, 150000, 3);
