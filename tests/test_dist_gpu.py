@@ -34,9 +34,12 @@ if os.environ.get("MAXMSG"):
 b0, b1 = rank * nb // world, (rank + 1) * nb // world
 p0, p1 = rank * npb // world, (rank + 1) * npb // world
 Bs = o.gen_build(b1 - b0, start=b0)
-if dup:  # duplicate build keys across shards: global row i and i + nb/2 share a key
+if dup == 1:  # duplicate build keys across shards: global row i and i + nb/2 share a key
     Bs[:, 0] = o.gen_build(b1 - b0, start=b0 % (nb // 2))[:, 0] if b0 >= nb // 2 else Bs[:, 0]
-Ps = o.gen_probe(p1 - p0, nb // 2 if dup else nb, start=p0, miss_mod=miss)
+Ps = o.gen_probe(p1 - p0, nb // 2 if dup == 1 else nb, start=p0, miss_mod=miss)
+if dup == 2:  # dense integer keys: every row's owner bits are 0 -> rank 0 receives everything, the others nothing
+    Bs[:, 0] = np.arange(b0, b1, dtype=np.uint64)
+    Ps[:, 0] = (np.arange(p0, p1, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
 to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy()).cuda()
 ex = H.Executor(0)
 bd, pd = to_dev(Bs), to_dev(Ps)
@@ -63,7 +66,8 @@ def free_port():
 
 
 @pytest.mark.parametrize("world,nb,npb,miss,dup,maxmsg", [(2, 300000, 200000, 3, 0, 0), (4, 1 << 20, (1 << 20) + 777, 0, 0, 0),
-                                                            (2, 1 << 21, 1 << 22, 5, 1, 1 << 20), (2, (1 << 23) + 10, 1 << 23, 0, 0, 0)])
+                                                            (2, 1 << 21, 1 << 22, 5, 1, 1 << 20), (2, (1 << 23) + 10, 1 << 23, 0, 0, 0),
+                                                            (2, 300000, 250000, 0, 2, 0)])
 def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup, maxmsg):
     port = free_port()
     procs = []
@@ -76,9 +80,12 @@ def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     glob = json.load(open(tmp_path / "glob.json"))
     B = oracle.gen_build(nb)
-    if dup:
+    if dup == 1:
         B[nb // 2:, 0] = B[: nb - nb // 2, 0]
-    P = oracle.gen_probe(npb, nb // 2 if dup else nb, miss_mod=miss)
+    P = oracle.gen_probe(npb, nb // 2 if dup == 1 else nb, miss_mod=miss)
+    if dup == 2:
+        B[:, 0] = np.arange(nb, dtype=np.uint64)
+        P[:, 0] = (np.arange(npb, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
     ck, rows = oracle.equijoin(B, P)
     ckf, _ = oracle.equijoin(B, P, first_wins=True, cap=0)
     assert glob["count"] == glob["count_again"]
