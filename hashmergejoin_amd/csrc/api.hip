@@ -584,17 +584,18 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
   const void *Rp, *Sp;
   int prefix = c->prefix_bits < 0 ? 0 : c->prefix_bits;
-  bool sampled = false, win_ordered = false;
+  bool sampled = false, win_ordered = false, hot_hint = false;
   u64 pfx_ref = 0;
   if (c->prefix_bits < 0 && allow_auto_prefix && B > 0 && (u64)nb + np > 0) {
     // dense / small-integer keys: skip the top bits every (sampled) key shares
     u64* hs = (u64*)c->h_accum.p;
-    if ((rc = ensure_dev(c, c->offs64, 2 * sizeof(u64))) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->offs64, 4 * sizeof(u64))) != HMJ_OK) return rc;
     HIP_TRY(hmj::launch_key_sample(R, nb, S, np, (u64*)c->offs64.p, c->stream));
-    HIP_TRY(hipMemcpyAsync(hs, c->offs64.p, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hs, c->offs64.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     prefix = hs[0] ? __builtin_clzll(hs[0]) : 64;
     pfx_ref = hs[1];
+    hot_hint = hs[2] >= 2 || hs[3] >= 2;  // neighbouring sample positions with equal keys: a hot key
     sampled = prefix > 0;
     if (prefix + B > 64) prefix = 64 - B;
     if (!c->prepare_only && c->window_mode && (!(flags & HMJ_ORDERED) || allow_win_ordered)) {
@@ -771,7 +772,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // split_*_kernel).  Pi = number of (virtual) partitions the probe kernels iterate over.
   u32 Pi = P;
   const u32 *v_start = nullptr, *vr_beg = nullptr, *vr_end = nullptr, *vs_beg = nullptr, *vs_end = nullptr;
-  if (Q == 1 && P >= 1024 && np > 0 && c->split_mode) {
+  // (not with HMJ_SUM_PROBE: a probe row would be added once per build slice)
+  const bool enumerating = (materialize || extra) && !first && !(flags & HMJ_SUM_PROBE);
+  // the step costs one 4-byte read-back: count modes take it from 1024 partitions on (joins of a few ms), the
+  // modes that write or mix every pair -- where one hot key can mean tens of millions of rows -- from 16 on,
+  // when the key sample saw a repeated key
+  if (Q == 1 && (P >= 1024 || (enumerating && hot_hint && P >= 16)) && np > 0 && c->split_mode) {
     const u32 avg = np / P + 1;
     u32 thr = probe_fits ? 5120u : 4u * avg, slice = probe_fits ? 4096u : avg;
     if (!probe_fits && thr < 32768u) thr = 32768u;
@@ -779,9 +785,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // modes that enumerate every pair (materialise, checksums) and are not first-wins also cut partitions with
     // thousands of copies of a key on the build side: the cross product of a hot key is then written by many
     // workgroups (each build slice meets every probe slice of the partition)
-    // (not with HMJ_SUM_PROBE: a probe row would be added once per build slice)
-    const bool enumerating = (materialize || extra) && !first && !(flags & HMJ_SUM_PROBE);
-    const u32 build_thr = enumerating ? 16384u : 0u, build_slice = 4096u;
+    const u32 build_thr = enumerating ? 6144u : 0u, build_slice = 4096u;
     // virtual partitions: at most P + np / slice from probe slices; build slices multiply a partition's count,
     // bounded by giving the table room for 8x that (a larger total makes the split be ignored)
     const u32 cap_v = (P + np / slice + 1) * (enumerating ? 8u : 1u);

@@ -697,33 +697,49 @@ __global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int low, i
 // out[0] = OR, out[1] = reference key.  A sample can miss outliers: the join stays correct for any
 // prefix (the partition id is a function of the key); ordered output additionally verifies it.
 // ---------------------------------------------------------------------------------------------
+// out[2] / out[3]: number of neighbouring sample positions of the build / probe relation that carry the SAME
+// key (a hint that costs two shuffles: unique keys give 0; a key that holds 5 % of a relation makes ~5 of the
+// 2048 neighbouring pairs equal).
 __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict__ R, u32 nb,
                                                           const Tup* __restrict__ S, u32 np,
                                                           u64* __restrict__ out) {
   __shared__ u64 acc;
-  const int tid = threadIdx.x;
+  __shared__ u32 same[2];
+  const int tid = threadIdx.x, lane = tid & 63;
   const u64* rk = reinterpret_cast<const u64*>(R);
   const u64* sk = reinterpret_cast<const u64*>(S);
   const u64 ref = nb ? rk[0] : (np ? sk[0] : 0);
   if (tid == 0) acc = 0;
+  if (tid < 2) same[tid] = 0;
   __syncthreads();
   u64 x = 0;
+  u32 eq_r = 0, eq_s = 0;
   const u32 sr = nb / 2048 + 1, ss = np / 2048 + 1;  // ~2048 samples per relation
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const u64 i = (u64)(tid + k * 1024) * sr, j = (u64)(tid + k * 1024) * ss;
-    if (i < nb) x |= rk[2 * i] ^ ref;
-    if (j < np) x |= sk[2 * j] ^ ref;
+    const bool vr = i < nb, vs = j < np;
+    const u64 kr = vr ? rk[2 * i] : 0, ks = vs ? sk[2 * j] : 0;
+    if (vr) x |= kr ^ ref;
+    if (vs) x |= ks ^ ref;
+    const u64 kr_next = __shfl_down(kr, 1, kWave), ks_next = __shfl_down(ks, 1, kWave);
+    const bool vr_next = __shfl_down((int)vr, 1, kWave) != 0, vs_next = __shfl_down((int)vs, 1, kWave) != 0;
+    if (lane < 63 && vr && vr_next && kr == kr_next) eq_r++;
+    if (lane < 63 && vs && vs_next && ks == ks_next) eq_s++;
   }
   if (nb) x |= rk[2 * (u64)(nb - 1)] ^ ref;
   if (np) x |= sk[2 * (u64)(np - 1)] ^ ref;
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) x |= __shfl_xor(x, o, kWave);
   if ((tid & 63) == 0 && x) atomicOr(&acc, x);
+  if (eq_r) atomicAdd(&same[0], eq_r);
+  if (eq_s) atomicAdd(&same[1], eq_s);
   __syncthreads();
   if (tid == 0) {
     out[0] = acc;
     out[1] = ref;
+    out[2] = same[0];
+    out[3] = same[1];
   }
 }
 
