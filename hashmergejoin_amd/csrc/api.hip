@@ -568,7 +568,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     Q = (u32)(by_grid < by_rows ? by_grid : by_rows);
     if (Q < 1) Q = 1;
   }
-  const u64 items = (u64)P * Q;
+  u64 items = (u64)P * Q;
 
   if ((rc = ensure_dev(c, c->r_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->s_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
@@ -596,6 +596,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     prefix = hs[0] ? __builtin_clzll(hs[0]) : 64;
     pfx_ref = hs[1];
     hot_hint = hs[2] >= 2 || hs[3] >= 2;  // neighbouring sample positions with equal keys: a hot key
+    if (hot_hint && P >= 16 && Q > 1 && c->split_mode && !c->prepare_only) {
+      // uniform probe slices would leave the hot partition to a few workgroups: take one item per partition
+      // and let the split step below cut the oversized ones into as many virtual partitions as they need
+      Q = 1;
+      items = P;
+    }
     sampled = prefix > 0;
     if (prefix + B > 64) prefix = 64 - B;
     if (!c->prepare_only && c->window_mode && (!(flags & HMJ_ORDERED) || allow_win_ordered)) {
@@ -774,14 +780,15 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   const u32 *v_start = nullptr, *vr_beg = nullptr, *vr_end = nullptr, *vs_beg = nullptr, *vs_end = nullptr;
   // (not with HMJ_SUM_PROBE: a probe row would be added once per build slice)
   const bool enumerating = (materialize || extra) && !first && !(flags & HMJ_SUM_PROBE);
-  // the step costs one 4-byte read-back: count modes take it from 1024 partitions on (joins of a few ms), the
-  // modes that write or mix every pair -- where one hot key can mean tens of millions of rows -- from 16 on,
-  // when the key sample saw a repeated key
-  if (Q == 1 && (P >= 1024 || (enumerating && hot_hint && P >= 16)) && np > 0 && c->split_mode) {
-    const u32 avg = np / P + 1;
-    u32 thr = probe_fits ? 5120u : 4u * avg, slice = probe_fits ? 4096u : avg;
-    if (!probe_fits && thr < 32768u) thr = 32768u;
+  // the step costs one 4-byte read-back: taken from 1024 partitions on (joins of a few ms), and from 16 on when
+  // the key sample saw a repeated key (a hot key can mean one partition with most of the rows)
+  if (Q == 1 && (P >= 1024 || (hot_hint && P >= 16)) && np > 0 && c->split_mode) {
+    // average partition fits the pipelines: cut everything above them into 4096-row slices.  Otherwise (big
+    // probe partitions by plan) a slice is 1/2048 of the probe side -- enough slices to fill the chip even when
+    // one partition holds most of the rows -- and only partitions of more than four slices are cut.
+    u32 slice = probe_fits ? 4096u : np / 2048u;
     if (!probe_fits && slice < 16384u) slice = 16384u;
+    const u32 thr = probe_fits ? 5120u : 4u * slice;
     // modes that enumerate every pair (materialise, checksums) and are not first-wins also cut partitions with
     // thousands of copies of a key on the build side: the cross product of a hot key is then written by many
     // workgroups (each build slice meets every probe slice of the partition)
