@@ -795,7 +795,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     const u32 build_thr = enumerating ? 6144u : 0u, build_slice = 4096u;
     // virtual partitions: at most P + np / slice from probe slices; build slices multiply a partition's count,
     // bounded by giving the table room for 8x that (a larger total makes the split be ignored)
-    const u32 cap_v = (P + np / slice + 1) * (enumerating ? 8u : 1u);
+    u32 cap_v = (P + np / slice + 1) * (enumerating ? 8u : 1u);
+    if (enumerating && cap_v < (1u << 18)) cap_v = 1u << 18;  // room for the 256-row slices of build-heavy partitions
     if ((rc = ensure_dev(c, c->vparts, ((size_t)cap_v * 4 + P + 3) * 4)) != HMJ_OK) return rc;
     u32* vp = (u32*)c->vparts.p;
     u32 *d_vstart = vp, *d_nv = vp + P + 1, *d_rb = vp + P + 2, *d_re = d_rb + cap_v, *d_sb = d_re + cap_v,

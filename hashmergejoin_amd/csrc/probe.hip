@@ -1041,6 +1041,9 @@ __device__ __forceinline__ void split_shape(const u32* r_off, const u32* s_off, 
   const u32 np = s_off[p + 1] - s_off[p], nb = r_off[p + 1] - r_off[p];
   *ns = (np > thr_rows) ? (np + slice_rows - 1) / slice_rows : 1u;
   *nbs = (build_thr && nb > build_thr && np) ? (nb + build_slice - 1) / build_slice : 1u;
+  // thousands of copies of a build key: every probe row that hits it yields thousands of result rows, written
+  // by the one thread that owns the probe row -- so give such a partition many small probe slices too
+  if (*nbs > 1 && np > 256u) *ns = (np + 255u) / 256u;
 }
 __global__ __launch_bounds__(1024) void split_count_kernel(const u32* __restrict__ r_off, const u32* __restrict__ s_off,
                                                            u32 P, u32 thr_rows, u32 slice_rows, u32 build_thr,
@@ -1100,8 +1103,9 @@ __global__ void split_fill_kernel(const u32* __restrict__ r_off, const u32* __re
       vs_beg[v] = sb;
       vs_end[v] = sb + np;
     } else {
-      const u32 b = qs * slice_rows, e = (b + slice_rows < np) ? b + slice_rows : np;
-      vs_beg[v] = sb + b;
+      const u32 step = (np + ns - 1) / ns;  // (a build-heavy partition uses 256-row probe slices)
+      const u32 b = qs * step, e = (b + step < np) ? b + step : np;
+      vs_beg[v] = sb + (b < np ? b : np);
       vs_end[v] = sb + e;
     }
   }
