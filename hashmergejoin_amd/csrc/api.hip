@@ -381,7 +381,7 @@ constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-plann
 // key ranges (window partitioning of keys with structure) but internally sorted -- one stable sort by key
 // finishes the order.  On return *rk/*rr/*rs are the ordered columns.
 int order_rows(hmj_ctx* c, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q, int low,
-               u64 n, bool by_key_only, const u64** rk, const u64** rr, const u64** rs, int* retry_code) {
+               u64 n, bool by_key_only, bool many_per_key, const u64** rk, const u64** rr, const u64** rs, int* retry_code) {
   int rc;
   const size_t bytes = (size_t)n * 8;
   if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
@@ -396,7 +396,7 @@ int order_rows(hmj_ctx* c, const u32* vstart, const u32* in_base32, const u64* i
   HIP_TRY(hmj::launch_order((const u64*)c->part_out_off.p, vstart, in_base32, in_base64, P, Q, low,
                             (const u64*)c->out_key.p, (const u64*)c->out_rval.p, (const u64*)c->out_sval.p,
                             (u64*)c->ord_key.p, (u64*)c->ord_rval.p, (u64*)c->ord_sval.p, (u64*)c->accum.p,
-                            can_sort ? 65536u : 0u, c->num_cus * 4, c->stream));
+                            can_sort ? 65536u : 0u, many_per_key, c->num_cus * 4, c->stream));
   span_end(c, sp);
   u64* h = (u64*)c->h_accum.p;
   HIP_TRY(hipMemcpyAsync(&h[hmj::ACC_ERR], (u64*)c->accum.p + hmj::ACC_ERR, 8, hipMemcpyDeviceToHost, c->stream));
@@ -498,7 +498,8 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
   if (!dense_out) {
     int retry = 0;
-    if ((rc = order_rows(c, nullptr, in_base32, in_base64, P, 1, low, out->n_matches, false, &rk, &rr, &rs, &retry)) !=
+    if ((rc = order_rows(c, nullptr, in_base32, in_base64, P, 1, low, out->n_matches, false, out->n_matches > 2ull * nb,
+                         &rk, &rr, &rs, &retry)) !=
         HMJ_OK)
       return rc;
   }
@@ -929,8 +930,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     if (flags & HMJ_ORDERED) {  // out of place: unsorted columns -> sorted columns (order_rows)
       const u64 *rk = nullptr, *rr = nullptr, *rs = nullptr;
       int retry = 0;
-      if ((rc = order_rows(c, v_start, nullptr, nullptr, P, Q, low, out->n_matches, win_ordered, &rk, &rr, &rs,
-                           &retry)) != HMJ_OK)
+      if ((rc = order_rows(c, v_start, nullptr, nullptr, P, Q, low, out->n_matches, win_ordered,
+                           out->n_matches > 2ull * nb, &rk, &rr, &rs, &retry)) != HMJ_OK)
         return rc;
       if (retry) return retry;
       a.out_key = const_cast<u64*>(rk);

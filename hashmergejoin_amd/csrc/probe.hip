@@ -778,6 +778,9 @@ __device__ __forceinline__ void order_network_global(u64* k, u64* r, u64* s, u32
 // (key, rval, sval) and store them at bkey/brval/bsval[ob ..).  One bucket pass on key bits [bsh, bsh+12)
 // (all rows must agree in the bits above), then every row ranks itself among the rows of its bucket.
 // Returns false -- nothing stored -- if a bucket holds more than OS_MAXBUCKET rows (duplicate-heavy keys).
+// MANY: the caller expects several rows per key (fan-out): the ranking loop is then branch-free and unrolled, so
+// that the loads of consecutive candidates overlap (-11 % on a 16-fold fan-out, +13 % on unique keys).
+template <bool MANY>
 __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const u64 (&key)[OS_ROWS],
                                                      const u64 (&rv)[OS_ROWS], const u64 (&sv)[OS_ROWS], int bsh,
                                                      u64 ob, u64* __restrict__ bkey, u64* __restrict__ brval,
@@ -834,16 +837,27 @@ __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const
     if (i < L) {
       const u32 s0 = sm.bstart[bk[k]], e0 = sm.bstart[bk[k] + 1];
       u32 rank = 0;
-      for (u32 j = s0; j < e0; j++) {
-        const u32 o = sm.sidx[j];
-        if (o == i) continue;
-        const u64 ok = sm.stage[o];
-        bool less = ok < key[k];
-        if (ok == key[k]) {  // duplicate key: order by (rval, sval), then by position
-          const u64 orv = sm.srv[o], osv = sm.ssv[o];
-          less = (orv != rv[k]) ? (orv < rv[k]) : (osv != sv[k]) ? (osv < sv[k]) : (o < i);
+      if (MANY) {  // order by key, then (rval, sval), then position; the row itself is "not less"
+#pragma unroll 4
+        for (u32 j = s0; j < e0; j++) {
+          const u32 o = sm.sidx[j];
+          const u64 ok = sm.stage[o], orv = sm.srv[o], osv = sm.ssv[o];
+          const bool less = (ok < key[k]) | ((ok == key[k]) & ((orv < rv[k]) | ((orv == rv[k]) &
+                            ((osv < sv[k]) | ((osv == sv[k]) & (o < i))))));
+          rank += less ? 1u : 0u;
         }
-        rank += less ? 1u : 0u;
+      } else {
+        for (u32 j = s0; j < e0; j++) {
+          const u32 o = sm.sidx[j];
+          if (o == i) continue;
+          const u64 ok = sm.stage[o];
+          bool less = ok < key[k];
+          if (ok == key[k]) {  // duplicate key: order by (rval, sval), then by position
+            const u64 orv = sm.srv[o], osv = sm.ssv[o];
+            less = (orv != rv[k]) ? (orv < rv[k]) : (osv != sv[k]) ? (osv < sv[k]) : (o < i);
+          }
+          rank += less ? 1u : 0u;
+        }
       }
       dest[k] = s0 + rank;
     }
@@ -885,6 +899,7 @@ __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const
 constexpr u32 OS_CHUNK_ROWS = OS_CAP - OS_MAXBUCKET;  // a chunk = the buckets that START inside one such window
 constexpr u32 OS_CHUNKS = 16;
 
+template <bool MANY>
 __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
     const u64* __restrict__ off, const u32* __restrict__ vstart, const u32* __restrict__ in_base32,
     const u64* __restrict__ in_base64,
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
           sv[k] = asval[b + i];
         }
       }
-      done = order_sort_registers(sm, L, key, rv, sv, bsh, ob, bkey, brval, bsval, tid);
+      done = order_sort_registers<MANY>(sm, L, key, rv, sv, bsh, ob, bkey, brval, bsval, tid);
     } else if (bsh >= 0 && L64 <= (u64)OS_CHUNKS * OS_CHUNK_ROWS) {
       const u32 L = (u32)L64;
       // bucket counts of the whole segment -> bucket starts (kept in bstart32, aliased on sidx + bstart:
@@ -994,7 +1009,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
           u32 cnt_keep[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) cnt_keep[q] = sm.bcur[tid * 4 + q];
-          order_sort_registers(sm, n_c, key, rv, sv, bsh, ob + base_c, bkey, brval, bsval, tid);
+          order_sort_registers<MANY>(sm, n_c, key, rv, sv, bsh, ob + base_c, bkey, brval, bsval, tid);
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             sm.sidx[tid * 4 + q] = (u16)(st[q] / OS_CHUNK_ROWS);
@@ -1223,22 +1238,31 @@ hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st) 
   return hipGetLastError();
 }
 
-hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
-                        int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
-                        u64* bsval, u64* accum, u32 defer_rows, int grid, hipStream_t st) {
+template <bool MANY>
+static hipError_t launch_order_t(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64,
+                                 u32 P, u32 Q, int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey,
+                                 u64* brval, u64* bsval, u64* accum, u32 defer_rows, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(order_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(OrderSmem));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(order_kernel<MANY>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OrderSmem));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if ((u32)grid > P) grid = (int)P;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(order_kernel, dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off, vstart,
+  hipLaunchKernelGGL((order_kernel<MANY>), dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off, vstart,
                      in_base32, in_base64, P, Q, low, akey, arval, asval, bkey, brval, bsval, accum, defer_rows);
   return hipGetLastError();
+}
+// many_per_key: the result has clearly more rows than the build side has keys (fan-out)
+hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
+                        int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
+                        u64* bsval, u64* accum, u32 defer_rows, bool many_per_key, int grid, hipStream_t st) {
+  return many_per_key ? launch_order_t<true>(part_out_off, vstart, in_base32, in_base64, P, Q, low, akey, arval, asval,
+                                             bkey, brval, bsval, accum, defer_rows, grid, st)
+                      : launch_order_t<false>(part_out_off, vstart, in_base32, in_base64, P, Q, low, akey, arval, asval,
+                                              bkey, brval, bsval, accum, defer_rows, grid, st);
 }
 
 }  // namespace hmj
