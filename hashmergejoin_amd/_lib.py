@@ -8,6 +8,10 @@ HMJ_ORDERED = 0x02
 HMJ_FIRST_WINS = 0x04
 HMJ_CHECKSUM = 0x08
 HMJ_SUM_PROBE = 0x10
+# hmj_timing.path bits
+HMJ_PATH_SLAB, HMJ_PATH_EXACT, HMJ_PATH_UNIQ_WRITE, HMJ_PATH_SPLIT, HMJ_PATH_WINDOW = 0x1, 0x2, 0x4, 0x8, 0x10
+HMJ_PATH_ORDER_DEFERRED, HMJ_PATH_ORDER_BY_KEY, HMJ_PATH_PREPARED, HMJ_PATH_CHUNKED_BUILD = 0x20, 0x40, 0x80, 0x100
+HMJ_PATH_HOT_KEY_HINT = 0x200
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _U64P = C.POINTER(C.c_uint64)
@@ -35,12 +39,14 @@ class Timing(C.Structure):
                 ("ms_offsets", C.c_float), ("ms_probe_count", C.c_float),
                 ("ms_out_scan", C.c_float), ("ms_probe_write", C.c_float), ("ms_order", C.c_float),
                 ("radix_bits", C.c_int), ("radix_passes", C.c_int),
-                ("n_scatter_launches", C.c_int), ("reserved", C.c_int),
+                ("n_scatter_launches", C.c_int), ("n_split_retries", C.c_int),
                 ("bytes_scatter", C.c_uint64), ("bytes_hist", C.c_uint64),
-                ("bytes_probe_count", C.c_uint64), ("bytes_probe_write", C.c_uint64)]
+                ("bytes_probe_count", C.c_uint64), ("bytes_probe_write", C.c_uint64),
+                ("path", C.c_uint32), ("key_prefix_bits", C.c_int32), ("key_window_low", C.c_int32),
+                ("n_probe_items", C.c_uint32), ("ms_scatter_pass0", C.c_float), ("ms_scatter_pass1", C.c_float)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 def lib_path():
@@ -98,6 +104,10 @@ def load_library():
     L.hmj_join_u64_rows.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult), C.POINTER(vp)]
     L.hmj_rows_free.restype = None
     L.hmj_rows_free.argtypes = [vp]
+    L.hmj_host_pool_trim.restype = u
+    L.hmj_host_pool_trim.argtypes = [u]
+    L.hmj_host_pool_bytes.restype = u
+    L.hmj_host_pool_bytes.argtypes = []
     L.hmj_set_host_threads.restype = i
     L.hmj_set_host_threads.argtypes = [vp, i]
     L.hmj_release_result.restype = None

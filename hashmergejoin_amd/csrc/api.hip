@@ -38,6 +38,7 @@ enum Kind {
 };
 struct Span {
   int kind, rel, e0, e1;  // rel: 0 = build side, 1 = probe side, -1 = n/a
+  int pass;               // K_SCATTER: 0 = a relation's first radix pass, 1 = a later one
 };
 
 }  // namespace
@@ -75,6 +76,9 @@ struct hmj_ctx {
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;
+#ifdef HMJ_DEV
+  u32 dev_ablate = 0;  // developer builds: HMJ_DEBUG_ABLATE, read once at hmj_create
+#endif
   std::vector<hipEvent_t> events;
   std::vector<Span> spans;
   int ev_used = 0;
@@ -105,6 +109,10 @@ int fail(hmj_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
 
 int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return HMJ_OK;
+  // a prepared build side (hmj_prepare_build_u64_device) lives in these buffers: once one of them is
+  // reallocated the prepared state points at freed memory, so it is dropped here, whoever the caller is
+  if (c && (&b == &c->rbuf[0] || &b == &c->rbuf[1] || &b == &c->r_off || &b == &c->slab_br || &b == &c->cnt_br))
+    c->prep.valid = false;
   if (b.p) {
     hipError_t e = hipFree(b.p);
     b.p = nullptr;
@@ -129,14 +137,50 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
 //   memory runs at 24 GB/s, into memory used before at 54 GB/s -- the same as into pinned memory --
 //   so a one-shot join of 2^26 rows gets its 1.5 GiB of result columns in 64 ms instead of 258 ms.
 std::mutex g_pool_mu;
-std::vector<HostBuf> g_pool;
+std::vector<HostBuf> g_pool;  // oldest first
+size_t g_pool_bytes = 0;
+// The pool keeps at most this many bytes; what exceeds it is returned to the OS (oldest buffers first).
+// HMJ_HOST_POOL_MAX_MB (read once per process) overrides the default of 8 GiB; hmj_host_pool_trim() empties it.
+size_t pool_limit() {
+  static const size_t lim = [] {
+    const char* e = getenv("HMJ_HOST_POOL_MAX_MB");
+    const long long mb = e ? atoll(e) : 8192;
+    return (size_t)(mb < 0 ? 0 : mb) << 20;
+  }();
+  return lim;
+}
+
+void host_release(HostBuf& b) {
+  if (!b.p) return;
+  if (b.pinned)
+    (void)hipHostFree(b.p);
+  else
+    free(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+// caller holds g_pool_mu
+size_t pool_trim_locked(size_t keep_bytes) {
+  size_t released = 0;
+  while (g_pool_bytes > keep_bytes && !g_pool.empty()) {
+    HostBuf b = g_pool.front();
+    g_pool.erase(g_pool.begin());
+    g_pool_bytes -= b.cap;
+    released += b.cap;
+    host_release(b);
+  }
+  return released;
+}
 
 void pool_give(HostBuf& b) {
   if (!b.p) return;
   std::lock_guard<std::mutex> g(g_pool_mu);
   g_pool.push_back(b);
+  g_pool_bytes += b.cap;
   b.p = nullptr;
   b.cap = 0;
+  pool_trim_locked(pool_limit());
 }
 
 bool pool_take(size_t bytes, bool pinned, HostBuf* out) {
@@ -149,6 +193,7 @@ bool pool_take(size_t bytes, bool pinned, HostBuf* out) {
   if (best < 0) return false;
   *out = g_pool[best];
   g_pool.erase(g_pool.begin() + best);
+  g_pool_bytes -= out->cap;
   return true;
 }
 
@@ -184,9 +229,9 @@ void free_dev(DevBuf& b) {
 void free_host(HostBuf& b) { pool_give(b); }
 
 // ---- profiling spans ---------------------------------------------------------------------------
-int span_begin(hmj_ctx* c, int kind, int rel) {
+int span_begin(hmj_ctx* c, int kind, int rel, int pass = 0) {
   if (!c->profiling || c->ev_used + 2 > (int)c->events.size()) return -1;
-  Span s{kind, rel, c->ev_used, c->ev_used + 1};
+  Span s{kind, rel, c->ev_used, c->ev_used + 1, pass};
   c->ev_used += 2;
   (void)hipEventRecord(c->events[s.e0], c->stream);
   c->spans.push_back(s);
@@ -212,7 +257,11 @@ void spans_collect(hmj_ctx* c) {  // call after the stream is synchronized
       case K_D2H: t.ms_d2h += ms; break;
       case K_HIST: t.ms_hist += ms; break;
       case K_SCAN: t.ms_scan += ms; break;
-      case K_SCATTER: t.ms_scatter += ms; t.n_scatter_launches++; break;
+      case K_SCATTER:
+        t.ms_scatter += ms;
+        t.n_scatter_launches++;
+        t.ms_scatter_pass[s.pass ? 1 : 0] += ms;
+        break;
       case K_OFFSETS: t.ms_offsets += ms; break;
       case K_PROBE_COUNT: t.ms_probe_count += ms; break;
       case K_OUT_SCAN: t.ms_out_scan += ms; break;
@@ -259,7 +308,7 @@ static inline bool slab_sizes_ok(const hmj_ctx* c, u64 nb, u64 np) {
 
 // one stable LSD pass src -> dst
 int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bits, int rel,
-               u64* offsets_out) {
+               u64* offsets_out, int pass_index = 0) {
   u32 nblk, rpb;
   const int variant = c->scatter_variant;
   const int tile = hmj::radix_tile_rows(bits, variant);
@@ -273,7 +322,7 @@ int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bit
   s = span_begin(c, K_SCAN, rel);
   HIP_TRY(hmj::launch_radix_rowscan((u32*)c->hist.p, nblk, bits, (u32*)c->totals.p, c->stream));
   span_end(c, s);
-  s = span_begin(c, K_SCATTER, rel);
+  s = span_begin(c, K_SCATTER, rel, pass_index);
   HIP_TRY(hmj::launch_radix_scatter(src, dst, n, variant, shift, bits, (const u32*)c->hist.p,
                                     (const u32*)c->totals.p, nblk, rpb, offsets_out, c->stream));
   span_end(c, s);
@@ -294,7 +343,7 @@ int partition_relation(hmj_ctx* c, const void* in, u32 n, DevBuf buf[2], int top
   int shift = top;  // lowest of the partition bits
   for (int i = 0; i < passes; i++) {
     void* dst = buf[i & 1].p;
-    if ((rc = radix_pass(c, src, dst, n, shift, pass_bits[i], rel, nullptr)) != HMJ_OK) return rc;
+    if ((rc = radix_pass(c, src, dst, n, shift, pass_bits[i], rel, nullptr, i)) != HMJ_OK) return rc;
     shift += pass_bits[i];
     src = dst;
   }
@@ -401,11 +450,14 @@ int order_rows(hmj_ctx* c, const u32* vstart, const u32* in_base32, const u64* i
   u64* h = (u64*)c->h_accum.p;
   HIP_TRY(hipMemcpyAsync(&h[hmj::ACC_ERR], (u64*)c->accum.p + hmj::ACC_ERR, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h[hmj::ACC_ERR] & hmj::ERR_ORDER_FAIL)
+    return fail(c, HMJ_E_UNSUPPORTED, "HMJ_ORDERED: one partition's result exceeds 2^31-1 rows and the whole result 2^32-1 rows");
   const bool deferred = (h[hmj::ACC_ERR] & hmj::ERR_ORDER_DEFER) != 0;
   *rk = (const u64*)c->ord_key.p;
   *rr = (const u64*)c->ord_rval.p;
   *rs = (const u64*)c->ord_sval.p;
   if (!deferred && !by_key_only) return HMJ_OK;
+  c->timing.path |= (deferred ? HMJ_PATH_ORDER_DEFERRED : 0u) | (by_key_only ? HMJ_PATH_ORDER_BY_KEY : 0u);
   c->prep.valid = false;  // the partition buffers become the sort's ping-pong pair
   if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->rbuf[1], (size_t)n * 16)) != HMJ_OK) return rc;
@@ -490,6 +542,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   out->mix_sum = h[hmj::ACC_MIX];
   out->sum_probe_all = h[hmj::ACC_SUM_P];
   c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
+  c->timing.path |= HMJ_PATH_UNIQ_WRITE;
   if (out->n_matches == 0) return HMJ_OK;
   const size_t bytes = (size_t)out->n_matches * 8;
   // every probe row matched: the columns have no gaps, an unordered result is complete as it stands.
@@ -621,6 +674,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       }
       if (best_low != 64 - prefix - B) {
         prefix = 64 - B - best_low;  // "prefix" now only positions the window; nothing relies on it
+        c->timing.path |= HMJ_PATH_WINDOW;
         sampled = false;
         // an ordered result is then finished by a stable sort of the rows on the whole key (below)
         win_ordered = (flags & HMJ_ORDERED) != 0;
@@ -637,6 +691,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   if (prefix + B > 64) prefix = 64 - B;
   const int low = 64 - prefix - B;  // partition id = (key >> low) & (P - 1)
   const bool verify_pfx = sampled && prefix > 0 && (flags & HMJ_ORDERED);  // ordered output relies on it
+  c->timing.key_prefix_bits = prefix;
+  c->timing.key_window_low = low;
+  if (hot_hint) c->timing.path |= HMJ_PATH_HOT_KEY_HINT;
+  if (((u64)nb >> B) > hmj::PB_CAP) c->timing.path |= HMJ_PATH_CHUNKED_BUILD;
   // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;
   hmj::SlabGeom gr, gs;
@@ -655,6 +713,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     const bool reuse = c->prep.valid && c->prep.slab && c->prep.ptr == R && c->prep.n == nb &&
                        c->prep.low == low && c->prep.B == B;
     c->prep.valid = false;  // one-shot; slab_br is about to be (re)written unless reused
+    c->timing.path |= HMJ_PATH_SLAB | (reuse ? HMJ_PATH_PREPARED : 0u);
+    c->timing.n_probe_items = P;
     const int ba = pass_bits[0], bb = pass_bits[1];
     const u64 rows_a = gr.rows_a > gs.rows_a ? gr.rows_a : gs.rows_a;
     const u32 wa = gr.WA > gs.WA ? gr.WA : gs.WA;
@@ -673,7 +733,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       int sp = span_begin(c, K_SCATTER, sd.rel);
       HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
       span_end(c, sp);
-      sp = span_begin(c, K_SCATTER, sd.rel);
+      sp = span_begin(c, K_SCATTER, sd.rel, 1);
       HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, *sd.g, sd.sb, sd.cb,
                                  acc, c->stream));
       span_end(c, sp);
@@ -721,7 +781,9 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     sa.P = P;
     sa.Q = 1;
     sa.accum = acc;
-    if (const char* e = getenv("HMJ_DEBUG_ABLATE")) sa.debug = (u32)atoi(e);
+#ifdef HMJ_DEV
+    sa.debug = c->dev_ablate;
+#endif
     int sp = span_begin(c, K_PROBE_COUNT, -1);
     if (first || extra) {
       sa.extra = (extra ? 1u : 0u) | (first ? 2u : 0u);
@@ -749,6 +811,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   const bool reuse_exact = c->prep.valid && !c->prep.slab && c->prep.ptr == R && c->prep.n == nb &&
                            c->prep.low == low && c->prep.B == B;
   c->prep.valid = false;  // one-shot; rbuf / r_off are about to be (re)written unless reused
+  c->timing.path |= HMJ_PATH_EXACT | (reuse_exact ? HMJ_PATH_PREPARED : 0u);
   int s;
   if (reuse_exact) {
     Rp = c->prep.Rp;
@@ -793,20 +856,41 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // modes that enumerate every pair (materialise, checksums) and are not first-wins also cut partitions with
     // thousands of copies of a key on the build side: the cross product of a hot key is then written by many
     // workgroups (each build slice meets every probe slice of the partition)
-    const u32 build_thr = enumerating ? 6144u : 0u, build_slice = 4096u;
+    const u32 build_slice = 4096u;
     // virtual partitions: at most P + np / slice from probe slices; build slices multiply a partition's count,
     // bounded by giving the table room for 8x that (a larger total makes the split be ignored)
+    u32 build_thr = enumerating ? 6144u : 0u;
     u32 cap_v = (P + np / slice + 1) * (enumerating ? 8u : 1u);
     if (enumerating && cap_v < (1u << 18)) cap_v = 1u << 18;  // room for the 256-row slices of build-heavy partitions
-    if ((rc = ensure_dev(c, c->vparts, ((size_t)cap_v * 4 + P + 3) * 4)) != HMJ_OK) return rc;
-    u32* vp = (u32*)c->vparts.p;
-    u32 *d_vstart = vp, *d_nv = vp + P + 1, *d_rb = vp + P + 2, *d_re = d_rb + cap_v, *d_sb = d_re + cap_v,
-        *d_se = d_sb + cap_v;
-    HIP_TRY(hmj::launch_split_parts((const u32*)c->r_off.p, (const u32*)c->s_off.p, P, thr, slice, build_thr, build_slice,
-                                    cap_v, d_vstart, d_rb, d_re, d_sb, d_se, d_nv, c->stream));
     u32* hnv = (u32*)c->h_accum.p;
-    HIP_TRY(hipMemcpyAsync(hnv, d_nv, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    u32 *d_vstart = nullptr, *d_rb = nullptr, *d_re = nullptr, *d_sb = nullptr, *d_se = nullptr;
+    // The count step reports how many virtual partitions the split needs.  If the table is too small it is
+    // grown (up to 2^24 entries) and the split repeated; a split that would still not fit falls back to
+    // probe-only slices (bounded by P + np / slice) instead of being dropped -- one workgroup enumerating a
+    // whole hot cross product is a cliff of minutes.
+    for (int attempt = 0; attempt < 4; attempt++) {
+      if ((rc = ensure_dev(c, c->vparts, ((size_t)cap_v * 4 + P + 3) * 4)) != HMJ_OK) return rc;
+      u32* vp = (u32*)c->vparts.p;
+      d_vstart = vp;
+      u32* d_nv = vp + P + 1;
+      d_rb = vp + P + 2;
+      d_re = d_rb + cap_v;
+      d_sb = d_re + cap_v;
+      d_se = d_sb + cap_v;
+      HIP_TRY(hmj::launch_split_parts((const u32*)c->r_off.p, (const u32*)c->s_off.p, P, thr, slice, build_thr, build_slice,
+                                      cap_v, d_vstart, d_rb, d_re, d_sb, d_se, d_nv, c->stream));
+      HIP_TRY(hipMemcpyAsync(hnv, d_nv, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (*hnv <= cap_v) break;
+      c->timing.n_split_retries++;
+      if (attempt < 2 && cap_v < (1u << 24)) {
+        u64 want = (u64)cap_v * 8;  // per-partition counts are clamped at cap_v + 1: the total is a lower bound
+        cap_v = want > (1ull << 24) ? (1u << 24) : (u32)want;
+      } else {
+        build_thr = 0;  // probe slices only
+        cap_v = P + np / slice + 1;
+      }
+    }
     if (*hnv > P && *hnv <= cap_v) {
       Pi = *hnv;
       v_start = d_vstart;
@@ -821,6 +905,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     }
   }
   const bool split = Pi != P;
+  if (split) c->timing.path |= HMJ_PATH_SPLIT;
+  c->timing.n_probe_items = split ? Pi : (u32)items;
 
   if (fast_write && !split) {  // (with split partitions a partition's rows are not in one piece: general passes)
     hmj::ProbeArgs wa;
@@ -853,7 +939,9 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     a.pfx_shift = (u32)(64 - prefix);
     a.pfx_val = pfx_ref >> (64 - prefix);
   }
-  if (const char* e = getenv("HMJ_DEBUG_ABLATE")) a.debug = (u32)atoi(e);
+#ifdef HMJ_DEV
+  a.debug = c->dev_ablate;
+#endif
   a.part_count = (u64*)c->part_count.p;
   a.part_out_off = (const u64*)c->part_out_off.p;
   const int grid = hmj::probe_default_grid(c->num_cus);
@@ -1007,6 +1095,9 @@ int hmj_create(hmj_ctx** out, int device_id) {
     if (l >= 16 && l <= 31) c->slab_min_rows = 1u << l;
   }
   if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
+#ifdef HMJ_DEV
+  if (const char* e = getenv("HMJ_DEBUG_ABLATE")) c->dev_ablate = (u32)atoi(e);
+#endif
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1152,6 +1243,7 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
   if (!c) return HMJ_E_ARG;
   if (n_build > 0xFFFFFFFFull || n_probe > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "too many rows");
   HIP_TRY(hipSetDevice(c->device));
+  c->prep.valid = false;  // "any other call discards the prepared state" (hmj.h)
   int B, passes, pass_bits[4], rc;
   plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
   const size_t P = (size_t)1 << B;
@@ -1298,6 +1390,16 @@ void hmj_rows_free(hmj_rows* r) {
   pool_give(r->rval);
   pool_give(r->sval);
   delete r;
+}
+
+uint64_t hmj_host_pool_trim(uint64_t keep_bytes) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  return (uint64_t)pool_trim_locked((size_t)keep_bytes);
+}
+
+uint64_t hmj_host_pool_bytes(void) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  return (uint64_t)g_pool_bytes;
 }
 
 int hmj_set_host_threads(hmj_ctx* c, int n) {

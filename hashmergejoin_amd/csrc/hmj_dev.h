@@ -16,6 +16,9 @@ struct __attribute__((aligned(16))) Tup {
 };
 
 constexpr int kWave = 64;
+#ifndef HMJ_SCAN_DPP
+#define HMJ_SCAN_DPP 1
+#endif
 
 // Streaming access to rows that are read or written exactly once per kernel: nontemporal policy, so
 // the line does not linger in L2 / Infinity Cache (a plain copy of 4 GiB runs 5.4 -> 6.0 TB/s with it).
@@ -68,6 +71,7 @@ constexpr int PB_PLAN_SLACK = 256;     // planner: tolerated excess of that aver
 enum { ACC_N = 0, ACC_SUM_R, ACC_SUM_S, ACC_XOR, ACC_MIX, ACC_SUM_P, ACC_ERR, ACC_PAD };
 constexpr u64 ERR_SLAB = 2;    // slab path: a slab overflowed or a partition does not fit -> exact path
 constexpr u64 ERR_ORDER_DEFER = 16;  // ordered epilogue left a very large segment unsorted: the host sorts the result
+constexpr u64 ERR_ORDER_FAIL = 32;   // ordered epilogue: a segment too large to sort in place AND to defer (result > 2^32-1 rows)
 constexpr u64 ERR_FASTPATH = 8;  // unique-key write mode met duplicate build keys / an oversized partition
 constexpr u64 ERR_PREFIX = 4;  // a key does not carry the sampled common prefix (ordered mode re-plans)
 
@@ -96,13 +100,26 @@ __device__ __forceinline__ u32 popc_below(u64 m) {
   return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
-__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {
+// Inclusive wave64 scan on the DPP path (VALU speed; __shfl_up goes through ds_bpermute: six LDS round trips).
+// row_shr:1,2,4,8 scan the four 16-lane rows, row_bcast:15 / :31 carry the row totals on (gfx9 family).
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int /*lane*/) {
+#if HMJ_SCAN_DPP
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+#else
+  const int lane = lane_id();
 #pragma unroll
   for (int o = 1; o < kWave; o <<= 1) {
     u32 t = __shfl_up(v, o, kWave);
     if (lane >= o) v += t;
   }
   return v;
+#endif
 }
 
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
@@ -153,7 +170,8 @@ __device__ __forceinline__ void block_accumulate(u64* red, u64* accum, const u64
 
 // Block-wide exclusive scan of one u32 per thread.  scratch: >= THREADS/64 + 1 words of LDS.
 // Returns the exclusive prefix; *total receives the block sum.  Contains two barriers.
-template <int THREADS>
+// TRAILING_BARRIER = false: the caller guarantees a workgroup barrier before `scratch` is written again.
+template <int THREADS, bool TRAILING_BARRIER = true>
 __device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* scratch, u32* total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   constexpr int NW = THREADS / kWave;
@@ -167,7 +185,7 @@ __device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* scratch, u32* tot
     if (k < w) pre += s;
     tot += s;
   }
-  lds_barrier();
+  if (TRAILING_BARRIER) lds_barrier();
   *total = tot;
   return pre + incl - v;
 }

@@ -4,9 +4,28 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace hmj {
 typedef unsigned long long u64;
 typedef unsigned int u32;
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per-DEVICE function state, and one process may hold a
+// ctx per GPU (hmj.h): remember per device (bit = device id) which kernels already carry the attribute.
+struct SmemAttrOnce {
+  std::atomic<unsigned long long> devices{0};
+};
+inline hipError_t ensure_max_smem(SmemAttrOnce& once, const void* kernel, size_t bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (dev < 64 && (once.devices.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  if (dev < 64) once.devices.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 // radix.hip
 // variant: 0 = plain staged scatter (4096-row tile), 1 = write-combining scatter (WC_X / WC_Y)
@@ -60,7 +79,7 @@ struct ProbeArgs {
   u32 pfx_shift;           // ordered mode: verify (key >> pfx_shift) == pfx_val for every row (0 = off)
   u64 pfx_val;
   u32* matched;            // HMJ_FIRST_WINS + chunked build: one bit per probe row already paired
-  u32 debug;               // dev-only ablation bits (HMJ_DEBUG_ABLATE env): 1 = loads only, 2 = no probe walk
+  u32 debug;               // developer builds (-DHMJ_DEV) only: ablation bits, 1 = loads only, 2 = no probe walk
 };
 // mode: 0 = count/sums only, 1 = count + per-partition counts, 2 = write
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,

@@ -321,6 +321,13 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
 // are appended to `irregular` and joined afterwards by the generic kernel.
 // ---------------------------------------------------------------------------------------------
 constexpr int FP_ROWS = 5;  // rows per thread per side
+// Ablation switches of the pipelined kernel (1 = loads only, 2 = no chain walk) exist in developer builds
+// only (-DHMJ_DEV, read from HMJ_DEBUG_ABLATE); the release library compiles them out.
+#ifdef HMJ_DEV
+#define HMJ_ABLATE(bit) ((a.debug & (bit)) != 0u)
+#else
+#define HMJ_ABLATE(bit) false
+#endif
 #ifndef BIG_LOG_NB
 #define BIG_LOG_NB 13
 #endif
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
         lds_barrier();
       }
       const u32 tag = epoch << 16;
-      if (!(a.debug & 1u)) {
+      if (!HMJ_ABLATE(1u)) {
         // build: the five exchanges are independent -> issue them together, then link
         u32 old[FP_ROWS];
 #pragma unroll
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
           const u32 i = k * THREADS + tid;
           if (i < nb) sm.next[i] = ((old[k] >> 16) == epoch) ? (u16)old[k] : (u16)NIL;
         }
-      } else {  // dev-only ablation (HMJ_DEBUG_ABLATE=1): stream the rows, no LDS work
+      } else {  // developer builds only (HMJ_ABLATE): stream the rows, no LDS work
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) acc_r += br[k].key;
       }
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       }
       lds_barrier();                                          // table complete
       const u64 n_before = acc_n;
-      if (!(a.debug & 1u)) {
+      if (!HMJ_ABLATE(1u)) {
         // probe: walk the five chains in lockstep so their LDS latencies overlap
         u32 cur[FP_ROWS];
         u32 cnt[FP_ROWS], first[FP_ROWS];  // OUT == 1
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
             cur[k] = ((hv >> 16) == epoch) ? (hv & 0xFFFFu) : NIL;
           }
         }
-        for (; !(a.debug & 2u);) {
+        for (; !HMJ_ABLATE(2u);) {
           bool any = false;
 #pragma unroll
           for (int k = 0; k < FP_ROWS; k++) any |= (cur[k] != NIL);
@@ -1035,6 +1042,8 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
         if (tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_ORDER_DEFER);
       } else if (n >= 2 && n <= 0x7FFFFFFFull) {
         order_network_global(bkey + ob, brval + ob, bsval + ob, (u32)n, tid);
+      } else if (n >= 2) {  // cannot be sorted here nor deferred (row indices of the global sorts are 32-bit)
+        if (tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_ORDER_FAIL);
       }
     }
   }
@@ -1138,14 +1147,8 @@ hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool FIRST, bool EXTRA>
 static hipError_t launch_probe_t(const ProbeArgs& a, int grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(probe_kernel<MODE, FIRST, EXTRA>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ProbeSmem));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_kernel<MODE, FIRST, EXTRA>), (size_t)sizeof(ProbeSmem)); e != hipSuccess) return e;
   hipLaunchKernelGGL((probe_kernel<MODE, FIRST, EXTRA>), dim3(grid), dim3(PB_THREADS),
                      sizeof(ProbeSmem), st, a);
   return hipGetLastError();
@@ -1155,14 +1158,8 @@ template <int THREADS, int LOG_NB, bool PCOUNT, bool SLAB = false, int OUT = 0>
 static hipError_t launch_fast_t(const ProbeArgs& a, u32* irregular, u32* n_irregular, int grid,
                                 hipStream_t st) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB, OUT>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB, OUT>), (size_t)sizeof(Smem)); e != hipSuccess) return e;
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((probe_count_fast_kernel<THREADS, LOG_NB, PCOUNT, SLAB, OUT>), dim3(grid), dim3(THREADS),
@@ -1242,13 +1239,8 @@ template <bool MANY>
 static hipError_t launch_order_t(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64,
                                  u32 P, u32 Q, int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey,
                                  u64* brval, u64* bsval, u64* accum, u32 defer_rows, int grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(order_kernel<MANY>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OrderSmem));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(order_kernel<MANY>), (size_t)sizeof(OrderSmem)); e != hipSuccess) return e;
   if ((u32)grid > P) grid = (int)P;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((order_kernel<MANY>), dim3(grid), dim3(OS_THREADS), sizeof(OrderSmem), st, part_out_off, vstart,

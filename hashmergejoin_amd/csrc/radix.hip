@@ -8,6 +8,8 @@
 // The result of a pass is therefore bit-identical to oracle orc_stable_partition() for any
 // worker count.  HBM-bound integer work: coalesced dwordx4 loads, per-wave ballot ranking,
 // LDS-staged tiles so each digit's rows leave as one contiguous run (write-combined scatter).
+#include <cstdlib>
+
 #include "hmj_dev.h"
 #include "hmj_launch.h"
 
@@ -271,6 +273,48 @@ __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
 constexpr int WC_ITEMS = 4;
 constexpr int WC_LINE = 8;  // rows per 128-byte line
 
+// Developer builds (-DHMJ_STAMPS): shader-clock stamps around the phases of wc_tile, summed over all waves of
+// a launch into g_wc_stamps[phase] (read and reset by hmj_dev_stamps, api.hip).  Phases: 0 wait for the tile's
+// rows, 1 rank, 2 barrier, 3 plan, 4 barrier, 5 stage + prefetch issue, 6 barrier, 7 copy out + keep, 8 barrier,
+// 9 carry + clear, 10 barrier, 11 = tiles.  The release library compiles none of this.
+#ifndef HMJ_WC_PLAN1
+#define HMJ_WC_PLAN1 0   // 1: one wave plans all digits with wave scans -- measured 40 % SLOWER (the other seven waves
+                         // wait 6000 cycles at the next barrier); 0: one thread per digit + block scan
+#endif
+#ifndef HMJ_WC_NOBAR5
+#define HMJ_WC_NOBAR5 1  // 1: waves zero their own mask slab / counters, no barrier at the end of a tile
+#endif
+#ifdef HMJ_STAMPS
+__device__ unsigned long long g_wc_stamps[32];  // [0..15] pass A / exact scatter, [16..31] slab pass B
+struct WcStamps {
+  u32 acc[14];
+  u64 last;
+  int base;
+  __device__ __forceinline__ void begin() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    const u64 now = __builtin_amdgcn_s_memtime();
+    acc[i] += (u32)(now - last);
+    last = now;
+  }
+  __device__ __forceinline__ void flush() {
+    if ((threadIdx.x & 63) == 0)
+      for (int i = 0; i < 14; i++) atomicAdd(&g_wc_stamps[base + i], (unsigned long long)acc[i]);
+  }
+};
+#define WC_STAMP_ARG , WcStamps& stamps
+#define WC_STAMP_PASS , stamps
+#define WC_MARK(i) stamps.mark(i)
+#define WC_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define WC_STAMP_ARG
+#define WC_STAMP_PASS
+#define WC_MARK(i)
+#define WC_VMWAIT()
+#endif
+
 template <int THREADS, int MAXD>
 struct WcSmem {
   static constexpr int TILE = THREADS * WC_ITEMS;
@@ -305,7 +349,7 @@ struct WcSmem {
 template <int THREADS, int MAXD, bool HI, bool ALLVALID, bool LIMIT, typename Prefetch>
 __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_ITEMS], u32 tile_n,
                                         Tup* __restrict__ out, int shift, u32 mask, u32 D,
-                                        Prefetch&& prefetch, const u32* limit, bool* ovf) {
+                                        Prefetch&& prefetch, const u32* limit, bool* ovf WC_STAMP_ARG) {
   typedef WcSmem<THREADS, MAXD> Smem;
   constexpr int WAVES = Smem::WAVES;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -317,6 +361,12 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
   // relaxed workgroup-scope atomics: plain LDS instructions, never cached in registers, and --
   // unlike volatile accesses -- no s_waitcnt vmcnt(0) around them (the prefetch stays in flight)
   u32 dr[WC_ITEMS];
+#ifdef HMJ_STAMPS
+  stamps.last = __builtin_amdgcn_s_memtime();
+  WC_VMWAIT();
+  WC_MARK(0);
+  stamps.acc[11]++;
+#endif
 #pragma unroll
   for (int r = 0; r < WC_ITEMS; r++) {
     u32 d = 0, rank = 0;
@@ -335,9 +385,68 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
     }
     dr[r] = (d << 16) | rank;
   }
+  WC_MARK(1);
   lds_barrier();
+  WC_MARK(2);
 
   // per digit: prefix over waves, tile offsets, this tile's flush plan and its 128-byte lines
+#if HMJ_WC_PLAN1
+  // ONE wave plans all digits (lane l: digits l, l + 64, ...): the scan over digits is then a wave scan per
+  // 64 digits with a running carry -- no block scan, no barriers inside the phase (it took 12 % of a tile with
+  // half the threads idle and two extra barriers; the other waves go straight to the next barrier).
+  if (w == 0) {
+    constexpr int DPL = MAXD / kWave;  // digits per lane
+    u32 cnt[DPL], nl[DPL], pd[DPL], cf[DPL], fl[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; j++) {
+      const u32 d = (u32)j * kWave + lane;
+      cnt[j] = nl[j] = pd[j] = cf[j] = fl[j] = 0;
+      if (d < D) {
+        u32 c[WAVES];
+#pragma unroll
+        for (int k = 0; k < WAVES; k++) c[k] = sm.wcnt[k][d];
+        u32 run = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; k++) {
+          sm.wcnt[k][d] = (u16)run;
+          run += c[k];
+        }
+        cnt[j] = run;
+        pd[j] = sm.pend[d];
+        cf[j] = sm.cflush[d];
+        u32 avail = pd[j] + run;
+        if (LIMIT && cf[j] + avail > limit[d]) {  // slab full: give up on this digit (and the run)
+          *ovf = true;
+          avail = 0;
+          pd[j] = 0;
+        }
+        const u32 tail = (cf[j] + avail) & (WC_LINE - 1);  // rows past the last whole line
+        fl[j] = (tail >= avail) ? 0u : avail - tail;
+        nl[j] = fl[j] ? (((cf[j] & (WC_LINE - 1)) + fl[j] + WC_LINE - 1) >> 3) : 0u;
+        sm.pend[d] = avail - fl[j];
+        sm.cflush[d] = cf[j] + fl[j];
+      }
+    }
+    u32 running = 0;  // lines << 16 | rows of the digits scanned so far
+#pragma unroll
+    for (int j = 0; j < DPL; j++) {
+      const u32 d = (u32)j * kWave + lane;
+      const u32 v = (nl[j] << 16) | cnt[j];
+      const u32 incl = wave_incl_scan_u32(v, lane);
+      const u32 sc = running + incl - v;
+      running += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+      if (d < D) {
+        const u32 loff = sc >> 16;
+        sm.tile_off[d] = sc & 0xFFFFu;
+        sm.cf_tile[d] = cf[j];
+        sm.plan[d] = (fl[j] << 8) | pd[j];
+        sm.line_off[d] = loff;
+        for (u32 l = 0; l < nl[j]; l++) sm.line_tab[loff + l] = (u16)d;
+      }
+    }
+    if (lane == 0) sm.total_lines = running >> 16;
+  }
+#else
   {
     u32 cnt = 0, nl = 0, pd = 0, cf = 0, fl = 0;
     if ((u32)tid < D) {
@@ -362,7 +471,8 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
       sm.cflush[tid] = cf + fl;
     }
     u32 tot;
-    const u32 sc = block_excl_scan_u32<THREADS>((nl << 16) | cnt, sm.scratch, &tot);
+    // (no trailing barrier: scratch is next written a whole tile -- four barriers -- later)
+    const u32 sc = block_excl_scan_u32<THREADS, false>((nl << 16) | cnt, sm.scratch, &tot);
     if ((u32)tid < D) {
       const u32 loff = sc >> 16;
       sm.tile_off[tid] = sc & 0xFFFFu;
@@ -373,7 +483,10 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
     }
     if (tid == 0) sm.total_lines = tot >> 16;
   }
+#endif
+  WC_MARK(3);
   lds_barrier();
+  WC_MARK(4);
 
 #pragma unroll
   for (int r = 0; r < WC_ITEMS; r++) {
@@ -382,8 +495,11 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
       sm.stage[sm.tile_off[d] + sm.wcnt[w][d] + (dr[r] & 0xFFFFu)] = t[r];
     }
   }
+  WC_MARK(5);
   prefetch();  // the rows now live in LDS: start fetching the next tile while this one leaves
+  WC_MARK(12);
   lds_barrier();
+  WC_MARK(6);
 
   // copy out WHOLE LINES: 8 consecutive lanes own one 128-byte line (carried rows first, then
   // this tile's rows), so every line leaves in a single store instruction
@@ -415,7 +531,9 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
     keep_k[q] = kv.key;
     keep_v[q] = kv.val;
   }
+  WC_MARK(7);
   lds_barrier();
+  WC_MARK(8);
 #pragma unroll
   for (int q = 0; q < WC_ITEMS; q++) {
     const u32 s = q * THREADS + tid;
@@ -426,6 +544,24 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
       sm.carry[s >> 3][s & (WC_LINE - 1)] = kv;
     }
   }
+#if HMJ_WC_NOBAR5
+  // every wave hands its OWN lane-mask slab (aliased on the tile buffer) and its own digit counters back as
+  // zeros: the next tile's ranking touches only those, so no barrier is needed between here and there.
+  // (The carry rows written above are next read after three more barriers, or behind wc_flush_carry's.)
+  {
+    constexpr int ZR = MAXD * 8 / 16;  // tile rows aliased by one wave's lane masks
+    Tup z;
+    z.key = 0;
+    z.val = 0;
+#pragma unroll
+    for (int r = 0; r < ZR / kWave; r++) sm.stage[w * ZR + r * kWave + lane] = z;
+    u32* wz = reinterpret_cast<u32*>(&sm.wcnt[w][0]);
+#pragma unroll
+    for (int r = 0; r < MAXD / 2 / kWave; r++) wz[r * kWave + lane] = 0;
+  }
+  WC_MARK(9);
+  WC_MARK(10);
+#else
 #pragma unroll
   for (int r = 0; r < WC_ITEMS; r++) {
     if (r * THREADS < Smem::ZROWS) {  // hand the slab back to the lane masks as zeros
@@ -436,13 +572,17 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
     }
   }
   for (int i = tid; i < WAVES * MAXD / 2; i += THREADS) reinterpret_cast<u32*>(&sm.wcnt[0][0])[i] = 0;
+  WC_MARK(9);
   lds_barrier();
+  WC_MARK(10);
+#endif
 }
 
 // worker done: whatever still waits in the carry buffers ends this worker's digit segments
 template <int THREADS, int MAXD>
 __device__ __forceinline__ void wc_flush_carry(WcSmem<THREADS, MAXD>& sm, Tup* __restrict__ out, u32 D) {
   const int tid = threadIdx.x;
+  lds_barrier();  // the last tile's carry rows are complete
 #pragma unroll
   for (int q = 0; q < WC_ITEMS; q++) {
     const u32 s = q * THREADS + tid, d = s >> 3, k = s & (WC_LINE - 1);
@@ -504,6 +644,9 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     if (FULL || begin + wbase + r * 64 < end) t[r] = load_stream(&in[begin + wbase + r * 64]);
 
   bool ovf = false;
+#ifdef HMJ_STAMPS
+  WcStamps stamps = {};
+#endif
   for (u64 tile = begin; tile < end; tile += TILE) {
     const u32 tile_n = FULL ? (u32)TILE : (u32)(end - tile);
     wc_tile<THREADS, MAXD, HI, FULL, false>(
@@ -515,9 +658,12 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
             for (int r = 0; r < WC_ITEMS; r++) t[r] = load_stream(&src[wbase + r * 64]);
           }
         },
-        nullptr, &ovf);
+        nullptr, &ovf WC_STAMP_PASS);
   }
   wc_flush_carry(sm, out, D);
+#ifdef HMJ_STAMPS
+  stamps.flush();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,6 +703,9 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   if (end > n) end = n;
   const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
   bool ovf = false;
+#ifdef HMJ_STAMPS
+  WcStamps stamps = {};
+#endif
   if (begin < end) {
     Tup t[WC_ITEMS];
     {
@@ -583,14 +732,23 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
               }
             }
           },
-          limit, &ovf);
+          limit, &ovf WC_STAMP_PASS);
     }
     wc_flush_carry(sm, slab, D);
   }
   if ((u32)tid < D) cnt_out[(u32)tid * WA + worker] = sm.cflush[tid] + sm.pend[tid] - ((u32)tid * WA + worker) * CA;
   if (ovf) atomicOr(&accum[ACC_ERR], ERR_SLAB);
+#ifdef HMJ_STAMPS
+  stamps.flush();
+#endif
 }
 
+#ifndef HMJ_B_ADDR
+#define HMJ_B_ADDR 1  // 1: per-round slab lookup, planned one tile ahead; 0: per-row walk (round 1)
+#endif
+#ifndef HMJ_B_NT
+#define HMJ_B_NT 0    // nontemporal loads of the A-slab rows
+#endif
 constexpr int SLAB_KB = 4;        // pass-B workers per bucket == pieces per final partition
 constexpr int SLAB_MAXSEG = 512;  // A-slabs one pass-B worker gathers (WA / KB <= 512)
 
@@ -625,12 +783,123 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   }
   __syncthreads();
   const u32 total = pre[ns];
+#if !HMJ_B_ADDR
   const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
+#endif
   const Tup* __restrict__ bucket = slab_a + (u64)(dA * WA + w0) * CA;  // A-slab j of this worker: + j*CA
   bool ovf = false;
+#ifdef HMJ_STAMPS
+  WcStamps stamps = {};
+  stamps.base = 16;
+#endif
   if (total) {
-    u32 seg = 0;  // first A-slab overlapping the tile being loaded (same value in every thread)
     Tup t[WC_ITEMS];
+#if HMJ_B_ADDR
+    // Row q of the worker's input (the concatenation of its A-slabs) lives in slab s = the last one with
+    // pre[s] <= q, at bucket[s * CA + (q - pre[s])].  A wave reads 4 ROUNDS of 64 consecutive rows per tile;
+    // lane r < 4 of every wave looks up round r's first slab by binary search ONE TILE AHEAD (nine dependent
+    // LDS reads that overlap the copy-out of the current tile), together with the next three slab starts.
+    // The 64 rows of a round then need no search: slabs average hundreds of rows, so a round crosses at most
+    // two slab starts (else: the per-row walk below), and a lane finds its slab with two compares.
+    u32 d_s0 = 0, d_b0 = 0, d_b1 = 0, d_b2 = 0, d_b3 = 0;  // descriptors of the tile to load next (lanes 0..3)
+    const float slabs_per_row = (float)ns / (float)total;
+    auto plan = [&](u32 tile_begin) {
+      u32 q0 = tile_begin + (u32)w * (WC_ITEMS * 64) + (u32)(lane & 3) * 64;
+      q0 = q0 < total ? q0 : total - 1;
+      // evenly filled slabs: slab(q0) ~ q0 * ns / total, off by a slab or two (the prefix sums wander by
+      // sqrt(#slabs) * sigma).  Look at the eight slab starts around the guess -- independent LDS reads, one
+      // latency -- and fall back to the binary search (nine dependent reads) when they do not bracket q0.
+      u32 g = (u32)((float)q0 * slabs_per_row);
+      g = g < ns ? g : ns - 1;
+      u32 lo = g >= 3 ? g - 3 : 0;
+      u32 pw[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) pw[i] = pre[lo + i < ns ? lo + i : ns];
+      u32 j = 0;
+#pragma unroll
+      for (int i = 1; i < 8; i++) j += pw[i] <= q0 ? 1u : 0u;
+      const bool bracketed = pw[0] <= q0 && pw[7] > q0;  // (pre[ns] = total > q0)
+      lo += j;
+      if (__any(!bracketed)) {
+        u32 hi = ns;  // pre[lo] <= q0, and hi == ns or pre[hi] > q0
+        lo = 0;
+#pragma unroll
+        for (int it = 0; it < 9; it++) {  // ns <= SLAB_MAXSEG = 512
+          const u32 mid = (lo + hi) >> 1;
+          const bool le = pre[mid] <= q0, act = hi - lo > 1;
+          lo = (act && le) ? mid : lo;
+          hi = (act && !le) ? mid : hi;
+        }
+      }
+      d_s0 = lo;
+      d_b0 = pre[lo];
+      d_b1 = pre[lo + 1 < ns ? lo + 1 : ns];
+      d_b2 = pre[lo + 2 < ns ? lo + 2 : ns];
+      d_b3 = pre[lo + 3 < ns ? lo + 3 : ns];  // (pre[ns] = total: never <= a row index)
+    };
+    auto issue = [&](u32 tile_begin) {
+      u64 off[WC_ITEMS];
+      const u32 wq0 = tile_begin + (u32)w * (WC_ITEMS * 64);  // the wave's first row of the tile
+      u32 wlast = wq0 + WC_ITEMS * 64 - 1;
+      wlast = wlast < total ? wlast : total - 1;
+      const u32 s00 = (u32)__builtin_amdgcn_readlane((int)d_s0, 0), b00 = (u32)__builtin_amdgcn_readlane((int)d_b0, 0),
+                b10 = (u32)__builtin_amdgcn_readlane((int)d_b1, 0);
+      if (b10 > wlast) {  // wave-uniform, the common case: all 256 rows of the wave lie in one slab
+        const u64 o0 = (u64)s00 * CA;
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          u32 q = wq0 + lane + r * 64;
+          q = q < total ? q : total - 1;
+          off[r] = o0 + (q - b00);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          const u32 s0 = (u32)__builtin_amdgcn_readlane((int)d_s0, r), b0 = (u32)__builtin_amdgcn_readlane((int)d_b0, r),
+                    b1 = (u32)__builtin_amdgcn_readlane((int)d_b1, r), b2 = (u32)__builtin_amdgcn_readlane((int)d_b2, r),
+                    b3 = (u32)__builtin_amdgcn_readlane((int)d_b3, r);
+          u32 q = wq0 + lane + r * 64;
+          q = q < total ? q : total - 1;
+          u32 qlast = wq0 + r * 64 + 63;
+          qlast = qlast < total ? qlast : total - 1;
+          if (b3 > qlast) {  // wave-uniform: the round crosses at most the slab starts b1 and b2
+            const u32 j = (q >= b1 ? 1u : 0u) + (q >= b2 ? 1u : 0u);
+            const u32 base = j == 0 ? b0 : (j == 1 ? b1 : b2);
+            off[r] = (u64)(s0 + j) * CA + (q - base);
+          } else {  // tiny or empty slabs in a row: walk
+            u32 sx = s0;
+            while (sx + 1 < ns && pre[sx + 1] <= q) sx++;
+            off[r] = (u64)sx * CA + (q - pre[sx]);
+          }
+        }
+      }
+#ifdef HMJ_B_ALIGN_HACK  // timing experiment only (wrong rows): what would line-aligned wave loads cost?
+#pragma unroll
+      for (int r = 0; r < WC_ITEMS; r++) off[r] = (off[r] & ~63ull) | (u64)lane;
+#endif
+#pragma unroll
+      for (int r = 0; r < WC_ITEMS; r++) t[r] = HMJ_B_NT ? load_stream(&bucket[off[r]]) : bucket[off[r]];
+    };
+    plan(0);
+    issue(0);
+    if ((u32)TILE < total) plan(TILE);
+    for (u32 tile = 0; tile < total; tile += TILE) {
+      const u32 tile_n = (total - tile < (u32)TILE) ? total - tile : (u32)TILE;
+      wc_tile<THREADS, MAXD, HI, false, true>(
+          sm, t, tile_n, slab_b, shift, mask, D,
+          [&]() {
+            if (tile + TILE < total) {
+              issue(tile + TILE);
+#ifdef HMJ_STAMPS
+              stamps.mark(13);
+#endif
+              if (tile + 2 * TILE < total) plan(tile + 2 * TILE);
+            }
+          },
+          limit, &ovf WC_STAMP_PASS);
+    }
+#else
+    u32 seg = 0;  // first A-slab overlapping the tile being loaded (same value in every thread)
     auto load = [&](u32 tile_begin) {
       const u32 tn = (total - tile_begin < (u32)TILE) ? total - tile_begin : (u32)TILE;
       while (seg + 1 < ns && pre[seg + 1] <= tile_begin) seg++;
@@ -644,7 +913,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
         off[r] = (u64)s * CA + (q - pre[s]);
       }
 #pragma unroll
-      for (int r = 0; r < WC_ITEMS; r++) t[r] = bucket[off[r]];
+      for (int r = 0; r < WC_ITEMS; r++) t[r] = HMJ_B_NT ? load_stream(&bucket[off[r]]) : bucket[off[r]];
     };
     load(0);
     for (u32 tile = 0; tile < total; tile += TILE) {
@@ -654,10 +923,14 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
           [&]() {
             if (tile + TILE < total) load(tile + TILE);
           },
-          limit, &ovf);
+          limit, &ovf WC_STAMP_PASS);
     }
+#endif
     wc_flush_carry(sm, slab_b, D);
   }
+#ifdef HMJ_STAMPS
+  stamps.flush();
+#endif
   if ((u32)tid < D) {
     const u32 pid = (((u32)tid << bits_a) | dA) * SLAB_KB + k;
     cnt_b[pid] = sm.cflush[tid] + sm.pend[tid] - pid * CB;
@@ -748,13 +1021,8 @@ static hipError_t launch_slab_a_t(const void* in, u32 n, int shift, int bits, u3
                                   u32 WA, u32* cnt, u64* accum, hipStream_t st) {
   typedef WcSmem<512, 256> Smem;
   const size_t smem = sizeof(Smem) + 256 * sizeof(u32);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(radix_slab_a_kernel<512, 256, HI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_a_kernel<512, 256, HI>), (size_t)smem); e != hipSuccess) return e;
   hipLaunchKernelGGL((radix_slab_a_kernel<512, 256, HI>), dim3(WA), dim3(512), smem, st,
                      static_cast<const Tup*>(in), n, shift, bits, rpw, static_cast<Tup*>(slab), CA, WA, cnt,
                      accum);
@@ -766,13 +1034,8 @@ static hipError_t launch_slab_b_t(const void* slab_a, const u32* cnt_a, u32 CA, 
                                   int bits, void* slab_b, u32 CB, u32* cnt_b, u64* accum, hipStream_t st) {
   typedef WcSmem<512, 256> Smem;
   const size_t smem = sizeof(Smem) + (256 + SLAB_MAXSEG + 1) * sizeof(u32);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI>), (size_t)smem); e != hipSuccess) return e;
   hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI>), dim3((1u << bits_a) * SLAB_KB), dim3(512), smem, st,
                      static_cast<const Tup*>(slab_a), cnt_a, CA, WA, bits_a, shift, bits,
                      static_cast<Tup*>(slab_b), CB, cnt_b, accum);
@@ -788,7 +1051,11 @@ static u32 slab_cap(double mean) {
 bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g) {
   const u32 tile = 2048;
   u64 tiles = ((u64)n + tile - 1) / tile;
-  u64 tpw = (tiles + 2047) / 2048;
+  u64 max_workers = 2048;
+#ifdef HMJ_DEV
+  if (const char* e = getenv("HMJ_SLAB_WORKERS")) max_workers = (u64)atoi(e) > 0 ? (u64)atoi(e) : max_workers;
+#endif
+  u64 tpw = (tiles + max_workers - 1) / max_workers;
   if (tpw == 0) tpw = 1;
   g->WA = (u32)((tiles + tpw - 1) / tpw);
   g->rpw = (u32)(tpw * tile);
@@ -871,14 +1138,8 @@ static hipError_t launch_radix_scatter_t(const void* in, void* out, u32 n, u32 n
                                          int bits, u32 rows_per_block, u32 worker_base, u32 grid,
                                          const u32* hist_scanned, const u32* totals, u32 nblk,
                                          u64* offsets_out, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(radix_scatter_kernel<HI, FULL>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterSmem));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_scatter_kernel<HI, FULL>), (size_t)sizeof(ScatterSmem)); e != hipSuccess) return e;
   hipLaunchKernelGGL((radix_scatter_kernel<HI, FULL>), dim3(grid), dim3(RP_THREADS),
                      sizeof(ScatterSmem), st, static_cast<const Tup*>(in), static_cast<Tup*>(out), n,
                      n_full, shift, bits, rows_per_block, worker_base, hist_scanned, totals, nblk,
@@ -891,14 +1152,8 @@ static hipError_t launch_wc_t(const void* in, void* out, u32 n, u32 n_full, int 
                               u32 rows_per_block, u32 worker_base, u32 grid, const u32* hist_scanned,
                               const u32* totals, u32 nblk, u64* offsets_out, hipStream_t st) {
   typedef WcSmem<THREADS, MAXD> Smem;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(radix_scatter_wc_kernel<THREADS, MAXD, HI, FULL>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_scatter_wc_kernel<THREADS, MAXD, HI, FULL>), (size_t)sizeof(Smem)); e != hipSuccess) return e;
   hipLaunchKernelGGL((radix_scatter_wc_kernel<THREADS, MAXD, HI, FULL>), dim3(grid), dim3(THREADS),
                      sizeof(Smem), st, static_cast<const Tup*>(in), static_cast<Tup*>(out), n, n_full,
                      shift, bits, rows_per_block, worker_base, hist_scanned, totals, nblk, offsets_out);
@@ -970,3 +1225,16 @@ hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off
 }
 
 }  // namespace hmj
+
+#ifdef HMJ_STAMPS
+// developer builds only: read (and clear) the phase stamps summed by the write-combining scatter kernels
+extern "C" int hmj_dev_stamps(unsigned long long out[32], int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -4;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hmj::g_wc_stamps), 32 * sizeof(unsigned long long)) != hipSuccess) return -4;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hmj::g_wc_stamps), z, sizeof(z)) != hipSuccess) return -4;
+  }
+  return 0;
+}
+#endif

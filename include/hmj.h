@@ -39,7 +39,8 @@ typedef struct hmj_ctx hmj_ctx;
 #define HMJ_E_NODEV (-2)       /* no usable HIP device */
 #define HMJ_E_OOM (-3)         /* device or host allocation failed */
 #define HMJ_E_HIP (-4)         /* HIP runtime error, see hmj_last_error() */
-#define HMJ_E_UNSUPPORTED (-5) /* reserved: flag combination not supported for this input      */
+#define HMJ_E_UNSUPPORTED (-5) /* the flags cannot be honoured for this input (e.g. HMJ_ORDERED with a */
+                               /* single partition's result beyond 2^31-1 rows)                      */
 
 /* flags for hmj_join_* */
 #define HMJ_MATERIALIZE 0x01u /* produce the (key, rval, sval) columns; else count/sums only --   */
@@ -83,12 +84,30 @@ typedef struct {
   int radix_bits;                 /* total partition bits B (2^B partitions)                    */
   int radix_passes;               /* LSD passes per relation                                    */
   int n_scatter_launches;         /* scatter kernel launches in this join                       */
-  int reserved;
+  int n_split_retries;            /* skewed joins: times the virtual-partition table was regrown        */
   uint64_t bytes_scatter;         /* algorithmic bytes of all scatter launches (32 B/tuple)     */
   uint64_t bytes_hist;            /* 16 B/tuple per pass                                        */
   uint64_t bytes_probe_count;     /* 16*(n_build + n_probe)                                     */
   uint64_t bytes_probe_write;     /* 16*(n_build + n_probe) + 24*n_matches                      */
+  /* which code paths the last join took -- filled with or without profiling; the tests assert on these
+   * instead of on wall-clock budgets                                                                */
+  uint32_t path;                  /* HMJ_PATH_* bits                                            */
+  int32_t key_prefix_bits;        /* top key bits skipped as shared by all rows (sampled or set)*/
+  int32_t key_window_low;         /* lowest key bit of the B-bit partition window               */
+  uint32_t n_probe_items;         /* probe work items: (virtual) partitions x probe slices      */
+  float ms_scatter_pass[2];       /* ms_scatter split: [0] first radix pass of a relation (slab A),
+                                     [1] later passes (slab B); both relations                  */
 } hmj_timing;
+#define HMJ_PATH_SLAB 0x001u           /* histogram-free slab partitioning                                */
+#define HMJ_PATH_EXACT 0x002u          /* histogram + scan + scatter passes                               */
+#define HMJ_PATH_UNIQ_WRITE 0x004u     /* materialised in one probe pass (unique build keys)              */
+#define HMJ_PATH_SPLIT 0x008u          /* oversized partitions cut into virtual partitions                */
+#define HMJ_PATH_WINDOW 0x010u         /* partition window moved below the shared prefix (structured keys)*/
+#define HMJ_PATH_ORDER_DEFERRED 0x020u /* ordered epilogue finished by global LSD sorts of the result     */
+#define HMJ_PATH_ORDER_BY_KEY 0x040u   /* partitions are not key ranges: final stable sort by key         */
+#define HMJ_PATH_PREPARED 0x080u       /* build side taken from hmj_prepare_build_u64_device              */
+#define HMJ_PATH_CHUNKED_BUILD 0x100u  /* plan with build partitions beyond the LDS table (forced bits)   */
+#define HMJ_PATH_HOT_KEY_HINT 0x200u   /* the key sample saw a repeated key                               */
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* Replaces: nothing in the reference (no device); one ctx per GPU. device_id < 0 = current.     */
@@ -166,6 +185,13 @@ int hmj_join_u64_rows(hmj_ctx* ctx, const void* build_aos_host, uint64_t n_build
                       const void* probe_aos_host, uint64_t n_probe, uint32_t flags, hmj_result* out,
                       hmj_rows** rows);
 void hmj_rows_free(hmj_rows* rows);
+/* Released result columns and staging slots return to a process-wide pool of host memory that keeps at
+ * most HMJ_HOST_POOL_MAX_MB (environment, default 8192) MiB; beyond that the oldest buffers go back to the
+ * OS.  hmj_host_pool_trim(keep) shrinks the pool to at most `keep` bytes now (0 empties it) and returns the
+ * bytes released; hmj_host_pool_bytes() reports what the pool holds.  Both are thread-safe.  (The
+ * reference frees its _r_sorted/_s_sorted vectors in clear(), hashjoin.h:192-195.)                     */
+uint64_t hmj_host_pool_trim(uint64_t keep_bytes);
+uint64_t hmj_host_pool_bytes(void);
 /* Host threads of the optional staged upload (pageable input -> pinned chunks -> PCIe), used only
  * with HMJ_UPLOAD=staged in the environment; by default each relation goes up in one copy straight
  * from the caller's memory (54 GB/s on the MI355X box).  The reference ctor's num_threads argument,
