@@ -1,19 +1,19 @@
-# Builds the product library (HIP, gfx950) and the test oracle.  No autotools needed; the
-# autotools files under build-aux/ wrap the same rules for trees that use them.
+# Builds the product library (HIP, gfx950) and the test oracle with plain make.  configure.ac / Makefile.am at
+# the repo root wrap the same rules for autotools trees (unexercised here: no autoreconf in the image).
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC     := hashmergejoin_amd/csrc
-OBJS     := $(CSRC)/radix.o $(CSRC)/probe.o $(CSRC)/gen.o $(CSRC)/api.o
+OBJS     := $(CSRC)/radix.o $(CSRC)/probe.o $(CSRC)/gen.o $(CSRC)/api.o $(CSRC)/exchange.o
 LIB      := hashmergejoin_amd/libhmj_hip.so
 
 all: $(LIB) oracle cpptest examples/hashjoin_bench_hip
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/hmj_dev.h $(CSRC)/hmj_launch.h include/hmj.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/hmj_dev.h $(CSRC)/hmj_launch.h $(CSRC)/hmj_ctx.h include/hmj.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle all

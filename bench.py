@@ -6,12 +6,12 @@ resident in HBM: radix-partition R, radix-partition S, bucket-local build + prob
 (the reduction hashjoin_bench.cc:131-133 performs).  value = probe rows of all ranks x steps / time.
 
 N=1 workload: BASELINE.json configs[2]: |R|=|S|=2^28 u64 key / 8 B payload, 100 % match.
-N>1: weak scaling, 2^28 rows per relation per GPU (N=8 -> |R|=|S|=2^31, configs[3]); each step adds
-the owner split + RCCL all-to-all exchange of both relations.
+N>1: weak scaling, 2^28 rows per relation per GPU (N=8 -> |R|=|S|=2^31, configs[3]); each step is one
+hmj_exchange_join_u64_device: owner split + RCCL grouped send/recv rounds of both relations + local join.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed inside
-the timed region), "roofline_probe" (the build+probe kernel), "cpu_baseline" (the compiled reference
-timed on the host cores, N=1 only).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernels, HIP-event timed inside the
+timed region), "roofline_probe" (the build+probe kernel), "cpu_baseline" (the compiled reference timed on
+the host cores, N=1 only), "extra" (N=1: other BASELINE configs / modes timed in the same run).
 """
 import argparse
 import json
@@ -24,48 +24,133 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(log2n, threads):
-    """The reference's own pthread CPU path on a bounded sample of the same workload, timed on this
-    box's host cores.  kind "reference": oracle/_ref/libhmj_ref.so is the real reference compiled
-    from its own headers (oracle/Makefile).  Falls back to the single-thread C port."""
-    import numpy as np
+def usable_cores():
+    """(threads to use, cores in the affinity mask).  The smaller of the affinity mask and the cgroup CPU quota."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    use = aff
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            use = max(1, min(use, int(int(q) / int(p))))
+    except Exception:
+        pass
+    if os.environ.get("HMJ_CPU_THREADS"):
+        use = max(1, int(os.environ["HMJ_CPU_THREADS"]))
+    return use, aff
 
+
+def cpu_baseline(log2n, threads, affinity):
+    """The reference's own pthread CPU path on a bounded sample of the same workload, timed on this box's host
+    cores as SURVEY.md 8(d) prescribes: all cores the process may use, one warm-up + best of 5, buffers
+    pre-faulted (the relations are generated and copied into the reference's vectors before the clock starts).
+    kind "reference": oracle/_ref/libhmj_ref.so is the real reference compiled from its own headers
+    (oracle/Makefile).  Falls back to the single-thread C port where that library is absent."""
     from oracle.pyoracle import Oracle, Reference
 
     orc, ref = Oracle(), Reference()
     n = 1 << log2n
     B, P = orc.gen_build(n), orc.gen_probe(n, n)
-    out = {"cores": threads, "unit": "probe tuples/s", "sample": "|R|=|S|=2^%d u64 key / 8 B payload, same generator, 100%% match" % log2n}
-    if ref.available:
-        rh, sh = ref.pairs_new(B), ref.pairs_new(P)
+    out = {"cores": threads, "affinity_cores": affinity, "unit": "probe tuples/s", "runs": "1 warm-up + best of 5",
+           "sample": "|R|=|S|=2^%d u64 key / 8 B payload, same generator, 100%% match" % log2n}
+
+    def best_of(fn, reps=5):
+        fn()  # warm-up (also faults the destination buffers in)
         best = None
-        for _ in range(2):
+        for _ in range(reps):
             t0 = time.perf_counter()
-            cnt, sm = ref.hashmergejoin_pairs(rh, sh, threads)  # ctor + iterate, hashjoin_bench.cc:126-133
+            fn()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        assert cnt == n
+        return best
+
+    if ref.available:
+        rh, sh, oh = ref.pairs_new(B), ref.pairs_new(P), ref.pairs_new(B)
+        res = {}
+
+        def join():
+            res["v"] = ref.hashmergejoin_pairs(rh, sh, threads)  # ctor + iterate, hashjoin_bench.cc:126-133
+
+        best = best_of(join)
+        assert res["v"][0] == n
         out.update(kind="reference", value=n / best, seconds=best, what="HashMergeJoin ctor + iterate (hashjoin_bench.cc:126-133)")
-        # what radix_bench_par times for u64 (radix_bench_par.cc:126-127)
-        oh = ref.pairs_new(B)
-        t0 = time.perf_counter()
-        ref.radix_int_non_inplace_pairs(rh, oh, threads)
-        dt = time.perf_counter() - t0
-        out["radix_int_non_inplace_keys_per_s"] = n / dt
-        m = min(n, 1 << 22)  # radix_bench_par.cc:96; the in-place sort is much slower, keep the sample short
-        t0 = time.perf_counter()
-        ref.radix_int_inplace(B[:m], threads)
-        out["radix_int_inplace_keys_per_s"] = m / (time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        psum, found = ref.partitioned_join_sum(P, B, threads, 10)  # hashjoin_bench.cc:88-96
-        out["partitioned_build_probe_tuples_per_s"] = n / (time.perf_counter() - t0)
+        # what radix_bench_par times for u64 keys (radix_bench_par.cc:126-127 and :96)
+        out["radix_int_non_inplace_keys_per_s"] = n / best_of(lambda: ref.radix_int_non_inplace_pairs(rh, oh, threads))
+        m = min(n, 1 << 22)  # the in-place sort is much slower: shorter sample, best of 3 (each run sorts a fresh copy)
+        out["radix_int_inplace_keys_per_s"] = m / best_of(lambda: ref.radix_int_inplace(B[:m], threads), reps=3)
+        out["radix_int_inplace_sample_log2"] = 22
+        out["partitioned_build_probe_tuples_per_s"] = n / best_of(lambda: ref.partitioned_join_sum(P, B, threads, 10), reps=2)  # hashjoin_bench.cc:88-96
         for h in (rh, sh, oh):
             ref.pairs_free(h)
     else:
-        t0 = time.perf_counter()
-        cnt, sm, _ = orc.hashmergejoin(B, P, 1, cap=0)
-        dt = time.perf_counter() - t0
-        out.update(kind="port", cores=1, value=n / dt, seconds=dt, what="C restatement of HashMergeJoin ctor + iterate, 1 thread")
+        best = best_of(lambda: orc.hashmergejoin(B, P, 1, cap=0), reps=2)
+        out.update(kind="port", cores=1, value=n / best, seconds=best, what="C restatement of HashMergeJoin ctor + iterate, 1 thread")
+    return out
+
+
+def extra_runs(ex, H, torch):
+    """Other BASELINE configs and operator modes, timed by the same run (best of 3 after a warm-up, wall clock
+    around the blocking call): configs[1] with its stated 10-bit plan and with the planner's, configs[4], and the
+    ordered mode the C++ operator uses."""
+    import numpy as np
+
+    def timed(fn, reps=3):
+        fn()
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        return round(best, 3), r
+
+    out = {}
+    n = 1 << 26
+    R, S = ex.gen_build(n), ex.gen_probe(n, n)
+    ms, r = timed(lambda: ex.join_device(R, S, 0))
+    assert int(r.n_matches) == n
+    out["configs1_2p26_planner_bits%d_ms" % ex.last_timing()["radix_bits"]] = ms
+    ex.set_radix_bits(10)
+    try:
+        ms, r = timed(lambda: ex.join_device(R, S, 0))
+        assert int(r.n_matches) == n
+        t = ex.last_timing()
+        out["configs1_2p26_forced_10bit_ms"] = ms
+        out["configs1_2p26_forced_10bit_plan"] = "%d passes, chunked LDS build (%d-row build partitions)" % (t["radix_passes"], n >> 10)
+    finally:
+        ex.set_radix_bits(None)
+    del R, S
+    n = 1 << 28
+    R, S = ex.gen_build(n), ex.gen_probe(n, n)
+    for name, fl in (("materialize", H.HMJ_MATERIALIZE), ("ordered", H.HMJ_ORDERED)):
+        ms, r = timed(lambda: ex.join_device(R, S, fl), reps=2)
+        assert int(r.n_matches) == n
+        out["configs2_2p28_%s_ms" % name] = ms
+    ex.release_result()
+    del R, S
+    torch.cuda.empty_cache()
+    # configs[4]: Zipf(0.9) build side of 2^24 rows over 2^24 distinct values, probe 2^30 uniform over the domain
+    nb, npb, theta = 1 << 24, 1 << 30, 0.9
+    w = 1.0 / np.arange(1, nb + 1, dtype=np.float64) ** theta
+    cdf = np.cumsum(w) / w.sum()
+    thr = np.empty(nb, np.uint64)
+    big = cdf >= 1.0 - 2.0 ** -53
+    thr[~big] = (cdf[~big] * 2.0 ** 64).astype(np.uint64)
+    thr[big] = np.uint64((1 << 64) - 1)
+    thr[-1] = np.uint64((1 << 64) - 1)
+    Rz = ex.gen_from_cdf(nb, torch.from_numpy(thr.view(np.int64).copy()).cuda())
+    Sz = ex.gen_uniform_domain(npb, nb)
+    ms, r = timed(lambda: ex.join_device(Rz, Sz, 0), reps=2)
+    out["configs4_zipf_2p24_x_2p30_count_ms"] = ms
+    out["configs4_matches"] = int(r.n_matches)
+    ms, r = timed(lambda: ex.join_device(Rz, Sz, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE), reps=2)
+    out["configs4_first_wins_ms"] = ms
+    del Rz, Sz
+    torch.cuda.empty_cache()
     return out
 
 
@@ -78,6 +163,7 @@ def main():
     ap.add_argument("--materialize", action="store_true", help="also write the (key,rval,sval) columns")
     ap.add_argument("--cpu-log2n", type=int, default=24)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configs / modes timed beside the headline")
     ap.add_argument("--bits", type=int, default=-1, help="force total radix bits")
     a = ap.parse_args()
 
@@ -88,22 +174,20 @@ def main():
     from hashmergejoin_amd import dist as hdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    force_dist = os.environ.get("HMJ_FORCE_DIST") == "1"  # dev: run the exchange path with 1 rank
+    force_dist = os.environ.get("HMJ_FORCE_DIST") == "1"  # dev: run the exchange path with 1 rank (RCCL self send/recv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-    backend = os.environ.get("HMJ_DIST_BACKEND", "nccl")  # "gloo": rehearse N ranks on one GPU
+    backend = os.environ.get("HMJ_DIST_BACKEND", "nccl")  # "gloo": rehearse N ranks on one GPU (callback transport)
     ndev = torch.cuda.device_count()
     local_dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1 or force_dist:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -114,74 +198,70 @@ def main():
     ex = H.Executor(local_dev)
     if a.bits >= 0:
         ex.set_radix_bits(a.bits)
+    if world > 1:
+        hdist.init_comm(ex)    # RCCL communicator inside the library (or the gloo callback transport)
+    elif force_dist:
+        hdist.init_comm_single(ex)
+    distributed = world > 1 or force_dist
     # synthetic relations generated on device: this rank's row shard [rank*n, (rank+1)*n)
     R = ex.gen_build(n, start=rank * n)
     S = ex.gen_probe(n, n_total, start=rank * n)
     flags = H.HMJ_MATERIALIZE if a.materialize else 0
     ex.set_profiling(True)
-    if world > 1:
-        ex.set_key_prefix_bits(hdist.owner_bits(world))  # received rows share their top owner bits
 
     def step():
-        if world == 1 and not force_dist:
+        if not distributed:
             res = ex.join_device(R, S, flags)
-            return res, ex.last_timing()
-        b = max(hdist.owner_bits(world), 1 if force_dist else 0)
-        if force_dist:  # one rank: everything is sent to self, as one message per relation
-            recv = []
-            for rel in (R, S):
-                parted, off = ex.partition_device(rel, 64 - b, b)
-                rows, _ = hdist.exchange_rows(parted, hdist.split_counts_from_offsets(off[[0, -1]]))
-                recv.append(rows)
-            res = ex.join_device(recv[0], recv[1], flags)
-        else:  # owner split, RCCL all-to-all hidden behind the splits / build-side partitioning, join
-            res = hdist.pipelined_exchange_join(ex, R, S, b, flags)
-        return res, ex.last_timing()
+            return res, ex.last_timing(), None
+        loc, glob = ex.exchange_join(R, S, flags)  # owner split, exchange rounds, prepared build, local join
+        return glob, ex.last_timing(), ex.last_exchange_info()
 
     for _ in range(a.warmup):
-        res, _ = step()
+        res, _, _ = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    agg = {}
+    agg, xagg = {}, {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        res, tm = step()
+        res, tm, xi = step()
         for k, v in tm.items():
             if k.startswith(("ms_", "bytes_", "n_scatter")):
                 agg[k] = agg.get(k, 0) + v
-        last_tm = tm
+        for k, v in (xi or {}).items():
+            if k.startswith("ms_"):
+                xagg[k] = xagg.get(k, 0) + v
+        last_tm, last_xi = tm, xi
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    n_local = int(res.n_matches)
+    n_matches = int(res.n_matches)  # distributed: the reduction over all ranks (hmj_exchange_join's global_out)
     if world > 1:
         rdev = dev if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        m = torch.tensor([n_local], dtype=torch.int64, device=rdev)
-        dist.all_reduce(m)
-        n_matches = int(m.item())
-    else:
-        n_matches = n_local
     assert n_matches == n_total, "every probe row must match exactly once (%d != %d)" % (n_matches, n_total)
 
     if rank == 0:
         K = a.steps
         ms_step = dt / K * 1e3
-        # dominant kernel by time: the radix scatter (4 launches per join at 2 passes x 2 relations)
+        # dominant kernels by time: the radix scatters (2 relations x 2 passes per join)
         launches = max(1, agg.get("n_scatter_launches", 0))
         sc_ms = agg.get("ms_scatter", 0.0) / launches
         sc_bytes = agg.get("bytes_scatter", 0) / launches  # 32 B per row: 16 read + 16 written
         pr_ms = agg.get("ms_probe_count", 0.0) / K
         pr_bytes = agg.get("bytes_probe_count", 0) / K      # 16*(n_build + n_probe), read only
-        traffic = None
+        slab = bool(last_tm["path"] & H.HMJ_PATH_SLAB)
+        traffic, traffic_note = None, "not collected in this run (PMC passes need rocprofv3)"
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and a.log2n == 28 and slab:
             try:
-                traffic = json.load(open(tj)).get("radix_scatter_kernel", {}).get("hbm_bytes_per_launch")
+                tjs = json.load(open(tj))
+                traffic = tjs.get("radix_scatter_kernel", {}).get("hbm_bytes_per_launch")
+                traffic_note = "from %s (rocprofv3 --pmc passes of this workload, %s), NOT measured by this run" % (
+                    "profiles/pmc_traffic.json", tjs.get("_round", "round 1"))
             except Exception:
                 traffic = None
 
@@ -209,6 +289,17 @@ def main():
         except Exception:
             copy_gbs = None
 
+        pa = agg.get("ms_scatter_pass0", 0.0) / max(1, launches // 2)
+        pb = agg.get("ms_scatter_pass1", 0.0) / max(1, launches // 2)
+        rows_launch = sc_bytes / 32.0
+        if slab:
+            sc_kernel = "radix_slab_a_kernel<512,256> + radix_slab_b_kernel<512,256>"
+            sc_desc = "write-combining stable scatter into private slabs, no histogram; mean over the launches of a join (2 x pass A + 2 x pass B)"
+            pr_kernel = "probe_count_fast_kernel<1024,13,PCOUNT=false,SLAB=true,OUT=0>"
+        else:
+            sc_kernel = "radix_scatter_wc_kernel<512,256>"
+            sc_desc = "write-combining stable scatter with histogram offsets; mean over the launches of a join"
+            pr_kernel = "probe_count_fast_kernel (dense layout) + probe_kernel<0> for set-aside partitions"
         line = {
             "metric": "probe-side tuples/s + achieved HBM GB/s, |R|=|S|=2^28 u64 keys",
             "value": n_total * K / dt,
@@ -221,23 +312,36 @@ def main():
                                                             "materialised columns" if a.materialize else "count+sum (hashjoin_bench.cc:131-133)"),
                        "rows_per_relation_per_gpu": n, "rows_per_relation_total": n_total,
                        "parallelism": "radix-sharded x%d" % world},
-            "roofline": dict(roof(sc_bytes, sc_ms, traffic), kernel="radix_scatter_kernel", device_copy_GBps=copy_gbs,
-                             launches_per_step=launches // K, kernel_name="radix_slab_a_kernel / radix_slab_b_kernel (write-combining stable scatter, mean of the launches)"),
-            "roofline_probe": dict(roof(pr_bytes, pr_ms), kernel="probe_kernel<count>",
-                                   probe_tuples_per_s=round(n / (pr_ms * 1e-3)) if pr_ms > 0 else None),
+            "roofline": dict(roof(sc_bytes, sc_ms, traffic), kernel=sc_kernel, what=sc_desc, traffic_source=traffic_note,
+                             device_copy_GBps=copy_gbs, launches_per_step=launches // K,
+                             pass_a={"ms_per_launch": round(pa, 4), "GBps": round(32.0 * rows_launch / (pa * 1e-3) / 1e9, 1) if pa > 0 else None},
+                             pass_b={"ms_per_launch": round(pb, 4), "GBps": round(32.0 * rows_launch / (pb * 1e-3) / 1e9, 1) if pb > 0 else None}),
+            "roofline_probe": dict(roof(pr_bytes, pr_ms), kernel=pr_kernel,
+                                   probe_tuples_per_s=round(last_tm["bytes_probe_count"] / 32.0 / (pr_ms * 1e-3)) if pr_ms > 0 else None),
             "phases_ms_per_step": {k[3:]: round(v / K, 4) for k, v in agg.items() if k.startswith("ms_")},
         }
-        if world == 1 and not a.no_cpu:
-            try:
+        if distributed:
+            line["exchange"] = dict({k[3:]: round(v / K, 3) for k, v in xagg.items()}, unit="ms per step on rank 0",
+                                    rounds_build=last_xi["rounds_build"], rounds_probe=last_xi["rounds_probe"],
+                                    owner="hash of the key" if last_xi["owner_mode"] == 1 else "key ranges",
+                                    transport="rccl" if (backend == "nccl" or force_dist) else "callbacks over " + backend,
+                                    recv_rows_rank0=[last_xi["recv_build"], last_xi["recv_probe"]])
+        if world == 1 and not distributed:
+            del R, S
+            torch.cuda.empty_cache()
+            if not a.no_extra:
                 try:
-                    cores = len(os.sched_getaffinity(0))
-                except Exception:
-                    cores = os.cpu_count() or 1
-                cores = min(cores, int(os.environ.get("HMJ_CPU_THREADS", "16")))  # the box's CPU share for one GPU
-                line["cpu_baseline"] = cpu_baseline(a.cpu_log2n, cores)
-            except Exception as e:  # the baseline is reporting only; never fail the bench on it
-                line["cpu_baseline"] = {"error": repr(e)}
+                    line["extra"] = extra_runs(ex, H, torch)
+                except Exception as e:  # reporting only
+                    line["extra"] = {"error": repr(e)}
+            if not a.no_cpu:
+                try:
+                    cores, aff = usable_cores()
+                    line["cpu_baseline"] = cpu_baseline(a.cpu_log2n, cores, aff)
+                except Exception as e:  # the baseline is reporting only; never fail the bench on it
+                    line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    ex.close()
     if world > 1:
         dist.destroy_process_group()
 

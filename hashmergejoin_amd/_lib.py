@@ -54,6 +54,27 @@ def lib_path():
     return os.environ.get("HMJ_LIB") or os.path.join(_HERE, "libhmj_hip.so")
 
 
+class ExchangeInfo(C.Structure):
+    _fields_ = [("n_ranks", C.c_int), ("owner_mode", C.c_int), ("rounds_build", C.c_uint32), ("rounds_probe", C.c_uint32),
+                ("recv_build", C.c_uint64), ("recv_probe", C.c_uint64), ("ms_split", C.c_float),
+                ("ms_exchange_build", C.c_float), ("ms_exchange_probe", C.c_float), ("ms_local", C.c_float),
+                ("ms_total", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# hmj_transport: the two collectives a host may supply instead of RCCL (include/hmj.h)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("n_ranks", C.c_int), ("rank", C.c_int), ("allgather_u64", ALLGATHER_FN),
+                ("alltoallv", ALLTOALLV_FN)]
+
+
 _LIB = None
 
 
@@ -112,6 +133,26 @@ def load_library():
     L.hmj_set_host_threads.argtypes = [vp, i]
     L.hmj_release_result.restype = None
     L.hmj_release_result.argtypes = [vp]
+    L.hmj_comm_unique_id.restype = i
+    L.hmj_comm_unique_id.argtypes = [vp]
+    L.hmj_comm_init_rank.restype = i
+    L.hmj_comm_init_rank.argtypes = [vp, i, i, vp]
+    L.hmj_comm_set_transport.restype = i
+    L.hmj_comm_set_transport.argtypes = [vp, C.POINTER(Transport)]
+    L.hmj_comm_destroy.restype = i
+    L.hmj_comm_destroy.argtypes = [vp]
+    L.hmj_comm_set_message_bytes.restype = i
+    L.hmj_comm_set_message_bytes.argtypes = [vp, u, u]
+    L.hmj_exchange_join_u64_device.restype = i
+    L.hmj_exchange_join_u64_device.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult), C.POINTER(JoinResult)]
+    L.hmj_owner_split_u64_device.restype = i
+    L.hmj_owner_split_u64_device.argtypes = [vp, vp, u, i, _U64P, vp, vp]
+    L.hmj_last_exchange_info.restype = i
+    L.hmj_last_exchange_info.argtypes = [vp, C.POINTER(ExchangeInfo)]
+    L.hmj_exchange_rounds.restype = C.c_uint32
+    L.hmj_exchange_rounds.argtypes = [i, _U64P, u]
+    L.hmj_exchange_layout.restype = i
+    L.hmj_exchange_layout.argtypes = [i, i, _U64P, C.c_uint32, i, _U64P, _U64P, _U64P, _U64P, _U64P]
     L.hmj_partition_u64_device.restype = i
     L.hmj_partition_u64_device.argtypes = [vp, vp, u, i, i, vp, vp]
     L.hmj_sort_u64_device.restype = i

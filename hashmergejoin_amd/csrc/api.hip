@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -13,84 +14,17 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/hmj.h"
-#include "hmj_dev.h"
-#include "hmj_launch.h"
+#include "hmj_ctx.h"
 
 using hmj::u32;
 using hmj::u64;
+using namespace hmj_host;
 
-namespace {
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-};
-struct HostBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  bool pinned = true;  // false: pageable memory on transparent huge pages (the result columns)
-};
-
-enum Kind {
-  K_TOTAL = 0, K_H2D, K_D2H, K_HIST, K_SCAN, K_SCATTER, K_OFFSETS, K_PROBE_COUNT, K_OUT_SCAN,
-  K_PROBE_WRITE, K_ORDER, K_NKINDS
-};
-struct Span {
-  int kind, rel, e0, e1;  // rel: 0 = build side, 1 = probe side, -1 = n/a
-  int pass;               // K_SCATTER: 0 = a relation's first radix pass, 1 = a later one
-};
-
-}  // namespace
-
-struct hmj_ctx {
-  int device = 0, num_cus = 256;
-  hipStream_t own_stream = nullptr, stream = nullptr;
-  DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
-      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
-      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs;
-  HostBuf h_accum, h_key, h_rval, h_sval;
-  int host_threads = 0;  // staging threads for pageable input (0 = default)
-  std::vector<hipStream_t> up_streams;
-  std::vector<hipEvent_t> up_events;  // 2 per staging thread
-  std::vector<HostBuf> up_slots;      // 2 per staging thread
-  int force_bits = -1;
-  int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
-  // build side partitioned ahead of the join by hmj_prepare_build_u64_device (one-shot)
-  struct Prep {
-    bool valid = false, slab = false;
-    const void* ptr = nullptr;
-    const void* Rp = nullptr;
-    u32 n = 0;
-    int low = 0, B = 0;
-  } prep;
-  bool prepare_only = false;
-  int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
-  u64 probe_hint = 0;
-  int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
-  bool staged_upload = false;  // HMJ_UPLOAD=staged
-  bool split_mode = true;      // HMJ_SPLIT=0: never split oversized probe partitions
-  bool window_mode = true;     // HMJ_WINDOW=0: always partition right below the shared key prefix
-  u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
-                                 // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
-  int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
-  int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
-  bool profiling = false;
-#ifdef HMJ_DEV
-  u32 dev_ablate = 0;  // developer builds: HMJ_DEBUG_ABLATE, read once at hmj_create
-#endif
-  std::vector<hipEvent_t> events;
-  std::vector<Span> spans;
-  int ev_used = 0;
-  hmj_timing timing;
-  std::string last_error;
-};
-
-namespace {
+namespace hmj_host {
 
 constexpr int kMaxEvents = 256;
 
-int fail(hmj_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+int fail(hmj_ctx* c, int code, const char* what, hipError_t e) {
   if (c) {
     c->last_error = what;
     if (e != hipSuccess) {
@@ -197,7 +131,7 @@ bool pool_take(size_t bytes, bool pinned, HostBuf* out) {
   return true;
 }
 
-int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes, bool pinned = true) {
+int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes, bool pinned) {
   if (bytes <= b.cap) return HMJ_OK;
   pool_give(b);
   if (pool_take(bytes, pinned, &b)) return HMJ_OK;
@@ -229,7 +163,7 @@ void free_dev(DevBuf& b) {
 void free_host(HostBuf& b) { pool_give(b); }
 
 // ---- profiling spans ---------------------------------------------------------------------------
-int span_begin(hmj_ctx* c, int kind, int rel, int pass = 0) {
+int span_begin(hmj_ctx* c, int kind, int rel, int pass) {
   if (!c->profiling || c->ev_used + 2 > (int)c->events.size()) return -1;
   Span s{kind, rel, c->ev_used, c->ev_used + 1, pass};
   c->ev_used += 2;
@@ -644,7 +578,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // dense / small-integer keys: skip the top bits every (sampled) key shares
     u64* hs = (u64*)c->h_accum.p;
     if ((rc = ensure_dev(c, c->offs64, 4 * sizeof(u64))) != HMJ_OK) return rc;
-    HIP_TRY(hmj::launch_key_sample(R, nb, S, np, (u64*)c->offs64.p, c->stream));
+    HIP_TRY(hmj::launch_key_sample(R, nb, c->sample_build_only ? nullptr : S, c->sample_build_only ? 0u : np,
+                                   (u64*)c->offs64.p, c->stream));
     HIP_TRY(hipMemcpyAsync(hs, c->offs64.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     prefix = hs[0] ? __builtin_clzll(hs[0]) : 64;
@@ -731,7 +666,22 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       if (sd.rel == 0 && reuse) continue;            // build side already in slab_br / cnt_br
       if (sd.rel == 1 && c->prepare_only) continue;  // hmj_prepare_build: build side only
       int sp = span_begin(c, K_SCATTER, sd.rel);
-      HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
+      if (sd.rel == 1 && !c->arrive_ev.empty()) {
+        // the probe rows are still arriving over the links (exchange.hip): pass-A workers own contiguous input
+        // ranges, so the workers whose rows are complete start after each round's event
+        u32 w_done = 0;
+        for (size_t i = 0; i < c->arrive_ev.size(); i++) {
+          HIP_TRY(hipStreamWaitEvent(c->stream, c->arrive_ev[i], 0));
+          const bool last = i + 1 == c->arrive_ev.size();
+          const u32 w_end = last ? sd.g->WA : (u32)std::min<u64>(sd.g->WA, c->arrive_rows[i] / sd.g->rpw);
+          if (w_end > w_done) {
+            HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream, w_done, w_end));
+            w_done = w_end;
+          }
+        }
+      } else {
+        HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
+      }
       span_end(c, sp);
       sp = span_begin(c, K_SCATTER, sd.rel, 1);
       HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, *sd.g, sd.sb, sd.cb,
@@ -832,6 +782,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     c->prep.B = B;
     return HMJ_OK;
   }
+  for (hipEvent_t ev : c->arrive_ev) HIP_TRY(hipStreamWaitEvent(c->stream, ev, 0));  // probe rows still on the links
   if ((rc = partition_relation(c, S, np, c->sbuf, low, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
   s = span_begin(c, K_OFFSETS, -1);
   HIP_TRY(hmj::launch_part_offsets(Sp, np, low, B, (u32*)c->s_off.p, c->stream));
@@ -1069,7 +1020,17 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
   return fail(c, HMJ_E_HIP, "join could not be planned");
 }
 
-}  // namespace
+int prepare_build(hmj_ctx* c, const void* R, uint64_t n_build, uint64_t n_probe_hint) {
+  hmj_result dummy;
+  c->prepare_only = true;
+  c->probe_hint = n_probe_hint;
+  c->prep.valid = false;
+  const int rc = join_device(c, R, n_build, nullptr, 0, 0, &dummy, false);
+  c->prepare_only = false;
+  return rc;
+}
+
+}  // namespace hmj_host
 
 extern "C" {
 
@@ -1120,6 +1081,7 @@ void hmj_destroy(hmj_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  comm_destroy(c);
   DevBuf* devs[] = {&c->rbuf[0], &c->rbuf[1], &c->sbuf[0], &c->sbuf[1], &c->in_r, &c->in_s,
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
@@ -1231,6 +1193,7 @@ const char* hmj_strerror(int code) {
     case HMJ_E_OOM: return "out of device or pinned host memory";
     case HMJ_E_HIP: return "HIP runtime error";
     case HMJ_E_UNSUPPORTED: return "unsupported flag combination for this input";
+    case HMJ_E_RCCL: return "RCCL / transport error";
     default: return "unknown error";
   }
 }
@@ -1297,12 +1260,7 @@ int hmj_prepare_build_u64_device(hmj_ctx* c, const void* build_aos_dev, uint64_t
   if (n_probe_hint > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "too many rows");
   HIP_TRY(hipSetDevice(c->device));
   spans_reset(c);
-  hmj_result dummy;
-  c->prepare_only = true;
-  c->probe_hint = n_probe_hint;
-  c->prep.valid = false;
-  int rc = join_device(c, build_aos_dev, n_build, nullptr, 0, 0, &dummy, false);
-  c->prepare_only = false;
+  int rc = prepare_build(c, build_aos_dev, n_build, n_probe_hint);
   if (c->profiling) {
     (void)hipStreamSynchronize(c->stream);
     spans_collect(c);

@@ -1,0 +1,111 @@
+// Host-side state of one hmj_ctx and the internal entry points shared by api.hip (the join driver) and
+// exchange.hip (the multi-GPU partition exchange).  Internal header.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/hmj.h"
+#include "hmj_dev.h"
+#include "hmj_launch.h"
+
+struct hmj_comm;  // exchange.hip
+
+namespace hmj_host {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool pinned = true;  // false: pageable memory on transparent huge pages (the result columns)
+};
+
+enum Kind {
+  K_TOTAL = 0, K_H2D, K_D2H, K_HIST, K_SCAN, K_SCATTER, K_OFFSETS, K_PROBE_COUNT, K_OUT_SCAN,
+  K_PROBE_WRITE, K_ORDER, K_NKINDS
+};
+struct Span {
+  int kind, rel, e0, e1;  // rel: 0 = build side, 1 = probe side, -1 = n/a
+  int pass;               // K_SCATTER: 0 = a relation's first radix pass, 1 = a later one
+};
+
+}  // namespace hmj_host
+
+struct hmj_ctx {
+  using DevBuf = hmj_host::DevBuf;
+  using HostBuf = hmj_host::HostBuf;
+  using Span = hmj_host::Span;
+  using u32 = hmj::u32;
+  using u64 = hmj::u64;
+  int device = 0, num_cus = 256;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
+      out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
+      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs;
+  HostBuf h_accum, h_key, h_rval, h_sval;
+  int host_threads = 0;  // staging threads for pageable input (0 = default)
+  std::vector<hipStream_t> up_streams;
+  std::vector<hipEvent_t> up_events;  // 2 per staging thread
+  std::vector<HostBuf> up_slots;      // 2 per staging thread
+  int force_bits = -1;
+  int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
+  // build side partitioned ahead of the join by hmj_prepare_build_u64_device (one-shot)
+  struct Prep {
+    bool valid = false, slab = false;
+    const void* ptr = nullptr;
+    const void* Rp = nullptr;
+    u32 n = 0;
+    int low = 0, B = 0;
+  } prep;
+  bool prepare_only = false;
+  int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
+  u64 probe_hint = 0;
+  int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
+  bool staged_upload = false;  // HMJ_UPLOAD=staged
+  bool split_mode = true;      // HMJ_SPLIT=0: never split oversized probe partitions
+  bool window_mode = true;     // HMJ_WINDOW=0: always partition right below the shared key prefix
+  u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
+                                 // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
+  int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
+  int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
+  bool profiling = false;
+#ifdef HMJ_DEV
+  u32 dev_ablate = 0;  // developer builds: HMJ_DEBUG_ABLATE, read once at hmj_create
+#endif
+  std::vector<hipEvent_t> events;
+  std::vector<Span> spans;
+  int ev_used = 0;
+  hmj_timing timing;
+  std::string last_error;
+  // ---- multi-GPU exchange (exchange.hip) ----
+  hmj_comm* comm = nullptr;
+  // Probe rows that are still arriving over the links: rows [0, arrive_rows[i]) of the probe relation are
+  // complete once arrive_ev[i] has fired (ascending).  The slab path starts pass A on the arrived part; every
+  // other path waits for the last event before it touches the probe side.
+  std::vector<u64> arrive_rows;
+  std::vector<hipEvent_t> arrive_ev;
+  bool sample_build_only = false;  // the key sample must not read the probe side (it is still arriving)
+};
+
+
+namespace hmj_host {
+int fail(hmj_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes);
+int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes, bool pinned = true);
+void free_dev(DevBuf& b);
+void free_host(HostBuf& b);
+void spans_reset(hmj_ctx* c);
+void spans_collect(hmj_ctx* c);
+int span_begin(hmj_ctx* c, int kind, int rel, int pass = 0);
+void span_end(hmj_ctx* c, int id);
+// the whole local join (planning, retries) on device-resident relations
+int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
+                hmj_result* out, bool to_host);
+// partition the build side only (hmj_prepare_build_u64_device without the API prologue)
+int prepare_build(hmj_ctx* c, const void* R, uint64_t n_build, uint64_t n_probe_hint);
+void comm_destroy(hmj_ctx* c);  // exchange.hip: called by hmj_destroy
+}  // namespace hmj_host

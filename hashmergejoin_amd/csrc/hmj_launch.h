@@ -28,12 +28,22 @@ inline hipError_t ensure_max_smem(SmemAttrOnce& once, const void* kernel, size_t
 }
 
 // radix.hip
+constexpr int kMaxRanks = 16;  // ranks of one exchange (owner split fan-out; one node has 8 GPUs)
+// what the owner split of the multi-GPU exchange partitions on (radix.hip owner_digit)
+struct OwnerFn {
+  u32 mode;  // 0 = radix digit of the key, 1 = floor(mix64(key) * G / 2^64), 2 = splitters
+  u32 G;
+  u64 spl[kMaxRanks - 1];
+};
 // variant: 0 = plain staged scatter (4096-row tile), 1 = write-combining scatter (WC_X / WC_Y)
 int radix_tile_rows(int bits, int variant);
 void radix_pass_geometry(u32 n, int tile, u32* nblk, u32* rows_per_block);
 size_t radix_scatter_smem_bytes();
 hipError_t launch_radix_hist(const void* in, u32 n, int tile, int shift, int bits, u32* hist,
-                             u32 nblk, u32 rows_per_block, hipStream_t st);
+                             u32 nblk, u32 rows_per_block, hipStream_t st, const OwnerFn* own = nullptr);
+hipError_t launch_owner_scatter(const void* in, void* out, u32 n, int bits, const OwnerFn& own,
+                                const u32* hist_scanned, const u32* totals, u32 nblk, u32 rows_per_block,
+                                u64* offsets_out, hipStream_t st);
 hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipStream_t st);
 hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, int shift, int bits,
                                 const u32* hist_scanned, const u32* totals, u32 nblk,
@@ -45,7 +55,7 @@ struct SlabGeom {
 };
 bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g);
 hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a,
-                         u32* cnt_a, u64* accum, hipStream_t st);
+                         u32* cnt_a, u64* accum, hipStream_t st, u32 w_begin = 0, u32 w_end = 0xFFFFFFFFu);
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
                          const SlabGeom& g, void* slab_b, u32* cnt_b, u64* accum, hipStream_t st);
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st);

@@ -9,20 +9,40 @@
 // worker count.  HBM-bound integer work: coalesced dwordx4 loads, per-wave ballot ranking,
 // LDS-staged tiles so each digit's rows leave as one contiguous run (write-combined scatter).
 #include <cstdlib>
+#include <cstring>
 
 #include "hmj_dev.h"
 #include "hmj_launch.h"
 
 namespace hmj {
 
+// What a pass splits on.  OWN == 0: a radix digit of the key, (key >> shift) & mask -- every pass of the
+// local join.  The multi-GPU owner split (exchange.hip) uses the same stable histogram / scan / scatter with
+//   OWN == 1: owner = floor(mix64(key) * G / 2^64): spreads ANY key set evenly over G ranks (dense integer
+//             keys share their top bits and would all belong to rank 0);
+//   OWN == 2: owner = number of splitters <= key (G - 1 ascending splitters agreed by all ranks): rank g
+//             owns a key range, so per-rank ordered results concatenate in key order (HMJ_ORDERED).
+template <int OWN>
+__device__ __forceinline__ u32 owner_digit(u64 key, int shift, u32 mask, const OwnerFn& f) {
+  if (OWN == 1) return (u32)__umul64hi(mix64(key), (u64)f.G);
+  if (OWN == 2) {
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxRanks - 1; i++) d += ((u32)i + 1 < f.G && key >= f.spl[i]) ? 1u : 0u;
+    return d;
+  }
+  return (u32)(key >> shift) & mask;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: per-worker digit histogram.  hist[d * nblk + worker].  Algorithmic traffic: 16 B/row read
 // (the key shares its 16-B row with the payload, so whole lines are fetched).
 // ---------------------------------------------------------------------------------------------
+template <int OWN>
 __global__ __launch_bounds__(RP_THREADS) void radix_hist_kernel(const Tup* __restrict__ in, u32 n,
                                                                 int shift, u32 mask,
                                                                 u32 rows_per_block, u32 n_full,
-                                                                u32* __restrict__ hist, u32 nblk) {
+                                                                u32* __restrict__ hist, u32 nblk, OwnerFn own) {
   __shared__ u32 h[RP_MAXD];
   const u32 D = mask + 1;
   for (u32 d = threadIdx.x; d < D; d += RP_THREADS) h[d] = 0;
@@ -47,7 +67,7 @@ __global__ __launch_bounds__(RP_THREADS) void radix_hist_kernel(const Tup* __res
 #pragma unroll
     for (int r = 0; r < RP_ITEMS; r++) {
       u64 i = base + (u64)r * RP_THREADS + threadIdx.x;
-      if (i < end) atomicAdd(&h[(u32)(k[r] >> shift) & mask], 1u);
+      if (i < end) atomicAdd(&h[owner_digit<OWN>(k[r], shift, mask, own)], 1u);
     }
   }
   __syncthreads();
@@ -116,11 +136,11 @@ __device__ __forceinline__ void load_tile(Tup (&t)[RP_ITEMS], const Tup* __restr
 // FULL = true : workers that own only whole tiles (the bulk; no predication anywhere).
 // FULL = false: the single tail worker (rows [n_full, n), fewer than one tile), launched apart so
 //               its predicated code does not cost the bulk kernel registers.
-template <bool HI, bool FULL>
+template <bool HI, bool FULL, int OWN = 0>
 __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
     const Tup* __restrict__ in, Tup* __restrict__ out, u32 n, u32 n_full, int shift, int bits,
     u32 rows_per_block, u32 worker_base, const u32* __restrict__ hist_scanned,
-    const u32* __restrict__ totals, u32 nblk, u64* __restrict__ offsets_out) {
+    const u32* __restrict__ totals, u32 nblk, u64* __restrict__ offsets_out, OwnerFn own) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ScatterSmem& sm = *reinterpret_cast<ScatterSmem*>(smem_raw);
   const u32 D = 1u << bits, mask = D - 1;
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
     for (int r = 0; r < RP_ITEMS; r++) {
       u32 d = 0, rank = 0;
       if (FULL || wbase + r * 64 < tile_n) {
-        d = digit_of<HI>(t[r].key, shift, mask);
+        d = OWN ? owner_digit<OWN>(t[r].key, shift, mask, own) : digit_of<HI>(t[r].key, shift, mask);
         __hip_atomic_fetch_or(&lm[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const u64 m = __hip_atomic_load(&lm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const u32 old = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -247,7 +267,7 @@ __global__ __launch_bounds__(RP_THREADS, 4) void radix_scatter_kernel(
       for (int r = 0; r < RP_ITEMS / 2; r++) {
         const u32 i = (h * (RP_ITEMS / 2) + r) * RP_THREADS + tid;
         if (FULL || i < tile_n) {
-          const u32 d = digit_of<HI>(v[r].key, shift, mask);
+          const u32 d = OWN ? owner_digit<OWN>(v[r].key, shift, mask, own) : digit_of<HI>(v[r].key, shift, mask);
           store_stream(&out[sm.delta[d] + i], v[r]);
         }
       }
@@ -681,7 +701,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 template <int THREADS, int MAXD, bool HI>
 __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_a_kernel(
     const Tup* __restrict__ in, u32 n, int shift, int bits, u32 rows_per_worker, Tup* __restrict__ slab,
-    u32 CA, u32 WA, u32* __restrict__ cnt_out, u64* __restrict__ accum) {
+    u32 CA, u32 WA, u32* __restrict__ cnt_out, u64* __restrict__ accum, u32 worker_base) {
   typedef WcSmem<THREADS, MAXD> Smem;
   constexpr int TILE = Smem::TILE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -689,7 +709,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   u32* limit = reinterpret_cast<u32*>(smem_raw + sizeof(Smem));  // MAXD entries
   const u32 D = 1u << bits, mask = D - 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 worker = blockIdx.x;
+  const u32 worker = worker_base + blockIdx.x;  // (a launch may cover a range of workers: rows that have arrived)
   if ((u32)tid < D) {
     const u32 base = ((u32)tid * WA + worker) * CA;
     sm.cflush[tid] = base;
@@ -1018,14 +1038,16 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
 
 template <bool HI>
 static hipError_t launch_slab_a_t(const void* in, u32 n, int shift, int bits, u32 rpw, void* slab, u32 CA,
-                                  u32 WA, u32* cnt, u64* accum, hipStream_t st) {
+                                  u32 WA, u32* cnt, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {
   typedef WcSmem<512, 256> Smem;
   const size_t smem = sizeof(Smem) + 256 * sizeof(u32);
   static SmemAttrOnce attr_once;
   if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_a_kernel<512, 256, HI>), (size_t)smem); e != hipSuccess) return e;
-  hipLaunchKernelGGL((radix_slab_a_kernel<512, 256, HI>), dim3(WA), dim3(512), smem, st,
+  if (w_end > WA) w_end = WA;
+  if (w_begin >= w_end) return hipSuccess;
+  hipLaunchKernelGGL((radix_slab_a_kernel<512, 256, HI>), dim3(w_end - w_begin), dim3(512), smem, st,
                      static_cast<const Tup*>(in), n, shift, bits, rpw, static_cast<Tup*>(slab), CA, WA, cnt,
-                     accum);
+                     accum, w_begin);
   return hipGetLastError();
 }
 
@@ -1070,10 +1092,11 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g) {
   return rows_a < 0xFFFFFFF0ull && rows_b < 0xFFFFFFF0ull;
 }
 
+// workers [w_begin, w_end) of the pass (default: all): worker w reads input rows [w * g.rpw, (w + 1) * g.rpw)
 hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a,
-                         u32* cnt_a, u64* accum, hipStream_t st) {
-  return shift >= 32 ? launch_slab_a_t<true>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st)
-                     : launch_slab_a_t<false>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st);
+                         u32* cnt_a, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {
+  return shift >= 32 ? launch_slab_a_t<true>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st, w_begin, w_end)
+                     : launch_slab_a_t<false>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st, w_begin, w_end);
 }
 
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
@@ -1120,11 +1143,21 @@ void radix_pass_geometry(u32 n, int tile, u32* nblk, u32* rows_per_block) {
 size_t radix_scatter_smem_bytes() { return sizeof(ScatterSmem); }
 
 hipError_t launch_radix_hist(const void* in, u32 n, int tile, int shift, int bits, u32* hist,
-                             u32 nblk, u32 rows_per_block, hipStream_t st) {
+                             u32 nblk, u32 rows_per_block, hipStream_t st, const OwnerFn* own) {
   const u32 n_full = (n / (u32)tile) * (u32)tile;
-  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(RP_THREADS), 0, st,
-                     static_cast<const Tup*>(in), n, shift, (1u << bits) - 1, rows_per_block, n_full,
-                     hist, nblk);
+  OwnerFn f;
+  std::memset(&f, 0, sizeof(f));
+  if (own) f = *own;
+#define HMJ_HIST(O)                                                                                      \
+  hipLaunchKernelGGL((radix_hist_kernel<O>), dim3(nblk), dim3(RP_THREADS), 0, st, static_cast<const Tup*>(in), n, \
+                     shift, (1u << bits) - 1, rows_per_block, n_full, hist, nblk, f)
+  if (f.mode == 1)
+    HMJ_HIST(1);
+  else if (f.mode == 2)
+    HMJ_HIST(2);
+  else
+    HMJ_HIST(0);
+#undef HMJ_HIST
   return hipGetLastError();
 }
 
@@ -1133,17 +1166,20 @@ hipError_t launch_radix_rowscan(u32* hist, u32 nblk, int bits, u32* totals, hipS
   return hipGetLastError();
 }
 
-template <bool HI, bool FULL>
+template <bool HI, bool FULL, int OWN = 0>
 static hipError_t launch_radix_scatter_t(const void* in, void* out, u32 n, u32 n_full, int shift,
                                          int bits, u32 rows_per_block, u32 worker_base, u32 grid,
                                          const u32* hist_scanned, const u32* totals, u32 nblk,
-                                         u64* offsets_out, hipStream_t st) {
+                                         u64* offsets_out, hipStream_t st, const OwnerFn* own = nullptr) {
   static SmemAttrOnce attr_once;
-  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_scatter_kernel<HI, FULL>), (size_t)sizeof(ScatterSmem)); e != hipSuccess) return e;
-  hipLaunchKernelGGL((radix_scatter_kernel<HI, FULL>), dim3(grid), dim3(RP_THREADS),
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_scatter_kernel<HI, FULL, OWN>), (size_t)sizeof(ScatterSmem)); e != hipSuccess) return e;
+  OwnerFn f;
+  std::memset(&f, 0, sizeof(f));
+  if (own) f = *own;
+  hipLaunchKernelGGL((radix_scatter_kernel<HI, FULL, OWN>), dim3(grid), dim3(RP_THREADS),
                      sizeof(ScatterSmem), st, static_cast<const Tup*>(in), static_cast<Tup*>(out), n,
                      n_full, shift, bits, rows_per_block, worker_base, hist_scanned, totals, nblk,
-                     offsets_out);
+                     offsets_out, f);
   return hipGetLastError();
 }
 
@@ -1213,6 +1249,31 @@ hipError_t launch_radix_scatter(const void* in, void* out, u32 n, int variant, i
                                                  1, hist_scanned, totals, nblk, offsets_out, st)
            : launch_radix_scatter_t<false, false>(in, out, n, n_full, shift, bits, rows_per_block,
                                                   wb, 1, hist_scanned, totals, nblk, offsets_out, st);
+  }
+  return e;
+}
+
+// The owner split of the multi-GPU exchange: plain staged scatter (fan-out <= 16) on owner_digit<mode>.
+hipError_t launch_owner_scatter(const void* in, void* out, u32 n, int bits, const OwnerFn& own,
+                                const u32* hist_scanned, const u32* totals, u32 nblk, u32 rows_per_block,
+                                u64* offsets_out, hipStream_t st) {
+  const u32 n_full = (n / RP_TILE) * RP_TILE;
+  const bool tail = n_full != n;
+  const u32 k = nblk - (tail ? 1 : 0);
+  hipError_t e = hipSuccess;
+  if (n_full) {
+    e = own.mode == 2 ? launch_radix_scatter_t<false, true, 2>(in, out, n, n_full, 0, bits, rows_per_block, 0, k,
+                                                              hist_scanned, totals, nblk, offsets_out, st, &own)
+                      : launch_radix_scatter_t<false, true, 1>(in, out, n, n_full, 0, bits, rows_per_block, 0, k,
+                                                              hist_scanned, totals, nblk, offsets_out, st, &own);
+    if (e != hipSuccess) return e;
+  }
+  if (tail) {
+    const u32 wb = n_full ? k : 0;
+    e = own.mode == 2 ? launch_radix_scatter_t<false, false, 2>(in, out, n, n_full, 0, bits, rows_per_block, wb, 1,
+                                                               hist_scanned, totals, nblk, offsets_out, st, &own)
+                      : launch_radix_scatter_t<false, false, 1>(in, out, n, n_full, 0, bits, rows_per_block, wb, 1,
+                                                               hist_scanned, totals, nblk, offsets_out, st, &own);
   }
   return e;
 }

@@ -1,196 +1,179 @@
-"""Multi-GPU radix partition exchange.  One process per GPU; the radix fan-out
-shards the join: the owner of a row is the top log2(G) bits of its key -- the same
-most-significant-bits rule the reference partitions with (radix_hash.h:369, partitioned_hash.h:102)
--- so rank g ends up with key range g and the per-rank results concatenate in key order.
+"""Multi-GPU use of the executor: one process per GPU, the partition exchange itself is inside
+libhmj_hip.so (hmj_exchange_join_u64_device, include/hmj.h; csrc/exchange.hip).  This module only
 
-Exchange = counts all-to-all + one all_to_all_single (grouped send/recv) per relation over
-torch.distributed (backend "nccl" is RCCL over xGMI on ROCm; "gloo" on CPU for tests).  The local
-split is the HIP radix pass (hmj_partition_u64_device); the local join is hmj_join_u64_device.
-Nothing here computes a join on the CPU.
+  * sets up the communicator of an Executor from a torch.distributed process group -- RCCL over xGMI when the
+    group's backend is "nccl" (rank 0's unique id is broadcast through the group), otherwise the library's
+    callback transport over the group's own collectives (gloo: CPU tests, several ranks sharing one GPU);
+  * mirrors, in numpy, the owner function and the round plan for tests that have no GPU.
+
+Nothing here computes a join.  Reference counterpart: the fork-join over threads inside the ctor
+(hashjoin.h:56-68 -> radix_hash.h:375-405); here the fork-join is over GPUs.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _lib
 
-def owner_bits(world_size):
-    b = world_size.bit_length() - 1
-    if world_size < 1 or (1 << b) != world_size:
-        raise ValueError("world size must be a power of two (owner = top log2(G) key bits)")
-    return b
+_M64 = (1 << 64) - 1
 
 
-def split_counts_from_offsets(offsets):
-    """offsets: [G+1] bucket starts -> python list of G row counts."""
-    o = offsets.to("cpu", torch.int64)
-    return [int(x) for x in (o[1:] - o[:-1]).tolist()]
+def mix64(x):
+    """numpy uint64 mirror of hmj_dev.h mix64 (same constants as the oracle)."""
+    x = np.asarray(x, dtype=np.uint64).copy()
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return x
 
 
-# RCCL (2.26) truncates a single all-to-all message of 2 GiB or more (seen on MI355X: a 2^27-row bucket
-# arrives half empty).  Buckets are therefore sent in rounds of at most MAX_MSG_BYTES per peer; the
-# receive side places every round's slice at its final position, so the received rows stay grouped by
-# source rank in shard order (= global input order, which HMJ_FIRST_WINS relies on).
-MAX_MSG_BYTES = 1 << 30
+def owner_of(keys, n_ranks, splitters=None):
+    """Owner rank of every key, as radix.hip owner_digit computes it: floor(mix64(key) * G / 2^64), or with
+    splitters (ordered mode) the number of splitters <= key."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    if splitters is not None:
+        return np.searchsorted(np.asarray(splitters, dtype=np.uint64), keys, side="right").astype(np.int64)
+    m = mix64(keys)
+    hi, lo = m >> np.uint64(32), m & np.uint64(0xFFFFFFFF)
+    g = np.uint64(n_ranks)
+    return ((hi * g + ((lo * g) >> np.uint64(32))) >> np.uint64(32)).astype(np.int64)
 
 
-class _Works:
-    """wait() for every queued round (they run in order on the communicator's stream)."""
-
-    def __init__(self, works):
-        self.works = works
-
-    def wait(self):
-        for w in self.works:
-            w.wait()
-
-
-def _starts(counts):
-    out, acc = [], 0
-    for c in counts:
-        out.append(acc)
-        acc += c
+def exchange_plan(counts, rank, max_msg_rows, layout):
+    """hmj_exchange_rounds + hmj_exchange_layout (pure host arithmetic inside the library).
+    counts: [G,G] matrix, counts[src][dst].  Returns dict of [n_rounds,G] uint64 arrays + round_end."""
+    L = _lib.load_library()
+    m = np.ascontiguousarray(counts, dtype=np.uint64)
+    G = m.shape[0]
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))
+    R = int(L.hmj_exchange_rounds(G, p(m), max_msg_rows))
+    out = {k: np.zeros((R, G), np.uint64) for k in ("send_off", "send_rows", "recv_off", "recv_rows")}
+    out["round_end"] = np.zeros(R, np.uint64)
+    rc = L.hmj_exchange_layout(G, rank, p(m), R, layout, p(out["send_off"]), p(out["send_rows"]), p(out["recv_off"]),
+                               p(out["recv_rows"]), p(out["round_end"]))
+    if rc:
+        raise _lib.HmjError(rc, "hmj_exchange_layout")
+    out["n_rounds"] = R
     return out
 
 
-def _exchange_counts(parted, send_counts, group):
-    """All ranks learn the whole G x G count matrix (one tiny all-gather): returns (this rank's receive
-    counts, the largest single message of the exchange in rows) -- the latter so that every rank splits
-    the exchange into the same number of rounds."""
-    world = dist.get_world_size(group)
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=parted.device)
-    rows = [torch.empty(world, dtype=torch.int64, device=parted.device) for _ in range(world)]
-    dist.all_gather(rows, sc, group=group)
-    m = torch.stack(rows).cpu()  # m[src][dst]
-    me = dist.get_rank(group)
-    return [int(x) for x in m[:, me].tolist()], int(m.max().item())
+def _hip():
+    hip = C.CDLL(None)
+    if not hasattr(hip, "hipMemcpy"):
+        hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.restype = C.c_int
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    return hip
 
 
-def _list_all_to_all(outs, ins, group, async_op):
-    """dist.all_to_all on tensor lists; gloo has none, so CPU tests get point-to-point transfers."""
-    if dist.get_backend(group) == "nccl":
-        return dist.all_to_all(outs, ins, group=group, async_op=async_op)
-    me, reqs = dist.get_rank(group), []
-    for g in range(dist.get_world_size(group)):
-        if g == me:
-            outs[g].copy_(ins[g])
-            continue
-        peer = g if group is None else dist.get_global_rank(group, g)
-        reqs.append(dist.isend(ins[g].contiguous(), dst=peer, group=group))
-        reqs.append(dist.irecv(outs[g], src=peer, group=group))
-    for q in reqs:
-        q.wait()
-    return None
+class GroupTransport:
+    """hmj_transport over a torch.distributed group's point-to-point operations.  device=True: the pointers the
+    library passes are device memory and are staged through host tensors (rehearsal of several ranks on one GPU,
+    where RCCL refuses duplicate devices); device=False: host pointers (CPU tests of the exchange plan)."""
+
+    def __init__(self, group=None, device=True):
+        self.group, self.device = group, device
+        self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.hip = _hip() if device else None
+        self.rounds_seen = 0
+        self.struct = _lib.Transport(None, self.n_ranks, self.rank, _lib.ALLGATHER_FN(self._allgather),
+                                     _lib.ALLTOALLV_FN(self._alltoallv))
+
+    def _peer(self, g):
+        return g if self.group is None else dist.get_global_rank(self.group, g)
+
+    def _allgather(self, user, send, recv, count):
+        try:
+            mine = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).view(np.int64).copy())
+            outs = [torch.empty(count, dtype=torch.int64) for _ in range(self.n_ranks)]
+            dist.all_gather(outs, mine, group=self.group)
+            np.ctypeslib.as_array(recv, shape=(count * self.n_ranks,))[:] = torch.cat(outs).numpy().view(np.uint64)
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            print("GroupTransport.allgather failed:", repr(e), flush=True)
+            return 1
+
+    def _copy(self, dst, src, nbytes, kind):
+        if self.device:
+            rc = self.hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), nbytes, kind)
+            if rc:
+                raise RuntimeError("hipMemcpy failed: %d" % rc)
+        else:
+            C.memmove(dst, src, nbytes)
+
+    def _alltoallv(self, user, rnd, sp, sb, rp, rb, stream):
+        try:
+            G, me = self.n_ranks, self.rank
+            if self.device and self.hip.hipStreamSynchronize(C.c_void_p(stream)):
+                raise RuntimeError("hipStreamSynchronize failed")
+            self.rounds_seen += 1
+            reqs, outs, keep = [], {}, []
+            for g in range(G):
+                if g == me:
+                    if sb[g]:
+                        self._copy(rp[g], sp[g], sb[g], 3)  # device to device (host: memmove)
+                    continue
+                if sb[g]:
+                    t = torch.empty(sb[g], dtype=torch.uint8)
+                    self._copy(t.data_ptr(), sp[g], sb[g], 2)  # device to host
+                    keep.append(t)
+                    reqs.append(dist.isend(t, dst=self._peer(g), group=self.group))
+                if rb[g]:
+                    outs[g] = torch.empty(rb[g], dtype=torch.uint8)
+                    reqs.append(dist.irecv(outs[g], src=self._peer(g), group=self.group))
+            for q in reqs:
+                q.wait()
+            for g, t in outs.items():
+                self._copy(rp[g], t.data_ptr(), rb[g], 1)  # host to device
+            return 0
+        except Exception as e:
+            print("GroupTransport.alltoallv failed:", repr(e), flush=True)
+            return 1
 
 
-def _exchange_data(parted, send_counts, recv_counts, biggest_rows, group, async_op):
-    """Queue the data exchange; returns (rows, work or None)."""
-    parted = parted.contiguous()
-    row_bytes = parted.shape[1] * parted.element_size()
-    out = torch.empty((sum(recv_counts), parted.shape[1]), dtype=parted.dtype, device=parted.device)
-    rounds = max(1, -(-(biggest_rows * row_bytes) // MAX_MSG_BYTES))
-    if rounds == 1:
-        work = dist.all_to_all_single(out, parted, output_split_sizes=list(recv_counts),
-                                      input_split_sizes=list(send_counts), group=group, async_op=async_op)
-        return out, work
-    s0, r0 = _starts(send_counts), _starts(recv_counts)
-    works = []
-    for r in range(rounds):
-        ins = [parted[s0[g] + r * c // rounds: s0[g] + (r + 1) * c // rounds] for g, c in enumerate(send_counts)]
-        outs = [out[r0[g] + r * c // rounds: r0[g] + (r + 1) * c // rounds] for g, c in enumerate(recv_counts)]
-        works.append(_list_all_to_all(outs, ins, group, async_op))
-    return out, (_Works(works) if async_op and works[0] is not None else None)
+def new_unique_id():
+    """128-byte RCCL unique id (rank 0 calls this and distributes it)."""
+    L = _lib.load_library()
+    buf = (C.c_char * 128)()
+    rc = L.hmj_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc:
+        raise _lib.HmjError(rc, "hmj_comm_unique_id (is librccl available?)")
+    return bytes(buf)
 
 
-def exchange_rows(parted, send_counts, group=None):
-    """parted: [n,2] int64 rows already grouped by owner (owner-major); send_counts[g] rows go to
-    rank g.  Returns ([m,2] rows received, recv_counts).  Works on CPU tensors (gloo) and device
-    tensors (RCCL)."""
-    world = dist.get_world_size(group)
-    assert len(send_counts) == world and sum(send_counts) == parted.shape[0]
-    if parted.is_cuda and dist.get_backend(group) == "gloo":
-        # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices):
-        # stage through host memory.  The production path is RCCL on device tensors, below.
-        rows, rc = exchange_rows(parted.cpu(), send_counts, group)
-        return rows.to(parted.device), rc
-    recv_counts, biggest = _exchange_counts(parted, send_counts, group)
-    out, _ = _exchange_data(parted, send_counts, recv_counts, biggest, group, async_op=False)
-    return out, recv_counts
+def init_comm(ex, group=None, force_transport=None):
+    """Give `ex` (an Executor) the communicator of a torch.distributed group.  backend nccl -> RCCL inside the
+    library (its own communicator over xGMI; torch's group only carries the 128-byte id); anything else -> the
+    callback transport over the group.  force_transport: "rccl" | "group"."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    kind = force_transport or ("rccl" if dist.get_backend(group) == "nccl" else "group")
+    if kind == "rccl":
+        dev = torch.device("cuda", ex.device)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.zeros(128, dtype=torch.uint8, device=dev if on_dev else "cpu")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(new_unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(t, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        ex.comm_init_rccl(world, rank, bytes(t.cpu().numpy().tobytes()))
+    else:
+        ex.comm_set_transport(GroupTransport(group, device=True))
+    return kind
 
 
-def exchange_rows_async(parted, send_counts, group=None):
-    """Like exchange_rows but returns (rows, work) right after queueing the data exchange: the caller
-    overlaps other GPU work and calls work.wait() (a stream wait, not a host wait) before using rows.
-    The small counts exchange stays synchronous (the receive size must be known to allocate)."""
-    world = dist.get_world_size(group)
-    assert len(send_counts) == world and sum(send_counts) == parted.shape[0]
-    if dist.get_backend(group) != "nccl" or not parted.is_cuda:
-        rows, _ = exchange_rows(parted, send_counts, group)
-        return rows, None
-    recv_counts, biggest = _exchange_counts(parted, send_counts, group)
-    return _exchange_data(parted, send_counts, recv_counts, biggest, group, async_op=True)
+def init_comm_single(ex):
+    """One rank, RCCL transport: the whole exchange path with self send/recv (tests, HMJ_FORCE_DIST)."""
+    ex.comm_init_rccl(1, 0, new_unique_id())
 
 
-def allreduce_checks(local, device, group=None):
-    """local: dict n_matches/sum_r/sum_s/xor_fold/mix_sum (python ints mod 2^64) -> global dict.
-    Sums wrap mod 2^64 (two's complement int64 add); the xor is folded after an all_gather."""
-    world = dist.get_world_size(group)
-
-    def s64(x):
-        x &= (1 << 64) - 1
-        return x - (1 << 64) if x >= (1 << 63) else x
-
-    keys = ["n_matches", "sum_r", "sum_s", "mix_sum"]
-    # split each 64-bit value in 32-bit halves so the reduction cannot overflow a signed add
-    halves = []
-    for k in keys:
-        v = local[k] & ((1 << 64) - 1)
-        halves += [v & 0xFFFFFFFF, v >> 32]
-    if dist.get_backend(group) == "gloo":
-        device = torch.device("cpu")
-    t = torch.tensor(halves, dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    h = t.tolist()
-    out = {}
-    for i, k in enumerate(keys):
-        out[k] = (h[2 * i] + (h[2 * i + 1] << 32)) & ((1 << 64) - 1)
-    x = torch.tensor([s64(local["xor_fold"])], dtype=torch.int64, device=device)
-    xs = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(xs, x, group=group)
-    acc = 0
-    for v in xs:
-        acc ^= int(v.item()) & ((1 << 64) - 1)
-    out["xor_fold"] = acc
-    return out
-
-
-def pipelined_exchange_join(ex, r_shard, s_shard, b, flags=0, group=None):
-    """Owner split + exchange + local join with the exchange hidden behind GPU work:
-         split R | exchange R  || split S | exchange S || partition received R | ... probe
-    (|| = runs concurrently: RCCL on its stream, the HIP kernels on the current stream).
-    The caller has set ex.set_key_prefix_bits(b)."""
-    parted_r, off_r = ex.partition_device(r_shard, 64 - b, b)
-    rows_r, work_r = exchange_rows_async(parted_r, split_counts_from_offsets(off_r), group)
-    parted_s, off_s = ex.partition_device(s_shard, 64 - b, b)   # overlaps the exchange of R
-    rows_s, work_s = exchange_rows_async(parted_s, split_counts_from_offsets(off_s), group)
-    if work_r is not None:
-        work_r.wait()
-    if flags == 0:
-        ex.prepare_build(rows_r, rows_s.shape[0])               # overlaps the exchange of S
-    if work_s is not None:
-        work_s.wait()
-    return ex.join_device(rows_r, rows_s, flags)
-
-
-def distributed_join(ex, r_shard, s_shard, flags=0, group=None):
-    """Each rank holds a row shard of R (build) and S (probe) on its GPU.  Returns
-    (local JoinResult for this rank's key range, global checks dict)."""
-    world = dist.get_world_size(group)
-    if world == 1:
-        res = ex.join_device(r_shard, s_shard, flags)
-        return res, res.checks()
-    b = owner_bits(world)
-    ex.set_key_prefix_bits(b)  # every row received here carries this rank's owner bits on top
-    try:
-        res = pipelined_exchange_join(ex, r_shard, s_shard, b, flags, group)
-    finally:
-        ex.set_key_prefix_bits(-1)
-    return res, allreduce_checks(res.checks(), r_shard.device, group)
+def distributed_join(ex, r_shard, s_shard, flags=0):
+    """Each rank holds a row shard of R (build) and S (probe) on its GPU; init_comm was called.
+    Returns (local JoinResult for the keys this rank owns, global checks dict)."""
+    loc, glob = ex.exchange_join(r_shard, s_shard, flags)
+    return loc, glob.checks()

@@ -144,6 +144,52 @@ class Executor:
     def release_result(self):
         self.L.hmj_release_result(self.h)
 
+    # ---- multi-GPU exchange (hmj_comm_* / hmj_exchange_join_u64_device) -------------------------
+    def comm_init_rccl(self, n_ranks, rank, unique_id):
+        """unique_id: the 128 bytes rank 0 got from hashmergejoin_amd.dist.new_unique_id()."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.L.hmj_comm_init_rank(self.h, n_ranks, rank, C.cast(buf, C.c_void_p)))
+
+    def comm_set_transport(self, transport):
+        """transport: a _lib.Transport whose callbacks stay alive as long as this executor uses them."""
+        self._keep = transport
+        self._check(self.L.hmj_comm_set_transport(self.h, C.byref(transport.struct)))
+
+    def comm_set_message_bytes(self, max_message_bytes=0, probe_round_bytes=0):
+        self._check(self.L.hmj_comm_set_message_bytes(self.h, max_message_bytes, probe_round_bytes))
+
+    def owner_split(self, rel, n_ranks, splitters=None):
+        """hmj_owner_split_u64_device: (rows grouped by owner, [G'+1] offsets) with G' = 2^ceil(log2 n_ranks)."""
+        torch = self._torch
+        self._sync_stream()
+        ptr, n = _dev_ptr(rel)
+        out = torch.empty_like(rel)
+        nd = 1
+        while nd < n_ranks:
+            nd *= 2
+        off = torch.empty(nd + 1, dtype=torch.int64, device=rel.device)
+        sp = None
+        if splitters is not None:
+            sp = (C.c_uint64 * (n_ranks - 1))(*[int(x) for x in splitters])
+        self._check(self.L.hmj_owner_split_u64_device(self.h, C.c_void_p(ptr), n, n_ranks, sp, C.c_void_p(out.data_ptr()),
+                                                      C.c_void_p(off.data_ptr())))
+        return out, off
+
+    def exchange_join(self, build_shard, probe_shard, flags=0):
+        """Distributed join of row shards (collective).  Returns (local JoinResult, global JoinResult)."""
+        self._sync_stream()
+        bp, nb = _dev_ptr(build_shard)
+        pp, np_ = _dev_ptr(probe_shard)
+        loc, glob = JoinResult(), JoinResult()
+        self._check(self.L.hmj_exchange_join_u64_device(self.h, C.c_void_p(bp), nb, C.c_void_p(pp), np_, flags,
+                                                        C.byref(loc), C.byref(glob)))
+        return loc, glob
+
+    def last_exchange_info(self):
+        info = _lib.ExchangeInfo()
+        self._check(self.L.hmj_last_exchange_info(self.h, C.byref(info)))
+        return info.as_dict()
+
     # ---- single radix pass (hmj_partition_u64_device) ------------------------------------------
     def partition_device(self, rel, shift, bits):
         torch = self._torch

@@ -42,6 +42,8 @@ typedef struct hmj_ctx hmj_ctx;
 #define HMJ_E_UNSUPPORTED (-5) /* the flags cannot be honoured for this input (e.g. HMJ_ORDERED with a */
                                /* single partition's result beyond 2^31-1 rows)                      */
 
+#define HMJ_E_RCCL (-6)        /* RCCL (or the host's transport callbacks) failed, or librccl is absent  */
+
 /* flags for hmj_join_* */
 #define HMJ_MATERIALIZE 0x01u /* produce the (key, rval, sval) columns; else count/sums only --   */
                               /* the reduction hashjoin_bench.cc:131-133 performs                 */
@@ -197,6 +199,83 @@ uint64_t hmj_host_pool_bytes(void);
  * from the caller's memory (54 GB/s on the MI355X box).  The reference ctor's num_threads argument,
  * hashjoin.h:58, maps to this.  Default min(8, cores).                                            */
 int hmj_set_host_threads(hmj_ctx* ctx, int n);
+
+/* ---- multi-GPU: the radix partition exchange --------------------------------------- */
+/* One process per GPU, one ctx per process.  The reference reaches all of its parallelism from the ctor
+ * (hashjoin.h:56-68 -> radix_hash.h:375-405: fork-join over threads of one address space); this is the same
+ * fork-join over GPUs: every rank passes its row shard of R and S, the ranks exchange rows so that each owns
+ * a disjoint set of keys (radix fan-out over ranks; partition p of the probe side only ever meets table p,
+ * hashjoin_bench.cc:92-96), and each joins what it owns.
+ *
+ * Communicator.  RCCL over xGMI: rank 0 makes an id (hmj_comm_unique_id), the host program hands the 128 bytes
+ * to every rank by whatever it has (torch.distributed, MPI, a file), every rank calls hmj_comm_init_rank.
+ * librccl is loaded at the first of these calls (dlopen: the library itself does not link it; a process that
+ * already holds RCCL, e.g. through PyTorch, shares that copy).  Alternatively the host supplies the two
+ * collectives itself (hmj_comm_set_transport): an existing communicator, or -- as the tests do -- several
+ * ranks on one GPU over gloo.  Both are collective calls: all ranks, same order.                           */
+#define HMJ_UNIQUE_ID_BYTES 128
+int hmj_comm_unique_id(void* id128);
+int hmj_comm_init_rank(hmj_ctx* ctx, int n_ranks, int rank, const void* id128);
+typedef struct hmj_transport {
+  void* user;
+  int n_ranks, rank;
+  /* every rank contributes `count` values; recv[r * count + i] = rank r's send[i].  Host memory, blocking.  */
+  int (*allgather_u64)(void* user, const uint64_t* send, uint64_t* recv, int count);
+  /* one round of the all-to-all-v on DEVICE memory: send send_bytes[g] bytes at send_ptrs[g] to rank g and
+   * receive recv_bytes[g] bytes from it into recv_ptrs[g] (g == own rank: a local copy).  hip_stream
+   * (hipStream_t): the inputs are complete on it and the received bytes must be usable by later work on it
+   * -- queue the transfers there, or synchronise it, move the data and return.  0 = ok.                      */
+  int (*alltoallv)(void* user, int round, const void* const* send_ptrs, const uint64_t* send_bytes,
+                   void* const* recv_ptrs, const uint64_t* recv_bytes, void* hip_stream);
+} hmj_transport;
+int hmj_comm_set_transport(hmj_ctx* ctx, const hmj_transport* t);
+int hmj_comm_destroy(hmj_ctx* ctx); /* also done by hmj_destroy */
+/* Message sizes (0 = leave unchanged).  max_message_bytes: no single send exceeds it (default and maximum
+ * 2^30: RCCL 2.26 truncates a message of 2 GiB or more); a bucket larger than that goes in rounds.
+ * probe_round_bytes: target size of a probe-side message (default 128 MiB): the probe side travels in several
+ * rounds so that the local partitioning starts on the rows that have arrived.                              */
+int hmj_comm_set_message_bytes(hmj_ctx* ctx, uint64_t max_message_bytes, uint64_t probe_round_bytes);
+
+/* The distributed join.  Replaces the HashMergeJoin ctor + iteration (hashjoin.h:56-68, :183-191) for
+ * relations sharded by rows over the ranks.  Per call: owner split of both shards (stable histogram / scan /
+ * scatter, as pass 1 of the reference's sort) -> counts all-gather -> grouped send/recv rounds on the
+ * communicator's own stream -> local join; the build side is partitioned while the probe side is on the links,
+ * and the probe side's first pass starts per arrived round.
+ * Owner of a row: floor(mix64(key) * n_ranks / 2^64) -- even for any key set, dense integer keys included.
+ * HMJ_ORDERED: the g-th key range between splitters all ranks agree on (quantiles of their pooled key
+ * samples), so rank g's ordered rows precede rank g+1's: the concatenation in rank order is the reference's
+ * iteration order.  HMJ_FIRST_WINS is global when rank r's build shard precedes rank r+1's in input order.
+ * local_out: this rank's result (columns: device pointers owned by the ctx).  global_out (may be NULL):
+ * counts and checksums over all ranks, columns NULL.  Collective: all ranks, same flags.                    */
+int hmj_exchange_join_u64_device(hmj_ctx* ctx, const void* build_shard_dev, uint64_t n_build_shard,
+                                 const void* probe_shard_dev, uint64_t n_probe_shard, uint32_t flags,
+                                 hmj_result* local_out, hmj_result* global_out);
+/* The owner split on its own: rows grouped by owner rank, stably (owner-major; within an owner in input
+ * order), offsets_dev[g] = first row of owner g (2^ceil(log2 n_ranks) + 1 uint64, device).  splitters: NULL =
+ * hash owner; else n_ranks - 1 ascending keys (host memory) = key-range owner.  in/out must not overlap.   */
+int hmj_owner_split_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, int n_ranks,
+                               const uint64_t* splitters, void* out_aos_dev, uint64_t* offsets_dev);
+typedef struct {
+  int n_ranks, owner_mode;            /* owner_mode: 1 = hash of the key, 2 = key ranges (splitters)          */
+  uint32_t rounds_build, rounds_probe;
+  uint64_t recv_build, recv_probe;    /* rows this rank owns                                                */
+  float ms_split;                     /* owner split of both shards + the read-back of the counts (host clock) */
+  float ms_exchange_build, ms_exchange_probe; /* on the communication stream                                */
+  float ms_local;                     /* from "build side complete" to the end of the local join (host clock) */
+  float ms_total;
+} hmj_exchange_info;
+int hmj_last_exchange_info(hmj_ctx* ctx, hmj_exchange_info* out);
+/* The round plan, exported because it is pure host arithmetic (no GPU needed; every rank computes the same
+ * from the same count matrix).  counts[src * n_ranks + dst] = rows rank src sends to rank dst.
+ * hmj_exchange_rounds: rounds so that no message exceeds max_msg_rows.  hmj_exchange_layout: for round r and
+ * peer g (index r * n_ranks + g) the rows [send_off, +send_rows) of this rank's owner-major split buffer that
+ * go to g, and the rows [recv_off, +recv_rows) of its receive buffer that g's message fills.  layout 0 =
+ * source-major (a source's rows contiguous, sources in rank order = global input order), 1 = round-major
+ * (a round's rows contiguous; round_end[r] = rows complete after round r).                                  */
+uint32_t hmj_exchange_rounds(int n_ranks, const uint64_t* counts, uint64_t max_msg_rows);
+int hmj_exchange_layout(int n_ranks, int rank, const uint64_t* counts, uint32_t n_rounds, int layout,
+                        uint64_t* send_off, uint64_t* send_rows, uint64_t* recv_off, uint64_t* recv_rows,
+                        uint64_t* round_end);
 
 /* ---- one radix pass ---------------------------------------------------------------------------- */
 /* Replaces pass 1 of radix_int_non_inplace / radix_non_inplace_par: per-worker histogram, exclusive

@@ -1,8 +1,12 @@
-"""N>1 path with the real kernels: `world` processes share the one GPU of the box (gloo carries the exchange,
-as RCCL refuses two ranks on one device) and run hashmergejoin_amd.dist.distributed_join -- owner split with
-the HIP radix pass, exchange, prepared build side / key-prefix plan, local join -- on row shards of the same
-relations.  Checked against the CPU oracle: all-reduced checksums, and the per-rank ordered rows concatenated
-in rank order (rank g owns key range g)."""
+"""N>1 path with the real kernels, through the C ABI (hmj_exchange_join_u64_device, csrc/exchange.hip).
+
+  * `world` processes share the one GPU of the box; the library's callback transport carries the exchange over
+    gloo (RCCL refuses two ranks on one device).  Owner split kernel, counts, round plan, receive layouts, prepared
+    build side, per-round pass A and the local join are the production code; only the byte transport differs.
+  * one rank with the RCCL transport (self send/recv inside ncclGroupStart/End), up to BASELINE configs[3]'s
+    per-rank shape: a 2^28-row shard in several rounds, slab path, prepared build side.
+  * two ranks over RCCL on two GPUs where the box has them (skipped on a one-GPU box).
+Checked against the CPU oracle, or at full size against the generator's closed forms."""
 import json
 import os
 import socket
@@ -14,6 +18,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+M64 = (1 << 64) - 1
+VAL_XOR = 0x9E3779B97F4A7C15
 
 WORKER = r'''
 import os, sys, json
@@ -26,33 +32,43 @@ from hashmergejoin_amd import dist as hdist
 from oracle.pyoracle import Oracle
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
+backend = os.environ.get("BACKEND", "gloo")
+dev = rank if backend == "nccl" else 0
+torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 o = Oracle()
 nb, npb, miss, dup = int(os.environ["NB"]), int(os.environ["NP"]), int(os.environ["MISS"]), int(os.environ["DUP"])
-if os.environ.get("MAXMSG"):
-    hdist.MAX_MSG_BYTES = int(os.environ["MAXMSG"])
 b0, b1 = rank * nb // world, (rank + 1) * nb // world
 p0, p1 = rank * npb // world, (rank + 1) * npb // world
 Bs = o.gen_build(b1 - b0, start=b0)
 if dup == 1:  # duplicate build keys across shards: global row i and i + nb/2 share a key
     Bs[:, 0] = o.gen_build(b1 - b0, start=b0 % (nb // 2))[:, 0] if b0 >= nb // 2 else Bs[:, 0]
 Ps = o.gen_probe(p1 - p0, nb // 2 if dup == 1 else nb, start=p0, miss_mod=miss)
-if dup == 2:  # dense integer keys: every row's owner bits are 0 -> rank 0 receives everything, the others nothing
+if dup == 2:  # dense integer keys: all top bits zero; the hash owner must spread them over the ranks
     Bs[:, 0] = np.arange(b0, b1, dtype=np.uint64)
     Ps[:, 0] = (np.arange(p0, p1, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
 to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy()).cuda()
-ex = H.Executor(0)
+ex = H.Executor(dev)
+kind = hdist.init_comm(ex)
+assert kind == ("rccl" if backend == "nccl" else "group")
+if os.environ.get("MAXMSG"):
+    ex.comm_set_message_bytes(int(os.environ["MAXMSG"]), int(os.environ["MAXMSG"]) // 4)
 bd, pd = to_dev(Bs), to_dev(Ps)
-out = {}
+out, infos = {}, {}
+ex.set_profiling(True)
 for name, fl in [("count", 0), ("checksum", H.HMJ_CHECKSUM), ("first", H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE),
                  ("ordered", H.HMJ_ORDERED | H.HMJ_CHECKSUM), ("count_again", 0)]:
     res, glob = hdist.distributed_join(ex, bd, pd, fl)
     out[name] = glob
+    infos[name] = dict(ex.last_exchange_info(), path=ex.last_timing()["path"])
     if fl & H.HMJ_ORDERED:
         np.save(os.path.join(os.environ["OUT"], "rows%d.npy" % rank), ex.columns_to_numpy(res, host=False))
     ex.release_result()
-if rank == 0:
-    json.dump(out, open(os.path.join(os.environ["OUT"], "glob.json"), "w"))
+json.dump({"glob": out, "info": infos}, open(os.path.join(os.environ["OUT"], "out%d.json" % rank), "w"))
+ex.close()
 dist.destroy_process_group()
 '''
 
@@ -65,20 +81,20 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,nb,npb,miss,dup,maxmsg", [(2, 300000, 200000, 3, 0, 0), (4, 1 << 20, (1 << 20) + 777, 0, 0, 0),
-                                                            (2, 1 << 21, 1 << 22, 5, 1, 1 << 20), (2, (1 << 23) + 10, 1 << 23, 0, 0, 0),
-                                                            (2, 300000, 250000, 0, 2, 0)])
-def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup, maxmsg):
+def run_world(tmp_path, world, nb, npb, miss, dup, maxmsg, backend="gloo"):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HMJ_ROOT=ROOT, NB=str(nb), NP=str(npb), MISS=str(miss), DUP=str(dup), OUT=str(tmp_path),
-                   MAXMSG=str(maxmsg) if maxmsg else "", OMP_NUM_THREADS="1", HMJ_SLAB_MIN_LOG2="22")
+                   MAXMSG=str(maxmsg) if maxmsg else "", OMP_NUM_THREADS="1", HMJ_SLAB_MIN_LOG2="22", BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=500)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    glob = json.load(open(tmp_path / "glob.json"))
+    return [json.load(open(tmp_path / ("out%d.json" % r))) for r in range(world)]
+
+
+def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
     B = oracle.gen_build(nb)
     if dup == 1:
         B[nb // 2:, 0] = B[: nb - nb // 2, 0]
@@ -88,10 +104,133 @@ def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup
         P[:, 0] = (np.arange(npb, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
     ck, rows = oracle.equijoin(B, P)
     ckf, _ = oracle.equijoin(B, P, first_wins=True, cap=0)
-    assert glob["count"] == glob["count_again"]
-    for k in ("n_matches", "sum_r", "sum_s"):
-        assert glob["count"][k] == ck[k]
-    assert glob["checksum"] == ck and glob["ordered"] == ck
-    assert glob["first"] == ckf  # first build row in GLOBAL input order: shards arrive in rank order
+    for o in res:  # every rank reports the same global reduction
+        glob = o["glob"]
+        assert glob["count"] == glob["count_again"]
+        for k in ("n_matches", "sum_r", "sum_s"):
+            assert glob["count"][k] == ck[k]
+        assert glob["checksum"] == ck and glob["ordered"] == ck
+        assert glob["first"] == ckf  # first build row in GLOBAL input order: sources arrive in rank order
+    # ordered mode: rank g owns the g-th key range, so the per-rank ordered rows concatenate to the global order
     cat = np.concatenate([np.load(tmp_path / ("rows%d.npy" % r)) for r in range(world)])
     assert np.array_equal(cat, rows)
+    # ownership: every rank owns about 1/world of the rows -- for ANY keys, dense integers included
+    for o in res:
+        i = o["info"]["count"]
+        assert i["owner_mode"] == 1 and o["info"]["ordered"]["owner_mode"] == 2 and i["n_ranks"] == world
+        assert 0.8 * nb / world <= i["recv_build"] <= 1.2 * nb / world, i
+        assert 0.7 * npb / world <= i["recv_probe"] <= 1.3 * npb / world, i
+        if maxmsg:
+            assert i["rounds_build"] > 1 and i["rounds_probe"] > 1, i
+    assert sum(o["info"]["count"]["recv_build"] for o in res) == nb
+    return res
+
+
+@pytest.mark.parametrize("world,nb,npb,miss,dup,maxmsg", [(2, 300000, 200000, 3, 0, 0), (4, 1 << 20, (1 << 20) + 777, 0, 0, 0),
+                                                            (2, 1 << 21, 1 << 22, 5, 1, 1 << 20), (2, 9 << 20, (9 << 20) + 10, 0, 0, 1 << 24),
+                                                            (2, 300000, 250000, 0, 2, 0), (3, 700000, 500000, 2, 0, 1 << 19)])
+def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup, maxmsg):
+    res = run_world(tmp_path, world, nb, npb, miss, dup, maxmsg)
+    check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg)
+    if nb >= 9 << 20:  # each rank owns ~4.7 M rows per side: the slab path (threshold lowered to 2^22 for the tests): the build side was prepared during the probe exchange
+        import hashmergejoin_amd as H
+
+        for o in res:
+            assert o["info"]["count"]["path"] & H.HMJ_PATH_SLAB and o["info"]["count"]["path"] & H.HMJ_PATH_PREPARED, o["info"]["count"]
+
+
+def test_two_ranks_over_rccl(oracle, tmp_path):
+    # the RCCL transport between two GPUs: owner split, all-gathers, grouped ncclSend / ncclRecv rounds
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node); the one-rank RCCL tests below run everywhere")
+    world, nb, npb = 2, 1 << 22, (1 << 22) + 12345
+    res = run_world(tmp_path, world, nb, npb, 3, 0, 1 << 22, backend="nccl")
+    check_world(oracle, tmp_path, res, world, nb, npb, 3, 0, 1 << 22)
+
+
+def sum_xor_range(n, c):
+    """sum over j in [0, n) of (j ^ c) mod 2^64, bit by bit."""
+    total = 0
+    for b in range(64):
+        period, half = 1 << (b + 1), 1 << b
+        ones = (n // period) * half + max(0, (n % period) - half)  # j in [0,n) with bit b set
+        cb = (c >> b) & 1
+        cnt = (n - ones) if cb else ones
+        total += cnt << b
+    return total & M64
+
+
+@pytest.fixture(scope="module")
+def ex1():
+    import hashmergejoin_amd as H
+    from hashmergejoin_amd import dist as hdist
+
+    e = H.Executor(0)
+    hdist.init_comm_single(e)  # one rank, RCCL transport
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("log2n,maxmsg", [(22, 1 << 22), (26, 1 << 28), (28, 1 << 30)])
+def test_one_rank_rccl_exchange_at_shard_size(ex1, log2n, maxmsg):
+    # BASELINE configs[3]'s per-rank shape (2^28-row shard at log2n = 28): the whole exchange path through RCCL
+    # -- multi-round build side, round-major probe side with pass A per arrived round, prepared build side, slab
+    # path -- checked by the generator's closed forms (every probe row matches one build row).
+    import hashmergejoin_amd as H
+
+    ex = ex1
+    n = 1 << log2n
+    bd, pd = ex.gen_build(n), ex.gen_probe(n, n)
+    ex.comm_set_message_bytes(maxmsg, maxmsg // 8)
+    ex.set_profiling(True)
+    loc, glob = ex.exchange_join(bd, pd, 0)
+    info, t = ex.last_exchange_info(), ex.last_timing()
+    for r in (loc, glob):
+        assert int(r.n_matches) == n
+        assert int(r.sum_r) == (n * (n - 1) // 2) & M64
+        assert int(r.sum_s) == sum_xor_range(n, VAL_XOR)
+    assert info["n_ranks"] == 1 and info["recv_build"] == n and info["recv_probe"] == n
+    if log2n >= 26:
+        assert info["rounds_build"] >= 4 and info["rounds_probe"] >= 8, info
+        assert t["path"] & H.HMJ_PATH_SLAB and t["path"] & H.HMJ_PATH_PREPARED, t
+    ck = ex.exchange_join(bd, pd, H.HMJ_CHECKSUM)[1].checks()
+    plain = ex.join_device(bd, pd, H.HMJ_CHECKSUM).checks()
+    assert ck == plain  # same multiset of result rows as the plain single-GPU join
+    if log2n <= 26:
+        loc, glob = ex.exchange_join(bd, pd, H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+        assert glob.checks() == plain and int(loc.n_matches) == n
+        import torch
+
+        from hashmergejoin_amd.join import _memcpy_d2d
+
+        k = torch.empty(n, dtype=torch.int64, device="cuda")
+        _memcpy_d2d(torch, k, loc.key, n * 8)
+        ks = k ^ torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
+        assert bool((ks[1:] > ks[:-1]).all())
+    ex.set_profiling(False)
+    ex.release_result()
+
+
+def test_owner_split_matches_the_numpy_mirror(ex1, oracle):
+    # the HIP owner_digit places every row exactly where dist.owner_of says, stably (owner-major, input order
+    # within an owner) -- hash owner for any rank count, key-range owner with splitters
+    import torch
+
+    from hashmergejoin_amd import dist as hdist
+
+    rng = np.random.default_rng(4)
+    for n in (1, 63, 4096, 4097, 300001):
+        B = oracle.gen_build(n)
+        if n > 1000:
+            B[: n // 3, 0] = np.arange(n // 3, dtype=np.uint64)  # dense integers mixed in
+        bd = torch.from_numpy(B.view(np.int64).copy()).cuda()
+        for G in (2, 3, 8, 16):
+            for spl in (None, np.sort(rng.integers(0, 1 << 63, size=G - 1, dtype=np.uint64) * np.uint64(2))):
+                own = hdist.owner_of(B[:, 0], G, spl)
+                order = np.argsort(own, kind="stable")
+                out, off = ex1.owner_split(bd, G, spl)
+                assert np.array_equal(out.cpu().numpy().view(np.uint64), B[order]), (n, G, spl is None)
+                cnt = np.bincount(own, minlength=G)
+                assert np.array_equal(np.diff(off.cpu().numpy())[:G], cnt), (n, G)
