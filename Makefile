@@ -20,7 +20,7 @@ oracle:
 
 # C++ drop-in test: host-only g++ against the C ABI (+ the oracle as checker)
 cpptest: tests/cpp/test_dropin
-tests/cpp/test_dropin: tests/cpp/test_dropin.cc include/hashmergejoin_hip.hpp include/hmj.h $(LIB) oracle
+tests/cpp/test_dropin: tests/cpp/test_dropin.cc include/hashmergejoin_hip.hpp include/hmj.h oracle/strgen_restated.h $(LIB) oracle
 	g++ -std=c++11 -O2 -Wall -Iinclude -Ioracle $< -o $@ -Lhashmergejoin_amd -lhmj_hip -Loracle -lhmj_oracle \
 	  -Wl,-rpath,'$$ORIGIN/../../hashmergejoin_amd' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,/opt/rocm/lib -pthread
 

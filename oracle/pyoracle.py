@@ -22,6 +22,9 @@ PI_B = 12345
 VAL_XOR = 0x9E3779B97F4A7C15
 
 
+M64 = (1 << 64) - 1
+
+
 class Checks(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_matches", "sum_r", "sum_s", "xor_fold", "mix_sum")]
 
@@ -216,6 +219,49 @@ class Oracle:
         return c.as_dict(), t[: min(n, cap)]
 
 
+def strgen_mix64(x):
+    x &= M64
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & M64
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & M64
+    x ^= x >> 31
+    return x
+
+
+def create_strvec(number, words, seed):
+    """Python restatement of oracle/strgen_restated.h create_strvec (itself the restated strgen.cc:27-61):
+    list of (key, value).  Pure-Python loops: small and medium sizes only."""
+    import math
+
+    sq = int(math.ceil(math.sqrt(float(number))))
+    assert sq <= len(words), "word list too short"
+    pairs = [(words[i], i) for i in range(sq)]
+    done = len(pairs) >= number
+    i = 0
+    while i < sq and not done:
+        wi = pairs[i][0]
+        for j in range(sq):
+            if len(pairs) == number:
+                done = True
+                break
+            pairs.append((wi + "-" + pairs[j][0], i + j))
+        i += 1
+    del pairs[number:]
+    for k in range(len(pairs), 1, -1):
+        j = strgen_mix64(seed + k) % k
+        pairs[k - 1], pairs[j] = pairs[j], pairs[k - 1]
+    return pairs
+
+
+def fnv_relation(pairs):
+    h = 0xCBF29CE484222325
+    for key, val in pairs:
+        for ch in key.encode() + int(val).to_bytes(8, "little"):
+            h = ((h ^ ch) * 0x100000001B3) & M64
+    return h
+
+
 class Reference:
     """The real reference compiled into oracle/_ref/ (None-like if the .so is absent)."""
 
@@ -329,6 +375,20 @@ class Reference:
         sm = C.c_uint64(0)
         n = int(self.lib.ref_hashmergejoin_str(nr, ns, seed, threads, _p(pairs), cap, C.cast(C.byref(sm), _U64P)))
         return n, int(sm.value), pairs[:n]
+
+    def hashmergejoin_strgen(self, words_path, n, seed_r=1, seed_s=2, threads=1):
+        """Reference HashMergeJoin<KeyValVec::iterator,...> over two restated create_strvec(n) relations
+        (ref_driver.cc ref_hashmergejoin_strgen).  Returns dict(n, sum, pairs, fnv_r, fnv_s, distinct)."""
+        pairs = np.zeros((n + 1, 2), np.uint64)
+        sm, dist = C.c_uint64(0), C.c_uint64(0)
+        fnv = (C.c_uint64 * 2)()
+        self.lib.ref_hashmergejoin_strgen.restype = C.c_uint64
+        self.lib.ref_hashmergejoin_strgen.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, _U64P, C.c_uint64,
+                                                      _U64P, _U64P, _U64P]
+        cnt = int(self.lib.ref_hashmergejoin_strgen(words_path.encode(), n, seed_r, seed_s, threads, _p(pairs), n + 1,
+                                                    C.cast(C.byref(sm), _U64P), fnv, C.cast(C.byref(dist), _U64P)))
+        return {"n": cnt, "sum": int(sm.value), "pairs": pairs[:cnt], "fnv_r": int(fnv[0]), "fnv_s": int(fnv[1]),
+                "distinct": int(dist.value)}
 
     # opaque PairVec handles so a timed region excludes the AoS->vector conversion
     def pairs_new(self, aos):

@@ -18,9 +18,11 @@
 #include <cstring>
 #include <tuple>
 #include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
+#include "strgen_restated.h"
 #include "hashjoin.h"
 #include "partitioned_hash.h"
 #include "radix_hash.h"
@@ -266,6 +268,38 @@ uint64_t ref_hashmergejoin_str(uint64_t nr, uint64_t ns, uint64_t seed, unsigned
   for (uint64_t k = 0; k < ns; k++) {
     uint64_t i = (40503ull * k + 5) % ns;
     s[k] = std::make_pair(drv_synth_key(nr / 2 + i, seed), 7 * i + 3);
+  }
+  HashMergeJoin<KeyValVec::iterator, KeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), threads);
+  uint64_t cnt = 0, sum = 0;
+  for (auto t : hmj) {
+    if (pairs && cnt < cap) {
+      pairs[2 * cnt] = *std::get<1>(t);
+      pairs[2 * cnt + 1] = *std::get<2>(t);
+    }
+    sum += *std::get<1>(t) + *std::get<2>(t);
+    cnt++;
+  }
+  if (sum_out) *sum_out = sum;
+  return cnt;
+}
+
+// The reference's benchmark relations (hashjoin_bench.cc:112-113: r = create_strvec(n), s = create_strvec(n)) from
+// the restated generator (strgen_restated.h: word list as a parameter, seeded shuffle), joined by the REAL
+// HashMergeJoin<KeyValVec::iterator, KeyValVec::iterator> (hashjoin.h:33-199).  fnv_rel_out[0..1]: FNV-1a of
+// the two generated relations (pins the generator); pairs: (rval, sval) in iteration order.
+uint64_t ref_hashmergejoin_strgen(const char* words_path, uint64_t n, uint64_t seed_r, uint64_t seed_s,
+                                  unsigned threads, uint64_t* pairs, uint64_t cap, uint64_t* sum_out,
+                                  uint64_t* fnv_rel_out, uint64_t* distinct_out) {
+  const std::vector<std::string> words = hmj_strgen::load_words(words_path);
+  KeyValVec r = hmj_strgen::create_strvec((int)n, words, seed_r), s = hmj_strgen::create_strvec((int)n, words, seed_s);
+  if (fnv_rel_out) {
+    fnv_rel_out[0] = hmj_strgen::fnv_relation(r);
+    fnv_rel_out[1] = hmj_strgen::fnv_relation(s);
+  }
+  if (distinct_out) {  // strgen_test.cc:24-33: all keys distinct
+    std::unordered_set<std::string> u;
+    for (const auto& p : r) u.insert(p.first);
+    *distinct_out = u.size();
   }
   HashMergeJoin<KeyValVec::iterator, KeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), threads);
   uint64_t cnt = 0, sum = 0;

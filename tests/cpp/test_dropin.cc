@@ -14,6 +14,7 @@
 
 #include "hashmergejoin_hip.hpp"
 #include "hmj_oracle.h"
+#include "strgen_restated.h"
 
 typedef std::vector<std::pair<uint64_t, uint64_t>> KeyValVec;  // reference: hashjoin.h:29 with Key=u64
 
@@ -117,6 +118,39 @@ static void run_string_case(uint64_t nr, uint64_t ns, uint64_t seed) {
               (unsigned long long)fnv, keys_ok ? 1 : 0);
 }
 
+// ---- the reference's benchmark relations themselves: r = create_strvec(n), s = create_strvec(n)
+// (hashjoin_bench.cc:112-113; strgen.cc:27-61 restated in oracle/strgen_restated.h over the word-list fixture
+// tests/golden/words.txt).  Expected count / sum / ordered FNV: the compiled reference's (golden "strgen_join");
+// n = 10^6 is BASELINE.json configs[0].
+static void run_strgen_case(const std::vector<std::string>& words, int n) {
+  StrKeyValVec r = hmj_strgen::create_strvec(n, words, 1), s = hmj_strgen::create_strvec(n, words, 2);
+  const uint64_t fr = hmj_strgen::fnv_relation(r), fs = hmj_strgen::fnv_relation(s);
+  auto t0 = std::chrono::steady_clock::now();
+  HashMergeJoin<StrKeyValVec::iterator, StrKeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(),
+                                                                     std::thread::hardware_concurrency());
+  uint64_t cnt = 0, sum = 0, fnv = 0xCBF29CE484222325ull;
+  bool keys_ok = true;
+  const std::string* prev = nullptr;
+  for (auto tuple : hmj) {
+    const uint64_t rv = *std::get<1>(tuple), sv = *std::get<2>(tuple);
+    sum += rv + sv;
+    cnt++;
+    // the key handed out belongs to a row of r with that payload pairing: rows of r and s with this key exist
+    keys_ok = keys_ok && !std::get<0>(tuple)->empty() && std::get<0>(tuple) != prev;
+    prev = std::get<0>(tuple);
+    const uint64_t w[2] = {rv, sv};
+    for (int q = 0; q < 2; q++)
+      for (int b = 0; b < 8; b++) {
+        fnv ^= (w[q] >> (8 * b)) & 0xFF;
+        fnv *= 0x100000001B3ull;
+      }
+  }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("STRGEN %d count=%llu sum=%llu fnv=%llu keys_ok=%d fnv_r=%llu fnv_s=%llu ms=%.1f\n", n,
+              (unsigned long long)cnt, (unsigned long long)sum, (unsigned long long)fnv, keys_ok ? 1 : 0,
+              (unsigned long long)fr, (unsigned long long)fs, ms);
+}
+
 // ---- HashMergeJoin2 (hashjoin.h:201-363): pre-hashed std::tuple<hash, key, value> rows.
 // mode 0: hash = key; mode 1: hash = mix64(key), a bijection -- both inside the reference's domain (one
 // key per hash value): the rows must equal the restated reference's, in its order.
@@ -180,7 +214,7 @@ static int run_prehashed_case(uint64_t nb, uint64_t np, uint64_t miss, int mode)
   return hmj.begin() != hmj.end();
 }
 
-int main() {
+int main(int argc, char** argv) {
   int fails = 0;
   fails += run_case(0, 0, 0, false);
   fails += run_case(0, 7, 0, false);
@@ -211,6 +245,12 @@ int main() {
   run_string_case(1000, 1000, 1);
   run_string_case(5000, 3000, 2);
   run_string_case(200000, 150000, 3);
+  {
+    const std::string words_path = argc > 1 ? argv[1] : "tests/golden/words.txt";
+    const std::vector<std::string> words = hmj_strgen::load_words(words_path);
+    const int sizes[] = {2, 1000, 1 << 12, 1 << 16, 1 << 18, 1000000};
+    for (int n : sizes) run_strgen_case(words, n);
+  }
   std::printf(fails ? "FAILED\n" : "all drop-in cases passed\n");
   return fails ? 1 : 0;
 }

@@ -138,6 +138,32 @@ for nr, ns, seed in [(1000, 1000, 1), (5000, 3000, 2), (200000, 150000, 3)]:
     n, sm, pairs = ref.hashmergejoin_str(nr, ns, seed, 4)
     C["string_join"].append({"nr": nr, "ns": ns, "seed": seed, "n": n, "sum": sm, "fnv_pairs": fnv_rows(pairs)})
 
+# (8) the reference's benchmark relations: r = create_strvec(n), s = create_strvec(n) (hashjoin_bench.cc:112-113)
+# from the restated generator over the word-list fixture (oracle/strgen_restated.h, tests/golden/words.txt),
+# joined by the compiled reference.  10^6 is BASELINE.json configs[0]; 2^18 is strgen_test.cc's size.
+WORDS = os.path.join(HERE, "words.txt")
+C["strgen_join"] = []
+for n in [2, 1000, 1 << 12, 1 << 16, 1 << 18, 10 ** 6]:
+    g = ref.hashmergejoin_strgen(WORDS, n, 1, 2, 8)
+    assert g["n"] == n and g["distinct"] == n  # same key set on both sides; strgen_test.cc:24-33 uniqueness
+    C["strgen_join"].append({"n": n, "seed_r": 1, "seed_s": 2, "count": g["n"], "sum": g["sum"], "fnv_pairs": fnv_rows(g["pairs"]),
+                             "fnv_r": g["fnv_r"], "fnv_s": g["fnv_s"], "distinct": g["distinct"]})
+
+# (9) full-size unique-key joins: the reference's own checksums at sizes the GPU tests otherwise check by the
+# generator's closed forms only (2^24: ~1 s; 2^26: ~20 s and ~10 GiB in the build container)
+C["gen_join_full"] = []
+for log2n, miss in [(24, 0), (24, 3), (26, 0)]:
+    nn = 1 << log2n
+    B = o.gen_build(nn)
+    P = o.gen_probe(nn, nn, miss_mod=miss)
+    n, sm, t = ref.hashmergejoin(B, P, 8, cap=nn)
+    ck = o.checks_of_triples(t)  # checksum arithmetic only; the triples themselves are the reference's
+    assert (ck["sum_r"] + ck["sum_s"]) & M64 == sm and ck["n_matches"] == n
+    keys = t[:, 0]
+    assert bool(np.all(keys[1:] > keys[:-1]))  # iteration order = ascending key
+    C["gen_join_full"].append({"log2n": log2n, "miss_mod": miss, "n": n, "sum": sm, "checks": ck})
+    del B, P, t, keys
+
 # optimal_partition table --------------------------------------------------------------------------
 ns = [0, 1, 5, 63, 64, 65, 1000, 4095, 4096, 12345, 10 ** 6, 1 << 16, 1 << 18, 1 << 20, 1 << 24, 1 << 26, 1 << 28, 1 << 30, 1 << 31,
       10 ** 7, 10 ** 9]

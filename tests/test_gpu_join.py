@@ -405,23 +405,60 @@ def test_errors_are_loud(ex, H):
         ex.partition_device(torch.zeros((4, 2), dtype=torch.int64, device="cuda"), 60, 12)
 
 
-@pytest.mark.parametrize("log2n", [24, 26, 28])
-def test_full_size_closed_form(ex, H, log2n):
+def test_full_size_matches_the_reference_checksums(ex, H, G):
+    # 2^24 and 2^26 rows per relation: count, sum and the row checksums the COMPILED REFERENCE produced for the
+    # same generated relations (goldens gen_join_full; libhmj_ref.so takes seconds there), in every mode
+    for c in G["gen_join_full"]:
+        n = 1 << c["log2n"]
+        bd, pd = ex.gen_build(n), ex.gen_probe(n, n, miss_mod=c["miss_mod"])
+        r = ex.join_device(bd, pd, 0)
+        assert int(r.n_matches) == c["n"] and (int(r.sum_r) + int(r.sum_s)) & M64 == c["sum"]
+        for fl in (H.HMJ_CHECKSUM, H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_ORDERED | H.HMJ_CHECKSUM):
+            if c["log2n"] >= 26 and fl & H.HMJ_MATERIALIZE and not fl & H.HMJ_ORDERED:
+                continue
+            assert ex.join_device(bd, pd, fl).checks() == c["checks"], (c["log2n"], c["miss_mod"], fl)
+        ex.release_result()
+        del bd, pd
+
+
+@pytest.mark.parametrize("log2n,bits", [(24, None), (26, None), (28, None), (26, 10)])
+def test_full_size_closed_form(ex, H, G, log2n, bits):
     # BASELINE configs[1] (2^26) and configs[2] (2^28): far beyond what the CPU oracle finishes in
     # seconds, so check through closed forms of the generator: every probe row matches exactly one
     # build row (pi is a bijection), rval = pi(j), sval = j ^ VAL_XOR.
+    # (26, 10) is configs[1] AS STATED: "single-pass 10-bit radix" -- the reference's own fixed fan-out,
+    # partition_only(..., cores, 10) (hashjoin_bench.cc:88-89).  2^26 / 2^10 = 65536-row build partitions do not
+    # fit the LDS table, so this plan runs the chunked build: 5120-row tables, the probe partition
+    # re-streamed per table.  (The 10 bits are split in two 5-bit LSD passes: one pass of 1024 digits would need
+    # 1024 write-combining carry lines = 128 KiB of LDS.)
     n = 1 << log2n
     bd, pd = ex.gen_build(n), ex.gen_probe(n, n)
+    ex.set_radix_bits(bits)
+    try:
+        _full_size_checks(ex, H, G, bd, pd, n, log2n, bits)
+    finally:
+        ex.set_radix_bits(None)
+
+
+def _full_size_checks(ex, H, G, bd, pd, n, log2n, bits):
     r = ex.join_device(bd, pd, 0)
     assert int(r.n_matches) == n
     assert int(r.sum_r) == (n * (n - 1) // 2) & M64
     assert int(r.sum_s) == sum_xor_range(n, VAL_XOR)
+    t = ex.last_timing()
+    if bits is not None:
+        assert t["radix_bits"] == bits and t["path"] & H.HMJ_PATH_CHUNKED_BUILD and t["path"] & H.HMJ_PATH_EXACT, t
+    else:
+        assert not t["path"] & H.HMJ_PATH_CHUNKED_BUILD
     import torch
 
     from hashmergejoin_amd.join import _memcpy_d2d
 
     ck = ex.join_device(bd, pd, H.HMJ_CHECKSUM).checks()
     assert ck["n_matches"] == n
+    for c in G["gen_join_full"]:  # where the compiled reference's own checksums exist, they must be these
+        if c["log2n"] == log2n and c["miss_mod"] == 0:
+            assert ck == c["checks"]
     sign = torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
     vx = torch.tensor(VAL_XOR - (1 << 64), dtype=torch.int64, device="cuda")  # VAL_XOR as int64
     for fl in (H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_ORDERED | H.HMJ_CHECKSUM):
@@ -454,7 +491,9 @@ def test_cpp_dropin_operator(G):
 
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "test_dropin")
     assert os.path.exists(exe), "run `make cpptest`"
-    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "words.txt")], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=600)
     txt = out.stdout.decode()
     assert out.returncode == 0 and "all drop-in cases passed" in txt, txt
     # std::string keys (the reference's KeyValVec): count, sum and iteration order as the compiled
@@ -467,6 +506,18 @@ def test_cpp_dropin_operator(G):
     for c in G["string_join"]:
         g = got[(c["nr"], c["ns"], c["seed"])]
         assert (g["count"], g["sum"], g["fnv"], g["keys_ok"]) == (c["n"], c["sum"], c["fnv_pairs"], 1), (c, g)
+    # the reference's benchmark relations (two create_strvec(n) calls over the word-list fixture; n = 10^6 is
+    # BASELINE configs[0]): relations, count, sum and iteration order as the compiled reference had them
+    gen = {}
+    for line in txt.splitlines():
+        if line.startswith("STRGEN "):
+            f = line.split()
+            gen[int(f[1])] = {kv.split("=")[0]: kv.split("=")[1] for kv in f[2:]}
+    assert 10 ** 6 in gen
+    for c in G["strgen_join"]:
+        g = gen[c["n"]]
+        assert (int(g["fnv_r"]), int(g["fnv_s"])) == (c["fnv_r"], c["fnv_s"]), ("generated relations differ", c["n"])
+        assert (int(g["count"]), int(g["sum"]), int(g["fnv"]), int(g["keys_ok"])) == (c["count"], c["sum"], c["fnv_pairs"], 1), (c, g)
 
 
 def test_inputs_written_on_the_torch_stream_are_ordered(ex, oracle):

@@ -122,3 +122,30 @@ def test_mix64_bijection(oracle):
     for x in [0, 1, 12345, M64, 0x243F6A8885A308D3, 1 << 63]:
         assert oracle.unmix64(oracle.mix64(x)) == x
         assert oracle.mix64(oracle.unmix64(x)) == x
+
+
+def test_strgen_restatement_matches_the_goldens(golden_dir):
+    # create_strvec (strgen.cc:27-61) restated twice -- C++ (oracle/strgen_restated.h, which fed the compiled
+    # reference when the goldens were made) and Python (oracle/pyoracle.py) -- over the word-list fixture: the
+    # Python one must regenerate the very relations the goldens were computed from, and (strgen_test.cc:24-33)
+    # all keys of a relation are distinct
+    import json
+
+    from oracle.pyoracle import create_strvec, fnv_relation
+
+    words = open(os.path.join(golden_dir, "words.txt")).read().split("\n")[:-1]
+    assert len(words) == 1200 and len(set(words)) == 1200 and not any("-" in w for w in words)
+    cases = json.load(open(os.path.join(golden_dir, "golden.json")))["cases"]["strgen_join"]
+    assert [c["n"] for c in cases] == [2, 1000, 1 << 12, 1 << 16, 1 << 18, 10 ** 6]
+    for c in cases:
+        assert c["count"] == c["n"] == c["distinct"]  # every key matches exactly once (same key set, two orders)
+        if c["n"] > 1 << 16:
+            continue
+        r, s = create_strvec(c["n"], words, c["seed_r"]), create_strvec(c["n"], words, c["seed_s"])
+        assert fnv_relation(r) == c["fnv_r"] and fnv_relation(s) == c["fnv_s"], c["n"]
+        assert len({k for k, _ in r}) == c["n"] and {k for k, _ in r} == {k for k, _ in s}
+        # the join the reference computed: each key pairs r's payload with s's payload -> the sum is 2 x sum of payloads
+        assert (2 * sum(v for _, v in r)) & ((1 << 64) - 1) == c["sum"]
+    # strgen_test.cc's own size
+    big = create_strvec(1 << 18, words, 1)
+    assert len({k for k, _ in big}) == 1 << 18
