@@ -1424,6 +1424,58 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
   return HMJ_OK;
 }
 
+// {key, index} pairs in rbuf[0] -> sorted by key (stable), back in rbuf[0]: eight 8-bit LSD passes
+static int sort_pairs_in_rbuf(hmj_ctx* c, u64 n) {
+  int rc;
+  c->prep.valid = false;
+  if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->rbuf[1], (size_t)n * 16)) != HMJ_OK) return rc;
+  for (int pass = 0; pass < 8; pass++)
+    if ((rc = radix_pass(c, c->rbuf[pass & 1].p, c->rbuf[(pass & 1) ^ 1].p, (u32)n, 8 * pass, 8, -1, nullptr)) != HMJ_OK) return rc;
+  return HMJ_OK;
+}
+
+int hmj_sort_rows_by_u64_host(hmj_ctx* c, void* rows_host, uint64_t n, uint32_t row_bytes, uint32_t key_offset) {
+  if (!c) return HMJ_E_ARG;
+  if (row_bytes < 16 || row_bytes > 64 || (row_bytes & 7) || (key_offset & 7) || key_offset + 8 > row_bytes)
+    return fail(c, HMJ_E_ARG, "row_bytes must be a multiple of 8 in 16..64 and hold the 8-byte key at an 8-byte offset");
+  if (n > 0xFFFFFFFFull || (n && !rows_host)) return fail(c, HMJ_E_ARG, "hmj_sort_rows_by_u64_host");
+  HIP_TRY(hipSetDevice(c->device));
+  spans_reset(c);
+  if (n < 2) return HMJ_OK;
+  int rc;
+  const size_t bytes = (size_t)n * row_bytes;
+  const u32 words = row_bytes / 8;
+  if ((rc = ensure_dev(c, c->in_r, bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->in_s, bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(c->in_r.p, rows_host, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hmj::launch_rows_key_idx(c->in_r.p, n, words, key_offset / 8, c->rbuf[0].p, c->stream));
+  if ((rc = sort_pairs_in_rbuf(c, n)) != HMJ_OK) return rc;
+  HIP_TRY(hmj::launch_rows_gather(c->in_r.p, c->rbuf[0].p, n, words, c->in_s.p, c->stream));
+  HIP_TRY(hipMemcpyAsync(rows_host, c->in_s.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HMJ_OK;
+}
+
+int hmj_argsort_u64_host(hmj_ctx* c, const void* keys_host, uint64_t n, uint32_t stride_bytes, uint32_t* perm_out) {
+  if (!c) return HMJ_E_ARG;
+  if (stride_bytes < 8 || n > 0xFFFFFFFFull || (n && (!keys_host || !perm_out))) return fail(c, HMJ_E_ARG, "hmj_argsort_u64_host");
+  HIP_TRY(hipSetDevice(c->device));
+  spans_reset(c);
+  if (n == 0) return HMJ_OK;
+  int rc;
+  if ((rc = ensure_dev(c, c->in_r, (size_t)n * 8)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
+  HIP_TRY(hipMemcpy2DAsync(c->in_r.p, 8, keys_host, stride_bytes, 8, n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hmj::launch_key_idx((const u64*)c->in_r.p, n, c->rbuf[0].p, c->stream));
+  if ((rc = sort_pairs_in_rbuf(c, n)) != HMJ_OK) return rc;
+  HIP_TRY(hmj::launch_pairs_val_u32(c->rbuf[0].p, n, (u32*)c->in_r.p, c->stream));
+  HIP_TRY(hipMemcpyAsync(perm_out, c->in_r.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return HMJ_OK;
+}
+
 #define GEN_PROLOGUE                                                        \
   if (!c) return HMJ_E_ARG;                                                 \
   if (n && !out_aos_dev) return fail(c, HMJ_E_ARG, "out_aos is NULL");      \

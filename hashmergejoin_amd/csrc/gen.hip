@@ -116,6 +116,43 @@ __global__ void gather3_kernel(const Tup* __restrict__ sorted, u64 n, const u64*
     osval[i] = sval[t.val];
   }
 }
+// rows of `words` u64 each: pairs[i] = {rows[i][key_word], i}
+__global__ void rows_key_idx_kernel(const u64* __restrict__ rows, u64 n, u32 words, u32 key_word, Tup* __restrict__ out) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    Tup t;
+    t.key = rows[i * words + key_word];
+    t.val = i;
+    out[i] = t;
+  }
+}
+// out row i = in row sorted[i].val   (one thread per u64 word: consecutive threads write consecutive words)
+__global__ void rows_gather_kernel(const u64* __restrict__ in, const Tup* __restrict__ sorted, u64 n, u32 words,
+                                   u64* __restrict__ out) {
+  const u64 total = n * words;
+  for (u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (u64)gridDim.x * blockDim.x) {
+    const u64 i = x / words;
+    const u32 w = (u32)(x - i * words);
+    out[x] = in[sorted[i].val * words + w];
+  }
+}
+__global__ void pairs_val_u32_kernel(const Tup* __restrict__ sorted, u64 n, u32* __restrict__ out) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = (u32)sorted[i].val;
+}
+hipError_t launch_rows_key_idx(const void* rows, u64 n, u32 words, u32 key_word, void* out, hipStream_t st) {
+  hipLaunchKernelGGL(rows_key_idx_kernel, dim3(2048), dim3(256), 0, st, static_cast<const u64*>(rows), n, words, key_word,
+                     static_cast<Tup*>(out));
+  return hipGetLastError();
+}
+hipError_t launch_rows_gather(const void* in, const void* sorted, u64 n, u32 words, void* out, hipStream_t st) {
+  hipLaunchKernelGGL(rows_gather_kernel, dim3(4096), dim3(256), 0, st, static_cast<const u64*>(in),
+                     static_cast<const Tup*>(sorted), n, words, static_cast<u64*>(out));
+  return hipGetLastError();
+}
+hipError_t launch_pairs_val_u32(const void* sorted, u64 n, u32* out, hipStream_t st) {
+  hipLaunchKernelGGL(pairs_val_u32_kernel, dim3(2048), dim3(256), 0, st, static_cast<const Tup*>(sorted), n, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_key_idx(const u64* key, u64 n, void* out, hipStream_t st) {
   hipLaunchKernelGGL(key_idx_kernel, dim3(2048), dim3(256), 0, st, key, n, static_cast<Tup*>(out));
   return hipGetLastError();

@@ -330,8 +330,11 @@ class HashMergeJoin<RIter, SIter, false> {
 // Value> rows.  The reference sorts both buffers in place on (hash, key) (radix_inplace_par,
 // radix_hash.h:589-654) and merges them; here the GPU joins the {hash, row index} rows, the host keeps
 // the pairs whose keys are equal, and iteration runs in the same ascending (hash, key) order.
-// operator* points into the caller's buffers, as the reference's does.  One documented difference: the
-// caller's buffers are left as they are (the reference leaves them sorted as a side effect).
+// operator* points into the caller's buffers, as the reference's does -- and, as in the reference
+// (hashjoin.h:234-235), the ctor leaves BOTH caller buffers sorted by hash: tuples of 8-byte trivially copyable
+// elements in contiguous storage are sorted on the GPU as they are (hmj_sort_rows_by_u64_host); any other
+// tuple type is permuted on the host into the order the GPU computes (hmj_argsort_u64_host).  The sort is
+// stable where the reference's is not: rows with equal hashes keep their input order.
 // ---------------------------------------------------------------------------------------------------
 template <typename RIter, typename SIter>
 class HashMergeJoin2 {
@@ -356,10 +359,40 @@ class HashMergeJoin2 {
     for (std::size_t i = 0; i < n; i++) out[i] = std::make_pair((std::uint64_t)std::get<0>(begin[i]), (std::uint64_t)i);
   }
 
+  // radix_inplace_par's visible effect (radix_hash.h:589-654): the caller's buffer ends up sorted by hash
+  template <typename Iter>
+  static void sort_in_place(Iter begin, std::size_t n) {
+    typedef typename std::iterator_traits<Iter>::value_type T;
+    typedef typename std::tuple_element<0, T>::type H;
+    typedef typename std::tuple_element<1, T>::type K;
+    typedef typename std::tuple_element<2, T>::type V;
+    if (n < 2) return;
+    hmj_ctx* c = hmj_detail::thread_ctx();
+    const bool contiguous = std::is_pointer<Iter>::value || std::is_same<Iter, typename std::vector<T>::iterator>::value;
+    const bool plain = std::is_trivially_copyable<H>::value && std::is_trivially_copyable<K>::value &&
+                       std::is_trivially_copyable<V>::value && sizeof(H) == 8 && sizeof(T) % 8 == 0 && sizeof(T) <= 64;
+    T* first = std::addressof(*begin);
+    const std::size_t hash_off = (std::size_t)(reinterpret_cast<const char*>(&std::get<0>(*first)) - reinterpret_cast<const char*>(first));
+    if (contiguous && plain) {
+      hmj_detail::check(c, hmj_sort_rows_by_u64_host(c, first, (uint64_t)n, (uint32_t)sizeof(T), (uint32_t)hash_off), "hmj_sort_rows_by_u64_host");
+      return;
+    }
+    std::vector<std::uint64_t> h(n);
+    for (std::size_t i = 0; i < n; i++) h[i] = (std::uint64_t)std::get<0>(begin[i]);
+    std::vector<std::uint32_t> perm(n);
+    hmj_detail::check(c, hmj_argsort_u64_host(c, h.data(), (uint64_t)n, 8, perm.data()), "hmj_argsort_u64_host");
+    std::vector<T> tmp;
+    tmp.reserve(n);
+    for (std::size_t i = 0; i < n; i++) tmp.push_back(std::move(begin[perm[i]]));
+    for (std::size_t i = 0; i < n; i++) begin[i] = std::move(tmp[i]);
+  }
+
  public:
   HashMergeJoin2() = default;
   HashMergeJoin2(RIter r_begin, RIter r_end, SIter s_begin, SIter s_end, unsigned int num_threads = 1)
       : _r(r_begin), _s(s_begin) {
+    sort_in_place(r_begin, (std::size_t)std::distance(r_begin, r_end));  // hashjoin.h:234
+    sort_in_place(s_begin, (std::size_t)std::distance(s_begin, s_end));  // hashjoin.h:235
     std::vector<std::pair<std::uint64_t, std::uint64_t>> hr, hs;
     hash_column(r_begin, (std::size_t)std::distance(r_begin, r_end), hr);
     hash_column(s_begin, (std::size_t)std::distance(s_begin, s_end), hs);

@@ -297,6 +297,18 @@ int hmj_partition_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, i
  * multiset of rows.  A partial overlap of in and out is not allowed.                               */
 int hmj_sort_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, void* out_aos_dev);
 
+/* Replaces radix_hash::radix_inplace_par on a caller's pre-hashed tuple buffer (radix_hash.h:589-654) -- what the
+ * HashMergeJoin2 ctor does to BOTH relations as a side effect callers may rely on (hashjoin.h:234-235): n rows
+ * of row_bytes bytes in HOST memory are sorted IN PLACE, ascending on the uint64 at byte offset key_offset.
+ * Stable (equal keys keep their input order; the reference's swap chains are not).  The rows go to the GPU,
+ * {key, index} pairs are sorted there (eight 8-bit LSD passes), the rows are gathered and copied back.
+ * row_bytes: a multiple of 8 in 16..64 (std::tuple<size_t, uint64_t, uint64_t> is 24; libstdc++ stores the
+ * elements in reverse order, so its hash sits at offset 16).                                               */
+int hmj_sort_rows_by_u64_host(hmj_ctx* ctx, void* rows_host, uint64_t n, uint32_t row_bytes, uint32_t key_offset);
+/* The sorted order only, for rows the GPU cannot move (non-trivial types such as std::string keys): key i is the
+ * uint64 at keys_host + i * stride_bytes; perm_out[j] = input index of the row that belongs at position j.   */
+int hmj_argsort_u64_host(hmj_ctx* ctx, const void* keys_host, uint64_t n, uint32_t stride_bytes, uint32_t* perm_out);
+
 /* ---- synthetic relations on device (same integer arithmetic as the oracle) ------- */
 /* key = mix64(i + seed), val = i, i in [start, start+n)                                          */
 int hmj_gen_build_u64_device(hmj_ctx* ctx, void* out_aos_dev, uint64_t n, uint64_t start,

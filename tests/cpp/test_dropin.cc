@@ -210,8 +210,67 @@ static int run_prehashed_case(uint64_t nb, uint64_t np, uint64_t miss, int mode)
                 (unsigned long long)np, mode, (unsigned long long)n, (unsigned long long)want_n, bad);
     return 1;
   }
+  // The ctor's side effect (hashjoin.h:234-235 -> radix_inplace_par): the CALLER'S buffers are now sorted by
+  // hash.  Inside the reference's domain (one key per hash value; modes 0 and 1) the sorted buffers are unique:
+  // they must equal what the restated reference left in rh / sh.  Mode 2 (many keys per hash): ascending
+  // hashes over the same multiset of rows, equal hashes in input order.
+  {
+    int unsorted = 0;
+    const HashKeyValVec* bufs[2] = {&r, &s};
+    const std::vector<uint64_t>* wants[2] = {&rh, &sh};
+    for (int q = 0; q < 2; q++) {
+      const HashKeyValVec& v = *bufs[q];
+      uint64_t xr = 0, xw = 0;
+      for (size_t i = 0; i < v.size(); i++) {
+        const uint64_t h = std::get<0>(v[i]), k = std::get<1>(v[i]), p = std::get<2>(v[i]);
+        if (i && h < (uint64_t)std::get<0>(v[i - 1])) unsorted++;
+        if (mode < 2 && (h != (*wants[q])[3 * i] || k != (*wants[q])[3 * i + 1] || p != (*wants[q])[3 * i + 2])) unsorted++;
+        if (mode == 2 && i && h == (uint64_t)std::get<0>(v[i - 1]) && q == 0 && p < std::get<2>(v[i - 1])) unsorted++;  // build payload = input position
+        xr ^= orc_mix64(h ^ orc_mix64(k ^ orc_mix64(p)));
+        xw ^= orc_mix64((*wants[q])[3 * i] ^ orc_mix64((*wants[q])[3 * i + 1] ^ orc_mix64((*wants[q])[3 * i + 2])));
+      }
+      if (xr != xw) unsorted++;  // same multiset of rows
+    }
+    if (unsorted) {
+      std::printf("FAIL HashMergeJoin2 nb=%llu np=%llu mode=%d: caller buffers not sorted in place (%d)\n",
+                  (unsigned long long)nb, (unsigned long long)np, mode, unsorted);
+      return 1;
+    }
+  }
   hmj.clear();
   return hmj.begin() != hmj.end();
+}
+
+// HashMergeJoin2 over tuples the GPU cannot move (std::string keys): the buffers are permuted on the host into
+// the order hmj_argsort_u64_host computes; same contract (sorted by hash afterwards, every key pairs once).
+static int run_prehashed_string_case(const std::vector<std::string>& words, int n) {
+  typedef std::vector<std::tuple<std::size_t, std::string, uint64_t>> HashStrVec;
+  StrKeyValVec a = hmj_strgen::create_strvec(n, words, 5), b = hmj_strgen::create_strvec(n, words, 6);
+  HashStrVec r(n), s(n);
+  std::hash<std::string> h;
+  uint64_t want_sum = 0;
+  for (int i = 0; i < n; i++) {
+    r[i] = std::make_tuple(h(a[i].first), a[i].first, a[i].second);
+    s[i] = std::make_tuple(h(b[i].first), b[i].first, b[i].second);
+    want_sum += a[i].second + b[i].second;
+  }
+  HashMergeJoin2<HashStrVec::iterator, HashStrVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), 2);
+  uint64_t cnt = 0, sum = 0;
+  for (auto t : hmj) {
+    sum += *std::get<1>(t) + *std::get<2>(t);
+    cnt++;
+  }
+  int bad = 0;
+  for (int i = 1; i < n; i++)
+    if (std::get<0>(r[i]) < std::get<0>(r[i - 1]) || std::get<0>(s[i]) < std::get<0>(s[i - 1])) bad++;
+  for (int i = 0; i < n; i++)
+    if (std::get<0>(r[i]) != h(std::get<1>(r[i])) || std::get<0>(s[i]) != h(std::get<1>(s[i]))) bad++;  // rows stayed whole
+  if (cnt != (uint64_t)n || sum != want_sum || bad) {
+    std::printf("FAIL HashMergeJoin2<string> n=%d: count=%llu sum=%llu want %llu, %d order errors\n", n,
+                (unsigned long long)cnt, (unsigned long long)sum, (unsigned long long)want_sum, bad);
+    return 1;
+  }
+  return 0;
 }
 
 int main(int argc, char** argv) {
@@ -250,6 +309,8 @@ int main(int argc, char** argv) {
     const std::vector<std::string> words = hmj_strgen::load_words(words_path);
     const int sizes[] = {2, 1000, 1 << 12, 1 << 16, 1 << 18, 1000000};
     for (int n : sizes) run_strgen_case(words, n);
+    fails += run_prehashed_string_case(words, 1000);
+    fails += run_prehashed_string_case(words, 70000);
   }
   std::printf(fails ? "FAILED\n" : "all drop-in cases passed\n");
   return fails ? 1 : 0;
