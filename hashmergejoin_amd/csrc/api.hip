@@ -355,6 +355,7 @@ int check_rel(hmj_ctx* c, const void* p, uint64_t n, const char* name) {
 constexpr int kRetryNoWinOrdered = 1003;  // internal: window + sort ordered path cannot index the result -> prefix rule
 constexpr int kRetryNoFastWrite = 1002;  // internal: unique-key write mode gave up -> general materialise
 constexpr int kRetryNoSlab = 1001;    // internal: the slab path gave up (skew) -> exact path
+constexpr int kRetryNoSlabProbe = 1004;  // internal: the probe-side slab partitioning overflowed -> exact path
 constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-planned without the sampled prefix
 
 // The ordered epilogue.  order_kernel sorts every partition's rows from the unsorted columns (c->out_*) into
@@ -509,7 +510,8 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
 
 int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                      uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix,
-                     bool allow_slab, bool allow_fast_write, bool allow_win_ordered, bool prefix_unsafe) {
+                     bool allow_slab, bool allow_fast_write, bool allow_win_ordered, bool prefix_unsafe,
+                     bool allow_slab_probe) {
   int rc;
   if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
   std::memset(out, 0, sizeof(*out));
@@ -783,6 +785,70 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     return HMJ_OK;
   }
   for (hipEvent_t ev : c->arrive_ev) HIP_TRY(hipStreamWaitEvent(c->stream, ev, 0));  // probe rows still on the links
+  // ---- probe-heavy count joins (BASELINE configs[4]: 2^24 build rows, 2^30 probe rows): the build side is
+  // small and was partitioned exactly above; the probe side -- almost all of the bytes -- takes the
+  // histogram-free slab partitioning (32 instead of 48 B per row and pass) and the generic kernel reads a
+  // partition's KB slab pieces as its KB probe slices.  Skewed probe keys overflow a slab: exact path.
+  {
+    hmj::SlabGeom gp;
+    const u32 kb = pass_bits[0] < 7 ? (512u >> pass_bits[0]) : 4u;  // 2^bits_a * KB >= 512 pass-B workers
+    if (c->slab_probe_cooldown > 0 && allow_slab_probe) c->slab_probe_cooldown--;
+    if (allow_slab_probe && c->slab_mode && c->slab_probe_cooldown == 0 && !materialize && !probe_fits && Q == 1 && passes == 2 &&
+        pass_bits[0] <= 8 && pass_bits[1] <= 8 && np >= c->slab_min_rows && (u64)np >= 4ull * nb &&
+        hmj::slab_geometry(np, pass_bits[0], pass_bits[1], &gp, kb, (double)np / (double)(nb ? nb : 1))) {  // (a foreign-key
+      // probe side repeats every key np / nb times: the slabs are sized for that spread)
+      const int ba = pass_bits[0], bb = pass_bits[1];
+      if ((rc = ensure_dev(c, c->slab_a, gp.rows_a * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_a, ((size_t)gp.WA << ba) * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->slab_bs, gp.rows_b * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * kb * 4)) != HMJ_OK) return rc;
+      u64* acc = (u64*)c->accum.p;
+      int sp = span_begin(c, K_SCATTER, 1, 0);
+      HIP_TRY(hmj::launch_slab_a(S, np, low, ba, gp, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
+      span_end(c, sp);
+      sp = span_begin(c, K_SCATTER, 1, 1);
+      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, gp, c->slab_bs.p, (u32*)c->cnt_bs.p,
+                                 acc, c->stream));
+      span_end(c, sp);
+      c->timing.bytes_scatter += 2 * 32ull * np;
+      c->timing.path |= HMJ_PATH_SLAB_PROBE;
+      hmj::ProbeArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.R = Rp;
+      a.r_off = (const u32*)c->r_off.p;
+      a.S = c->slab_bs.p;
+      a.s_cnt = (const u32*)c->cnt_bs.p;
+      a.s_cap = gp.CB;
+      a.P = P;
+      a.Q = kb;
+      a.accum = acc;
+      c->timing.n_probe_items = P * kb;
+      if (first) {  // one bit per probe row SLOT of the slab layout
+        const size_t mb = ((size_t)gp.rows_b / 32 + 1) * 4;
+        if ((rc = ensure_dev(c, c->matched, mb)) != HMJ_OK) return rc;
+        a.matched = (u32*)c->matched.p;
+        HIP_TRY(hipMemsetAsync(c->matched.p, 0, mb, c->stream));
+      }
+      sp = span_begin(c, K_PROBE_COUNT, -1);
+      HIP_TRY(hmj::launch_probe(a, 0, first, extra, hmj::probe_default_grid(c->num_cus), c->stream));
+      span_end(c, sp);
+      c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
+      u64* hh = (u64*)c->h_accum.p;
+      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // a probe slab overflowed (skewed probe keys)
+        c->slab_probe_cooldown = 8;
+        return kRetryNoSlabProbe;
+      }
+      out->n_matches = hh[hmj::ACC_N];
+      out->sum_r = hh[hmj::ACC_SUM_R];
+      out->sum_s = hh[hmj::ACC_SUM_S];
+      out->xor_fold = hh[hmj::ACC_XOR];
+      out->mix_sum = hh[hmj::ACC_MIX];
+      out->sum_probe_all = hh[hmj::ACC_SUM_P];
+      return HMJ_OK;
+    }
+  }
   if ((rc = partition_relation(c, S, np, c->sbuf, low, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
   s = span_begin(c, K_OFFSETS, -1);
   HIP_TRY(hmj::launch_part_offsets(Sp, np, low, B, (u32*)c->s_off.p, c->stream));
@@ -997,11 +1063,21 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
 
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
-  bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true, prefix_unsafe = false;
-  for (int attempt = 0; attempt < 6; attempt++) {
+  bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true, prefix_unsafe = false, slab_probe = true;
+  for (int attempt = 0; attempt < 7; attempt++) {
     int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab, fast_write,
-                              win_ordered, prefix_unsafe);
-    if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite || rc == kRetryNoWinOrdered) {
+                              win_ordered, prefix_unsafe, slab_probe);
+    if (c->trace)
+      std::fprintf(stderr, "[hmj] join nb=%llu np=%llu flags=%#x attempt %d: rc=%d bits=%d passes=%d path=%#x prefix=%d low=%d items=%u%s\n",
+                   (unsigned long long)n_build, (unsigned long long)n_probe, flags, attempt, rc, c->timing.radix_bits,
+                   c->timing.radix_passes, c->timing.path, c->timing.key_prefix_bits, c->timing.key_window_low,
+                   c->timing.n_probe_items,
+                   rc == kRetryNoSlab ? " -> retry without the slab path (a slab overflowed)"
+                   : rc == kRetryNoPrefix ? " -> retry: a row outside the sampled key prefix"
+                   : rc == kRetryNoFastWrite ? " -> retry without the unique-key write mode"
+                   : rc == kRetryNoWinOrdered ? " -> retry without the key window"
+                   : rc == kRetryNoSlabProbe ? " -> retry without probe-side slabs (one overflowed)" : "");
+    if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite || rc == kRetryNoWinOrdered || rc == kRetryNoSlabProbe) {
       // forget the abandoned attempt's phase spans (the enclosing total / h2d spans stay)
       std::vector<Span> keep;
       for (const Span& sp : c->spans)
@@ -1009,6 +1085,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
       c->spans.swap(keep);
       std::memset(&c->timing, 0, sizeof(c->timing));
       if (rc == kRetryNoSlab) slab = false;
+      else if (rc == kRetryNoSlabProbe) slab_probe = false;
       else if (rc == kRetryNoFastWrite) fast_write = false;
       else if (rc == kRetryNoWinOrdered) win_ordered = false;
       else if (!prefix_unsafe && win_ordered) prefix_unsafe = true;  // outliers: same plan + final sort by key
@@ -1056,6 +1133,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
     if (l >= 16 && l <= 31) c->slab_min_rows = 1u << l;
   }
   if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
+  if (const char* e = getenv("HMJ_TRACE")) c->trace = atoi(e) != 0;
 #ifdef HMJ_DEV
   if (const char* e = getenv("HMJ_DEBUG_ABLATE")) c->dev_ablate = (u32)atoi(e);
 #endif

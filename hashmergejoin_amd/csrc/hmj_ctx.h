@@ -71,8 +71,10 @@ struct hmj_ctx {
   u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
                                  // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
+  int slab_probe_cooldown = 0;  // the same for the probe-side-only slab partitioning of probe-heavy count joins
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;
+  bool trace = false;  // HMJ_TRACE=1: one stderr line per join attempt (plan, paths taken, why an attempt was retried)
 #ifdef HMJ_DEV
   u32 dev_ablate = 0;  // developer builds: HMJ_DEBUG_ABLATE, read once at hmj_create
 #endif

@@ -53,7 +53,9 @@ struct SlabGeom {
   u32 WA, rpw, CA, CB, KB;
   u64 rows_a, rows_b;
 };
-bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g);
+// kb: pieces per final partition (0 = 4, what the pipelined probe kernel reads)
+// fan: expected rows per distinct key (>= 1): widens the slabs by sqrt(fan) standard deviations
+bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb = 0, double fan = 1.0);
 hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a,
                          u32* cnt_a, u64* accum, hipStream_t st, u32 w_begin = 0, u32 w_end = 0xFFFFFFFFu);
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,

@@ -80,9 +80,16 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
     const u64 w = a.item_list ? (u64)a.item_list[wi] : wi;
     const u32 p = (u32)(w / a.Q), q = (u32)(w % a.Q);
     const u32 rb = a.r_off[p], nb = (a.r_end ? a.r_end[p] : a.r_off[p + 1]) - rb;
-    const u32 sb0 = a.s_off[p], np0 = (a.s_end ? a.s_end[p] : a.s_off[p + 1]) - sb0;
-    const u32 lo = (u32)((u64)np0 * q / a.Q), hi = (u32)((u64)np0 * (q + 1) / a.Q);
-    const u32 sb = sb0 + lo, np = hi - lo;  // this item's slice of partition p's probe rows
+    u32 sb, np;  // this item's slice of partition p's probe rows
+    if (a.s_cnt) {  // probe side in the slab layout (radix.hip): slice q is the partition's q-th piece
+      sb = (u32)w * a.s_cap;
+      np = a.s_cnt[w];
+    } else {
+      const u32 sb0 = a.s_off[p], np0 = (a.s_end ? a.s_end[p] : a.s_off[p + 1]) - sb0;
+      const u32 lo = (u32)((u64)np0 * q / a.Q), hi = (u32)((u64)np0 * (q + 1) / a.Q);
+      sb = sb0 + lo;
+      np = hi - lo;
+    }
     if (nb == 0 || np == 0) {
       if (EXTRA && MODE != 2)
         for (u32 j = tid; j < np; j += PB_THREADS) acc_p += S[sb + j].val;

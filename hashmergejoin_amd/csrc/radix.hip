@@ -769,13 +769,14 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 #ifndef HMJ_B_NT
 #define HMJ_B_NT 0    // nontemporal loads of the A-slab rows
 #endif
-constexpr int SLAB_KB = 4;        // pass-B workers per bucket == pieces per final partition
+constexpr int SLAB_KB = 4;        // pass-B workers per bucket == pieces per final partition (the pipelined probe
+                                  // kernel reads exactly 4; the generic kernel takes any KB as its probe slices)
 constexpr int SLAB_MAXSEG = 512;  // A-slabs one pass-B worker gathers (WA / KB <= 512)
 
 template <int THREADS, int MAXD, bool HI>
 __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_b_kernel(
     const Tup* __restrict__ slab_a, const u32* __restrict__ cnt_a, u32 CA, u32 WA, int bits_a, int shift,
-    int bits, Tup* __restrict__ slab_b, u32 CB, u32* __restrict__ cnt_b, u64* __restrict__ accum) {
+    int bits, Tup* __restrict__ slab_b, u32 CB, u32* __restrict__ cnt_b, u64* __restrict__ accum, u32 KB) {
   typedef WcSmem<THREADS, MAXD> Smem;
   constexpr int TILE = Smem::TILE;
   static_assert(SLAB_MAXSEG <= THREADS, "one A-slab count per thread in the prologue scan");
@@ -785,8 +786,8 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   u32* pre = limit + MAXD;                                       // SLAB_MAXSEG + 1 prefix sums
   const u32 D = 1u << bits, mask = D - 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 dA = blockIdx.x / SLAB_KB, k = blockIdx.x % SLAB_KB;
-  const u32 w0 = (u32)((u64)k * WA / SLAB_KB), w1 = (u32)((u64)(k + 1) * WA / SLAB_KB), ns = w1 - w0;
+  const u32 dA = blockIdx.x / KB, k = blockIdx.x % KB;
+  const u32 w0 = (u32)((u64)k * WA / KB), w1 = (u32)((u64)(k + 1) * WA / KB), ns = w1 - w0;
   {
     const u32 c = ((u32)tid < ns) ? cnt_a[dA * WA + w0 + tid] : 0;
     u32 tot;
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     if ((u32)tid < ns) pre[tid] = ex;
     if (tid == 0) pre[ns] = tot;
     if ((u32)tid < D) {
-      const u32 base = ((((u32)tid << bits_a) | dA) * SLAB_KB + k) * CB;
+      const u32 base = ((((u32)tid << bits_a) | dA) * KB + k) * CB;
       sm.cflush[tid] = base;
       limit[tid] = base + CB;
       sm.pend[tid] = 0;
@@ -952,7 +953,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   stamps.flush();
 #endif
   if ((u32)tid < D) {
-    const u32 pid = (((u32)tid << bits_a) | dA) * SLAB_KB + k;
+    const u32 pid = (((u32)tid << bits_a) | dA) * KB + k;
     cnt_b[pid] = sm.cflush[tid] + sm.pend[tid] - pid * CB;
   }
   if (ovf) atomicOr(&accum[ACC_ERR], ERR_SLAB);
@@ -1053,24 +1054,26 @@ static hipError_t launch_slab_a_t(const void* in, u32 n, int shift, int bits, u3
 
 template <bool HI>
 static hipError_t launch_slab_b_t(const void* slab_a, const u32* cnt_a, u32 CA, u32 WA, int bits_a, int shift,
-                                  int bits, void* slab_b, u32 CB, u32* cnt_b, u64* accum, hipStream_t st) {
+                                  int bits, void* slab_b, u32 CB, u32* cnt_b, u64* accum, hipStream_t st, u32 KB) {
   typedef WcSmem<512, 256> Smem;
   const size_t smem = sizeof(Smem) + (256 + SLAB_MAXSEG + 1) * sizeof(u32);
   static SmemAttrOnce attr_once;
   if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI>), (size_t)smem); e != hipSuccess) return e;
-  hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI>), dim3((1u << bits_a) * SLAB_KB), dim3(512), smem, st,
+  hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI>), dim3((1u << bits_a) * KB), dim3(512), smem, st,
                      static_cast<const Tup*>(slab_a), cnt_a, CA, WA, bits_a, shift, bits,
-                     static_cast<Tup*>(slab_b), CB, cnt_b, accum);
+                     static_cast<Tup*>(slab_b), CB, cnt_b, accum, KB);
   return hipGetLastError();
 }
 
 // Geometry of the slab path for a relation of n rows split by bits_a then bits_b (both <= 8).
 // cap(m) = m + 8 sqrt(m) + 24 rounded up to whole 128-byte lines.
-static u32 slab_cap(double mean) {
-  double c = mean + 8.0 * __builtin_sqrt(mean) + 24.0;
+// fan: rows per distinct key (a probe side drawn from a smaller key domain): a digit's row count then varies
+// like fan * (number of its keys), i.e. sigma = sqrt(fan * mean) instead of sqrt(mean)
+static u32 slab_cap(double mean, double fan) {
+  double c = mean + 8.0 * __builtin_sqrt(fan * mean) + 24.0;
   return ((u32)c + 8) & ~7u;
 }
-bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g) {
+bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fan) {
   const u32 tile = 2048;
   u64 tiles = ((u64)n + tile - 1) / tile;
   u64 max_workers = 2048;
@@ -1081,12 +1084,14 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g) {
   if (tpw == 0) tpw = 1;
   g->WA = (u32)((tiles + tpw - 1) / tpw);
   g->rpw = (u32)(tpw * tile);
-  g->KB = SLAB_KB;
-  if (g->WA < (u32)SLAB_KB || (g->WA + SLAB_KB - 1) / SLAB_KB > (u32)SLAB_MAXSEG) return false;
-  g->CA = slab_cap((double)g->rpw / (double)(1u << bits_a));
-  g->CB = slab_cap((double)n / (double)(1u << bits_a) / SLAB_KB / (double)(1u << bits_b));
+  if (kb == 0) kb = SLAB_KB;
+  g->KB = kb;
+  if (g->WA < kb || (g->WA + kb - 1) / kb > (u32)SLAB_MAXSEG) return false;
+  if (fan < 1.0) fan = 1.0;
+  g->CA = slab_cap((double)g->rpw / (double)(1u << bits_a), fan);
+  g->CB = slab_cap((double)n / (double)(1u << bits_a) / (double)kb / (double)(1u << bits_b), fan);
   const u64 rows_a = (u64)(1u << bits_a) * g->WA * g->CA;
-  const u64 rows_b = (u64)(1u << (bits_a + bits_b)) * SLAB_KB * g->CB;
+  const u64 rows_b = (u64)(1u << (bits_a + bits_b)) * kb * g->CB;
   g->rows_a = rows_a;
   g->rows_b = rows_b;
   return rows_a < 0xFFFFFFF0ull && rows_b < 0xFFFFFFF0ull;
@@ -1102,9 +1107,9 @@ hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabG
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
                          const SlabGeom& g, void* slab_b, u32* cnt_b, u64* accum, hipStream_t st) {
   return shift >= 32 ? launch_slab_b_t<true>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
-                                             cnt_b, accum, st)
+                                             cnt_b, accum, st, g.KB)
                      : launch_slab_b_t<false>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
-                                              cnt_b, accum, st);
+                                              cnt_b, accum, st, g.KB);
 }
 
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st) {

@@ -607,6 +607,39 @@ def test_skewed_build_side_config5(ex, H, oracle, log2b, log2p, log2dom):
     del R, S
 
 
+def test_probe_heavy_count_join_partitions_the_probe_side_in_slabs(ex, H, oracle):
+    # The shape of BASELINE configs[4] at a size the oracle checks: a build side with heavily duplicated (Zipf)
+    # keys, a probe side many times larger.  The build side takes the exact path, the probe side the
+    # histogram-free slab partitioning, and the generic kernel reads a partition's slab pieces as its probe
+    # slices.  Counts, first-wins and the hashjoin_bench.cc:92-96 sum against the oracle; a skewed PROBE side
+    # overflows a slab and must fall back to the exact path with the same answers.
+    import torch
+
+    nb, npb, dom = 1 << 22, (1 << 24) + 777, 1 << 22
+    thr = _zipf_thresholds(dom)
+    thr_d = torch.from_numpy(thr.view(np.int64).copy()).cuda()
+    # (a) Zipf build side with duplicate keys x uniform probe side; (b) unique build keys x Zipf-skewed probe side
+    # (a hot foreign key: its slab overflows) -- the cross product of two skewed sides would be 10^11 rows
+    for skewed_probe in (False, True):
+        R = ex.gen_build(nb) if skewed_probe else ex.gen_from_cdf(nb, thr_d)
+        S = ex.gen_from_cdf(npb, thr_d, zseed=0x5EED) if skewed_probe else ex.gen_uniform_domain(npb, dom)
+        Rn, Sn = to_np(R), to_np(S)
+        ck, _ = oracle.equijoin(Rn, Sn, cap=0)
+        ckf, _ = oracle.equijoin(Rn, Sn, first_wins=True, cap=0)
+        for fl, want in ((0, ck), (H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE, ckf), (H.HMJ_CHECKSUM, ck)):
+            r = ex.join_device(R, S, fl)
+            t = ex.last_timing()
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (want["n_matches"], want["sum_r"], want["sum_s"]), (skewed_probe, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck
+            if fl & H.HMJ_SUM_PROBE:
+                assert int(r.sum_probe_all) == int(Sn[:, 1].sum(dtype=np.uint64))
+            # (a): really the probe-side slab path; (b): the hot keys' slabs overflowed, the exact path answered
+            assert bool(t["path"] & H.HMJ_PATH_SLAB_PROBE) == (not skewed_probe), (skewed_probe, fl, t)
+        del R, S
+    ex.release_result()
+
+
 @pytest.mark.parametrize("n", [0, 1, 5, 4095, 12345, 1 << 16, (1 << 20) + 3])
 def test_full_radix_sort_matches_reference_sort(ex, oracle, n):
     # hmj_sort_u64_device vs the restated radix_int_non_inplace (radix_sort.h:452-522; the call
