@@ -54,6 +54,13 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
     if (e != hipSuccess) return fail(c, HMJ_E_HIP, "hipFree", e);
   }
   size_t want = bytes + (bytes >> 4) + 256;  // a little headroom against regrowth
+#ifdef HMJ_DEV
+  if (const char* e = getenv("HMJ_ALLOC_PAD_KB")) want += (size_t)atoll(e) << 10;       // placement experiments
+  if (const char* e = getenv("HMJ_ALLOC_ROUND_MB")) {
+    const size_t g = (size_t)atoll(e) << 20;
+    if (g) want = (want + g - 1) / g * g;
+  }
+#endif
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
     b.p = nullptr;

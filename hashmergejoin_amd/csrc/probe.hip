@@ -338,6 +338,9 @@ constexpr int FP_ROWS = 5;  // rows per thread per side
 #ifndef BIG_LOG_NB
 #define BIG_LOG_NB 13
 #endif
+#ifndef HMJ_PROBE_PIECES
+#define HMJ_PROBE_PIECES 1  // slab layout, count mode: rows are taken piece by piece (no flattening arithmetic)
+#endif
 
 template <int THREADS, int LOG_NB>
 struct FastSmem {
@@ -387,6 +390,25 @@ __device__ __forceinline__ void fp_load_slab(Tup (&t)[FP_ROWS], const Tup* __res
   }
 }
 
+// Slab layout, count mode: which (thread, slot) holds which row of a partition does not matter to a count join,
+// so instead of flattening the 4 pieces (three compares and selects per row) every quarter of the workgroup
+// takes one piece: thread tid reads rows (tid mod T/4) + k * T/4 of piece tid / (T/4).  A wave lies inside one
+// quarter, so its piece -- base and row count -- is wave-uniform and the address is base + row.  A piece may
+// hold up to FP_ROWS * T/4 rows (1280; the slabs' capacity is mean + 8 sigma = 1304 at the headline size:
+// beyond 1280 the partition is reported like any other that does not fit).
+template <int THREADS>
+__device__ __forceinline__ void fp_load_pieces(Tup (&t)[FP_ROWS], const Tup* __restrict__ base, u32 cap, u32 cnt_mine, int tid) {
+  constexpr int QT = THREADS / 4;
+  const u32 g = (u32)tid / QT, l = (u32)tid % QT;
+  const Tup* __restrict__ piece = base + (u64)g * cap;
+  const u32 last = cnt_mine ? cnt_mine - 1 : 0;
+#pragma unroll
+  for (int k = 0; k < FP_ROWS; k++) {
+    const u32 r = l + (u32)k * QT;
+    t[k] = piece[r < last ? r : last];  // clamped, unpredicated: the five loads issue back to back
+  }
+}
+
 // PCOUNT: also store each partition's match count in a.part_count[p] (first pass of materialising).
 // SLAB: the partitioned relations are in the histogram-free slab layout (radix.hip, slab kernels);
 //       a partition that does not fit the pipeline raises ERR_SLAB (the caller re-runs the exact path).
@@ -400,6 +422,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     ProbeArgs a, u32* __restrict__ irregular, u32* __restrict__ n_irregular) {
   typedef FastSmem<THREADS, LOG_NB> Smem;
   constexpr u32 CAP = Smem::CAP, NB = 1u << LOG_NB;
+  constexpr bool PIECES = SLAB && OUT == 0 && !PCOUNT && HMJ_PROBE_PIECES;  // rows are taken piece by piece (see fp_load_pieces)
+  constexpr u32 QT = THREADS / 4, PIECE_CAP = FP_ROWS * QT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
@@ -428,6 +452,9 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
   Tup br[FP_ROWS], pr[FP_ROWS], pq[FP_ROWS];
   // slab layout: piece prefix sums of the current (r1..3, s1..3) and next (…n) partition
   u32 r1 = 0, r2 = 0, r3 = 0, s1 = 0, s2 = 0, s3 = 0, r1n = 0, r2n = 0, r3n = 0, s1n = 0, s2n = 0, s3n = 0;
+  // PIECES: rows of this thread's quarter's piece, current (rm, sm_) and next (rmn, smn) partition
+  u32 rm = 0, sm_ = 0, rmn = 0, smn = 0;
+  const u32 my_piece = (u32)tid / QT;
   bool slab_bad = false;
   if (p < P) {
     if (SLAB) {
@@ -436,13 +463,25 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       r1 = rc[0]; r2 = r1 + rc[1]; r3 = r2 + rc[2]; nb = r3 + rc[3];
       s1 = sc[0]; s2 = s1 + sc[1]; s3 = s2 + sc[2]; np = s3 + sc[3];
       if (nb > CAP || np > CAP) slab_bad = true;
+      if (PIECES) {  // (scalar loads + selects: indexing by the piece number would be a per-lane global load)
+        rm = my_piece == 0 ? rc[0] : my_piece == 1 ? rc[1] : my_piece == 2 ? rc[2] : rc[3];
+        sm_ = my_piece == 0 ? sc[0] : my_piece == 1 ? sc[1] : my_piece == 2 ? sc[2] : sc[3];
+        if (rc[0] > PIECE_CAP || rc[1] > PIECE_CAP || rc[2] > PIECE_CAP || rc[3] > PIECE_CAP || sc[0] > PIECE_CAP ||
+            sc[1] > PIECE_CAP || sc[2] > PIECE_CAP || sc[3] > PIECE_CAP) {
+          slab_bad = true;
+          nb = CAP + 1;  // not "regular"
+        }
+      }
     } else {
       rb = r_off[p]; nb = r_end[p] - rb;
       sb = s_off[p]; np = s_end[p] - sb;
     }
     regular = nb && np && nb <= CAP && np <= CAP;
     if (regular) {
-      if (SLAB) {
+      if (PIECES) {
+        fp_load_pieces<THREADS>(br, R + (u64)p * 4 * a.r_cap, a.r_cap, rm, tid);
+        fp_load_pieces<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, sm_, tid);
+      } else if (SLAB) {
         fp_load_slab<THREADS>(br, R + (u64)p * 4 * a.r_cap, a.r_cap, r1, r2, r3, nb, tid);
         if (OUT == 0) fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
       } else {
@@ -462,6 +501,15 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
         r1n = rc[0]; r2n = r1n + rc[1]; r3n = r2n + rc[2]; nb2 = r3n + rc[3];
         s1n = sc[0]; s2n = s1n + sc[1]; s3n = s2n + sc[2]; np2 = s3n + sc[3];
         if (nb2 > CAP || np2 > CAP) slab_bad = true;
+        if (PIECES) {
+          rmn = my_piece == 0 ? rc[0] : my_piece == 1 ? rc[1] : my_piece == 2 ? rc[2] : rc[3];
+          smn = my_piece == 0 ? sc[0] : my_piece == 1 ? sc[1] : my_piece == 2 ? sc[2] : sc[3];
+          if (rc[0] > PIECE_CAP || rc[1] > PIECE_CAP || rc[2] > PIECE_CAP || rc[3] > PIECE_CAP || sc[0] > PIECE_CAP ||
+              sc[1] > PIECE_CAP || sc[2] > PIECE_CAP || sc[3] > PIECE_CAP) {
+            slab_bad = true;
+            nb2 = CAP + 1;
+          }
+        }
       } else {
         rb2 = r_off[pn]; nb2 = r_end[pn] - rb2;
         sb2 = s_off[pn]; np2 = s_end[pn] - sb2;
@@ -470,7 +518,9 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     }
     if (OUT == 0) {
       if (regular2) {  // next partition's probe rows, one whole partition ahead
-        if (SLAB)
+        if (PIECES)
+          fp_load_pieces<THREADS>(pq, S + (u64)pn * 4 * a.s_cap, a.s_cap, smn, tid);
+        else if (SLAB)
           fp_load_slab<THREADS>(pq, S + (u64)pn * 4 * a.s_cap, a.s_cap, s1n, s2n, s3n, np2, tid);
         else
           fp_load<THREADS>(pq, S + sb2, np2, tid);
@@ -502,7 +552,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 i = k * THREADS + tid;
           old[k] = tag | NIL;
-          if (i < nb) {
+          if (PIECES ? ((u32)tid % QT + (u32)k * QT < rm) : (i < nb)) {
             if (a.pfx_shift && (br[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             sm.key[i] = br[k].key;
             sm.val[i] = br[k].val;
@@ -512,14 +562,16 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 i = k * THREADS + tid;
-          if (i < nb) sm.next[i] = ((old[k] >> 16) == epoch) ? (u16)old[k] : (u16)NIL;
+          if (PIECES ? ((u32)tid % QT + (u32)k * QT < rm) : (i < nb)) sm.next[i] = ((old[k] >> 16) == epoch) ? (u16)old[k] : (u16)NIL;
         }
       } else {  // developer builds only (HMJ_ABLATE): stream the rows, no LDS work
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) acc_r += br[k].key;
       }
       if (regular2) {  // next partition's build rows
-        if (SLAB)
+        if (PIECES)
+          fp_load_pieces<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, rmn, tid);
+        else if (SLAB)
           fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
         else
           fp_load<THREADS>(br, R + rb2, nb2, tid);
@@ -536,7 +588,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
           cur[k] = NIL;
           cnt[k] = 0;
           first[k] = OUT == 2 ? NIL : 0;
-          if (j < np) {
+          if (PIECES ? ((u32)tid % QT + (u32)k * QT < sm_) : (j < np)) {
             if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             if (OUT >= 1 && (a.extra & 1u)) acc_p += pr[k].val;
             const u32 hv = sm.head[fast_hash<LOG_NB>(pr[k].key)];
@@ -674,7 +726,9 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       }
       if (OUT != 1 && !SLAB && tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
       if (regular2) {
-        if (SLAB)
+        if (PIECES)
+          fp_load_pieces<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, rmn, tid);
+        else if (SLAB)
           fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
         else
           fp_load<THREADS>(br, R + rb2, nb2, tid);
@@ -686,6 +740,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     }
     p = pn; rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
     r1 = r1n; r2 = r2n; r3 = r3n; s1 = s1n; s2 = s2n; s3 = s3n;
+    rm = rmn; sm_ = smn;
   }
   if (SLAB && slab_bad && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_SLAB);
   if (OUT == 1 && __any(giveup) && (tid & 63) == 0) atomicOr(&a.accum[ACC_ERR], ERR_FASTPATH);

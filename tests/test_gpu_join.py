@@ -755,9 +755,21 @@ def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
     assert int(r.n_matches) == nref == 12345 and np.array_equal(got, tref)
 
 
-def test_slab_path_parity_and_fallback(ex, H, oracle):
+@pytest.fixture
+def ex_fresh(H):
+    # an executor of its own: after a slab overflow a ctx skips the slab path for its next 8 joins, so tests that
+    # assert "the slab path ran" must not inherit that state from whatever ran before them
+    os.environ["HMJ_SLAB_MIN_LOG2"] = "22"
+    e = H.Executor(0)
+    del os.environ["HMJ_SLAB_MIN_LOG2"]
+    yield e
+    e.close()
+
+
+def test_slab_path_parity_and_fallback(ex_fresh, H, oracle):
     # The histogram-free slab path (plain count joins, >= 2^22 rows per side) against the CPU oracle,
     # including ragged sizes, a probe side of a different size, and misses.
+    ex = ex_fresh
     for nb, npb, miss in [(1 << 22, 1 << 22, 0), ((1 << 22) + 12345, 4500000 - 777, 3)]:
         B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=miss)
         ck, _ = oracle.equijoin(B, P, cap=0)
