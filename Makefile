@@ -7,7 +7,7 @@ CSRC     := hashmergejoin_amd/csrc
 OBJS     := $(CSRC)/radix.o $(CSRC)/probe.o $(CSRC)/gen.o $(CSRC)/api.o $(CSRC)/exchange.o
 LIB      := hashmergejoin_amd/libhmj_hip.so
 
-all: $(LIB) oracle cpptest examples/hashjoin_bench_hip
+all: $(LIB) oracle cpptest examples/hashjoin_bench_hip examples/exchange_join
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/hmj_dev.h $(CSRC)/hmj_launch.h $(CSRC)/hmj_ctx.h include/hmj.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -26,6 +26,10 @@ tests/cpp/test_dropin: tests/cpp/test_dropin.cc include/hashmergejoin_hip.hpp in
 
 examples/hashjoin_bench_hip: examples/hashjoin_bench_hip.cc include/hashmergejoin_hip.hpp include/hmj.h $(LIB)
 	g++ -std=c++11 -O2 -Wall -Iinclude $< -o $@ -Lhashmergejoin_amd -lhmj_hip \
+	  -Wl,-rpath,'$$ORIGIN/../hashmergejoin_amd' -Wl,-rpath,/opt/rocm/lib -pthread
+
+examples/exchange_join: examples/exchange_join.cc include/hmj.h $(LIB)
+	g++ -std=c++11 -O2 -Wall -Iinclude $< -o $@ -Lhashmergejoin_amd -lhmj_hip -L/opt/rocm/lib -lamdhip64 \
 	  -Wl,-rpath,'$$ORIGIN/../hashmergejoin_amd' -Wl,-rpath,/opt/rocm/lib -pthread
 
 clean:

@@ -894,10 +894,6 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
           }
         }
       }
-#ifdef HMJ_B_ALIGN_HACK  // timing experiment only (wrong rows): what would line-aligned wave loads cost?
-#pragma unroll
-      for (int r = 0; r < WC_ITEMS; r++) off[r] = (off[r] & ~63ull) | (u64)lane;
-#endif
 #pragma unroll
       for (int r = 0; r < WC_ITEMS; r++) t[r] = HMJ_B_NT ? load_stream(&bucket[off[r]]) : bucket[off[r]];
     };
