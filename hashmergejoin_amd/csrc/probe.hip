@@ -490,6 +490,29 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       }
     }
   }
+  // The prefetches of the NEXT partition are issued unconditionally: when there is no next partition, or it does
+  // not fit the pipeline, the same five loads read one dummy row (the accumulator block) instead.  Inside an
+  // `if` the compiler cannot count them, and every wait for older rows becomes s_waitcnt vmcnt(0) -- i.e. the
+  // probe walk of partition p waited for partition p + G's rows, which had only just been requested.
+  const Tup* __restrict__ dummy = reinterpret_cast<const Tup*>(a.accum);
+  auto load_build = [&](Tup (&t)[FP_ROWS], bool ok, u32 pp, u32 rb_, u32 nb_, u32 q1, u32 q2, u32 q3, u32 mine) {
+    if (PIECES)
+      fp_load_pieces<THREADS>(t, ok ? R + (u64)pp * 4 * a.r_cap : dummy, ok ? a.r_cap : 0u, ok ? mine : 1u, tid);
+    else if (SLAB)
+      fp_load_slab<THREADS>(t, ok ? R + (u64)pp * 4 * a.r_cap : dummy, ok ? a.r_cap : 0u, ok ? q1 : 1u, ok ? q2 : 1u,
+                            ok ? q3 : 1u, ok ? nb_ : 1u, tid);
+    else
+      fp_load<THREADS>(t, ok ? R + rb_ : dummy, ok ? nb_ : 1u, tid);
+  };
+  auto load_probe = [&](Tup (&t)[FP_ROWS], bool ok, u32 pp, u32 sb_, u32 np_, u32 q1, u32 q2, u32 q3, u32 mine) {
+    if (PIECES)
+      fp_load_pieces<THREADS>(t, ok ? S + (u64)pp * 4 * a.s_cap : dummy, ok ? a.s_cap : 0u, ok ? mine : 1u, tid);
+    else if (SLAB)
+      fp_load_slab<THREADS>(t, ok ? S + (u64)pp * 4 * a.s_cap : dummy, ok ? a.s_cap : 0u, ok ? q1 : 1u, ok ? q2 : 1u,
+                            ok ? q3 : 1u, ok ? np_ : 1u, tid);
+    else
+      fp_load<THREADS>(t, ok ? S + sb_ : dummy, ok ? np_ : 1u, tid);
+  };
   while (p < P) {
     const u32 pn = __builtin_amdgcn_readfirstlane(p + gridDim.x);  // keep the offsets on the scalar path
     u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
@@ -517,14 +540,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
     }
     if (OUT == 0) {
-      if (regular2) {  // next partition's probe rows, one whole partition ahead
-        if (PIECES)
-          fp_load_pieces<THREADS>(pq, S + (u64)pn * 4 * a.s_cap, a.s_cap, smn, tid);
-        else if (SLAB)
-          fp_load_slab<THREADS>(pq, S + (u64)pn * 4 * a.s_cap, a.s_cap, s1n, s2n, s3n, np2, tid);
-        else
-          fp_load<THREADS>(pq, S + sb2, np2, tid);
-      }
+      load_probe(pq, regular2, pn, sb2, np2, s1n, s2n, s3n, smn);  // next partition's probe rows, a whole partition ahead
     } else if (regular) {  // write mode keeps fewer rows in flight (registers): this partition's probe rows
       if (SLAB)
         fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
@@ -568,14 +584,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) acc_r += br[k].key;
       }
-      if (regular2) {  // next partition's build rows
-        if (PIECES)
-          fp_load_pieces<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, rmn, tid);
-        else if (SLAB)
-          fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
-        else
-          fp_load<THREADS>(br, R + rb2, nb2, tid);
-      }
+      load_build(br, regular2, pn, rb2, nb2, r1n, r2n, r3n, rmn);  // next partition's build rows
       lds_barrier();                                          // table complete
       const u64 n_before = acc_n;
       if (!HMJ_ABLATE(1u)) {
@@ -725,14 +734,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
         }
       }
       if (OUT != 1 && !SLAB && tid == 0 && nb && np) irregular[atomicAdd(n_irregular, 1u)] = p;
-      if (regular2) {
-        if (PIECES)
-          fp_load_pieces<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, rmn, tid);
-        else if (SLAB)
-          fp_load_slab<THREADS>(br, R + (u64)pn * 4 * a.r_cap, a.r_cap, r1n, r2n, r3n, nb2, tid);
-        else
-          fp_load<THREADS>(br, R + rb2, nb2, tid);
-      }
+      load_build(br, regular2, pn, rb2, nb2, r1n, r2n, r3n, rmn);
     }
     if (OUT == 0) {
 #pragma unroll
