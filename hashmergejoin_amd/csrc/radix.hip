@@ -301,6 +301,9 @@ constexpr int WC_LINE = 8;  // rows per 128-byte line
 #define HMJ_WC_PLAN1 0   // 1: one wave plans all digits with wave scans -- measured 40 % SLOWER (the other seven waves
                          // wait 6000 cycles at the next barrier); 0: one thread per digit + block scan
 #endif
+#ifndef HMJ_WC_FULLTILE
+#define HMJ_WC_FULLTILE 1  // slab kernels: whole tiles run the predicate-free instantiation of wc_tile
+#endif
 #ifndef HMJ_WC_NOBAR5
 #define HMJ_WC_NOBAR5 1  // 1: waves zero their own mask slab / counters, no barrier at the end of a tile
 #endif
@@ -738,21 +741,23 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     }
     for (u64 tile = begin; tile < end; tile += TILE) {
       const u32 tile_n = (u32)((end - tile < TILE) ? end - tile : TILE);
-      wc_tile<THREADS, MAXD, HI, false, true>(
-          sm, t, tile_n, slab, shift, mask, D,
-          [&]() {
-            if (tile + TILE < end) {
-              const u64 nt = tile + TILE;
-              const u32 tn = (u32)((end - nt < TILE) ? end - nt : TILE);
-              const Tup* src = in + nt;
+      auto prefetch = [&]() {
+        if (tile + TILE < end) {
+          const u64 nt = tile + TILE;
+          const u32 tn = (u32)((end - nt < TILE) ? end - nt : TILE);
+          const Tup* src = in + nt;
 #pragma unroll
-              for (int r = 0; r < WC_ITEMS; r++) {
-                const u32 q = wbase + r * 64;
-                t[r] = load_stream(&src[q < tn ? q : tn - 1]);
-              }
-            }
-          },
-          limit, &ovf WC_STAMP_PASS);
+          for (int r = 0; r < WC_ITEMS; r++) {
+            const u32 q = wbase + r * 64;
+            t[r] = load_stream(&src[q < tn ? q : tn - 1]);
+          }
+        }
+      };
+      // whole tiles (all but a worker's last) run the predicate-free instantiation
+      if (HMJ_WC_FULLTILE && tile_n == (u32)TILE)
+        wc_tile<THREADS, MAXD, HI, true, true>(sm, t, tile_n, slab, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
+      else
+        wc_tile<THREADS, MAXD, HI, false, true>(sm, t, tile_n, slab, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
     }
     wc_flush_carry(sm, slab, D);
   }
@@ -902,18 +907,19 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     if ((u32)TILE < total) plan(TILE);
     for (u32 tile = 0; tile < total; tile += TILE) {
       const u32 tile_n = (total - tile < (u32)TILE) ? total - tile : (u32)TILE;
-      wc_tile<THREADS, MAXD, HI, false, true>(
-          sm, t, tile_n, slab_b, shift, mask, D,
-          [&]() {
-            if (tile + TILE < total) {
-              issue(tile + TILE);
+      auto prefetch = [&]() {
+        if (tile + TILE < total) {
+          issue(tile + TILE);
 #ifdef HMJ_STAMPS
-              stamps.mark(13);
+          stamps.mark(13);
 #endif
-              if (tile + 2 * TILE < total) plan(tile + 2 * TILE);
-            }
-          },
-          limit, &ovf WC_STAMP_PASS);
+          if (tile + 2 * TILE < total) plan(tile + 2 * TILE);
+        }
+      };
+      if (HMJ_WC_FULLTILE && tile_n == (u32)TILE)
+        wc_tile<THREADS, MAXD, HI, true, true>(sm, t, tile_n, slab_b, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
+      else
+        wc_tile<THREADS, MAXD, HI, false, true>(sm, t, tile_n, slab_b, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
     }
 #else
     u32 seg = 0;  // first A-slab overlapping the tile being loaded (same value in every thread)
