@@ -68,6 +68,9 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
     return fail(c, HMJ_E_OOM, "hipMalloc", e);
   }
   b.cap = want;
+  if (c && c->trace && want >= (64u << 20))
+    std::fprintf(stderr, "[hmj] hipMalloc %.1f MiB -> %p (low 30 bits %#llx)\n", (double)want / 1048576.0, b.p,
+                 (unsigned long long)((uintptr_t)b.p & ((1ull << 30) - 1)));
   return HMJ_OK;
 }
 
