@@ -115,27 +115,33 @@ int rccl_fail(hmj_ctx* c, const char* what, ncclResult_t r) {
     if (_r != ncclSuccess) return rccl_fail(c, #expr, _r); \
   } while (0)
 
+void comm_free(hmj_comm* m) {  // everything a (possibly half-built) communicator holds, except the RCCL handle
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  DevBuf* devs[] = {&m->parted_r, &m->parted_s, &m->recv_r, &m->recv_s, &m->offs, &m->gather_dev, &m->sample_dev};
+  for (DevBuf* b : devs) free_dev(*b);
+  free_host(m->gather_host);
+  hipEvent_t evs[] = {m->ev_split, m->ev_build, m->ev_t0, m->ev_t1, m->ev_t2};
+  for (hipEvent_t e : evs)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : m->round_ev) (void)hipEventDestroy(e);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
 int comm_ensure(hmj_ctx* c) {
   if (c->comm) return HMJ_OK;
   hmj_comm* m = new hmj_comm();
   std::memset(&m->cb, 0, sizeof(m->cb));
   std::memset(&m->info, 0, sizeof(m->info));
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete m;
-    return fail(c, HMJ_E_HIP, "communication stream");
-  }
+  bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
   hipEvent_t* evs[] = {&m->ev_split, &m->ev_build};
-  for (hipEvent_t* e : evs)
-    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
-      delete m;
-      return fail(c, HMJ_E_HIP, "hipEventCreate");
-    }
+  for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   hipEvent_t* tevs[] = {&m->ev_t0, &m->ev_t1, &m->ev_t2};
-  for (hipEvent_t* e : tevs)
-    if (hipEventCreate(e) != hipSuccess) {
-      delete m;
-      return fail(c, HMJ_E_HIP, "hipEventCreate");
-    }
+  for (hipEvent_t* e : tevs) ok = ok && hipEventCreate(e) == hipSuccess;
+  if (!ok) {
+    comm_free(m);
+    return fail(c, HMJ_E_HIP, "communication stream / events");
+  }
   c->comm = m;
   return HMJ_OK;
 }
@@ -314,15 +320,7 @@ void comm_destroy(hmj_ctx* c) {
     RcclApi* a = rccl_api();
     if (a) (void)a->CommDestroy(m->nccl);
   }
-  DevBuf* devs[] = {&m->parted_r, &m->parted_s, &m->recv_r, &m->recv_s, &m->offs, &m->gather_dev, &m->sample_dev};
-  for (DevBuf* b : devs) free_dev(*b);
-  free_host(m->gather_host);
-  hipEvent_t evs[] = {m->ev_split, m->ev_build, m->ev_t0, m->ev_t1, m->ev_t2};
-  for (hipEvent_t e : evs)
-    if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : m->round_ev) (void)hipEventDestroy(e);
-  if (m->stream) (void)hipStreamDestroy(m->stream);
-  delete m;
+  comm_free(m);
   c->comm = nullptr;
 }
 }  // namespace hmj_host

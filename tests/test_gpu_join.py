@@ -1140,3 +1140,72 @@ def test_release_build_ignores_the_ablation_switch(H, oracle):
         assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"])
     finally:
         e.close()
+
+
+def test_host_row_sort_and_argsort(H, oracle):
+    # hmj_sort_rows_by_u64_host (the radix_inplace_par replacement HashMergeJoin2 uses, radix_hash.h:589-654) and
+    # hmj_argsort_u64_host: rows of 16..64 bytes, key at any 8-byte offset, stable; edge sizes; argument errors
+    import ctypes as C
+
+    e = H.Executor(0)
+    L = e.L
+    L.hmj_sort_rows_by_u64_host.restype = C.c_int
+    L.hmj_sort_rows_by_u64_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.hmj_argsort_u64_host.restype = C.c_int
+    L.hmj_argsort_u64_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(12)
+    try:
+        for n in (0, 1, 2, 63, 4097, 300001):
+            for words, kw in ((2, 0), (3, 2), (3, 0), (8, 5)):
+                rows = rng.integers(0, 1 << 63, size=(n, words), dtype=np.uint64)
+                if n:
+                    rows[:, kw] = rng.integers(0, max(2, n // 3), size=n, dtype=np.uint64)  # many equal keys: stability shows
+                want = rows[np.argsort(rows[:, kw], kind="stable")] if n else rows
+                got = rows.copy()
+                assert L.hmj_sort_rows_by_u64_host(e.h, got.ctypes.data, n, 8 * words, 8 * kw) == 0
+                assert np.array_equal(got, want), (n, words, kw)
+                perm = np.zeros(max(n, 1), np.uint32)
+                assert L.hmj_argsort_u64_host(e.h, rows.ctypes.data + 8 * kw if n else None, n, 8 * words, perm.ctypes.data) == 0
+                if n:
+                    assert np.array_equal(perm[:n], np.argsort(rows[:, kw], kind="stable").astype(np.uint32)), (n, words, kw)
+        buf = np.zeros((4, 3), np.uint64)
+        assert L.hmj_sort_rows_by_u64_host(e.h, buf.ctypes.data, 4, 20, 0) == -1   # not a multiple of 8
+        assert L.hmj_sort_rows_by_u64_host(e.h, buf.ctypes.data, 4, 24, 24) == -1  # key beyond the row
+        assert L.hmj_sort_rows_by_u64_host(e.h, buf.ctypes.data, 4, 72, 0) == -1   # row too wide
+        assert L.hmj_sort_rows_by_u64_host(e.h, None, 4, 24, 0) == -1
+    finally:
+        e.close()
+
+
+def test_exchange_entry_points_report_errors(H):
+    # the multi-GPU entry points fail with a status, never crash: no communicator, bad ranks, NULL outputs
+    import ctypes as C
+
+    import torch
+
+    e = H.Executor(0)
+    try:
+        L = e.L
+        res = H.JoinResult()
+        t = torch.zeros((8, 2), dtype=torch.int64, device="cuda")
+        rc = L.hmj_exchange_join_u64_device(e.h, C.c_void_p(t.data_ptr()), 8, C.c_void_p(t.data_ptr()), 8, 0, C.byref(res), None)
+        assert rc == -1 and b"communicator" in L.hmj_last_error(e.h)
+        idbuf = (C.c_char * 128)()
+        assert L.hmj_comm_init_rank(e.h, 0, 0, C.cast(idbuf, C.c_void_p)) == -1
+        assert L.hmj_comm_init_rank(e.h, 2, 2, C.cast(idbuf, C.c_void_p)) == -1
+        assert L.hmj_comm_init_rank(e.h, 17, 0, C.cast(idbuf, C.c_void_p)) == -5  # HMJ_E_UNSUPPORTED: more than 16 ranks
+        assert L.hmj_comm_set_transport(e.h, None) == -1
+        assert L.hmj_comm_set_message_bytes(e.h, 1 << 20, 0) == -1  # no communicator yet
+        assert L.hmj_strerror(-6) == b"RCCL / transport error"
+        from hashmergejoin_amd import dist as hdist
+
+        hdist.init_comm_single(e)
+        assert L.hmj_comm_set_message_bytes(e.h, 8, 0) == -1 and L.hmj_comm_set_message_bytes(e.h, 1 << 31, 0) == -1
+        assert L.hmj_exchange_join_u64_device(e.h, C.c_void_p(t.data_ptr()), 8, C.c_void_p(t.data_ptr()), 8, 0, None, None) == -1
+        assert L.hmj_exchange_join_u64_device(e.h, None, 8, C.c_void_p(t.data_ptr()), 8, 0, C.byref(res), None) == -1
+        # and an empty shard on either side is a valid join
+        loc, glob = e.exchange_join(t[:0], t, 0)
+        assert int(loc.n_matches) == 0 and int(glob.n_matches) == 0
+        assert L.hmj_comm_destroy(e.h) == 0 and L.hmj_comm_destroy(e.h) == 0
+    finally:
+        e.close()
