@@ -128,15 +128,17 @@ def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
 
 @pytest.mark.parametrize("world,nb,npb,miss,dup,maxmsg", [(2, 300000, 200000, 3, 0, 0), (4, 1 << 20, (1 << 20) + 777, 0, 0, 0),
                                                             (2, 1 << 21, 1 << 22, 5, 1, 1 << 20), (2, 9 << 20, (9 << 20) + 10, 0, 0, 1 << 24),
-                                                            (2, 300000, 250000, 0, 2, 0), (3, 700000, 500000, 2, 0, 1 << 19)])
+                                                            (2, 300000, 250000, 0, 2, 0), (3, 700000, 500000, 2, 0, 1 << 19),
+                                                            (2, 17 << 19, 36 << 20, 0, 0, 1 << 24)])
 def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup, maxmsg):
     res = run_world(tmp_path, world, nb, npb, miss, dup, maxmsg)
     check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg)
-    if nb >= 9 << 20:  # each rank owns ~4.7 M rows per side: the slab path (threshold lowered to 2^22 for the tests): the build side was prepared during the probe exchange
+    if nb >= 17 << 19:  # each rank owns >= 4.4 M build rows: the slab path (threshold lowered to 2^22 for the tests): the build side was prepared during the probe exchange
         import hashmergejoin_amd as H
 
-        for o in res:
-            assert o["info"]["count"]["path"] & H.HMJ_PATH_SLAB and o["info"]["count"]["path"] & H.HMJ_PATH_PREPARED, o["info"]["count"]
+        for o in res:  # (a probe-heavy shard of this size takes the probe-side plan of the full slab path)
+            pth = o["info"]["count"]["path"]
+            assert pth & (H.HMJ_PATH_SLAB | H.HMJ_PATH_SLAB_PROBE) and pth & H.HMJ_PATH_PREPARED, o["info"]["count"]
 
 
 def test_two_ranks_over_rccl(oracle, tmp_path):

@@ -618,6 +618,15 @@ def test_probe_heavy_count_join_partitions_the_probe_side_in_slabs(ex, H, oracle
     nb, npb, dom = 1 << 22, (1 << 24) + 777, 1 << 22
     thr = _zipf_thresholds(dom)
     thr_d = torch.from_numpy(thr.view(np.int64).copy()).cuda()
+    # (0) ragged sizes, unique build keys, a third of the probe rows missing
+    nb0, np0 = (1 << 22) + 4321, 5 * ((1 << 22) + 4321) + 17
+    R0, S0 = ex.gen_build(nb0), ex.gen_probe(np0, nb0, miss_mod=3)
+    ck0, _ = oracle.equijoin(to_np(R0), to_np(S0), cap=0)
+    r = ex.join_device(R0, S0, H.HMJ_CHECKSUM)
+    # (unique, uniform build keys: the probe-side plan makes the FULL slab path applicable; the Zipf build side of
+    #  (a) overflows that one and lands on the probe-side-only slabs)
+    assert r.checks() == ck0 and ex.last_timing()["path"] & (H.HMJ_PATH_SLAB | H.HMJ_PATH_SLAB_PROBE)
+    del R0, S0
     # (a) Zipf build side with duplicate keys x uniform probe side; (b) unique build keys x Zipf-skewed probe side
     # (a hot foreign key: its slab overflows) -- the cross product of two skewed sides would be 10^11 rows
     for skewed_probe in (False, True):
