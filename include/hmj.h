@@ -137,7 +137,7 @@ int hmj_set_radix_bits(hmj_ctx* ctx, int total_bits);
 int hmj_autotune_radix_bits(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, int apply, int* best_bits,
                             double ms[3]);
 /* Tell the executor that the top `bits` key bits are equal in all rows of both relations (an outer
- * radix split already consumed them, e.g. the multi-GPU owner split): partitioning then starts
+ * radix split of the caller's already consumed them; hmj_exchange_join_u64_device needs none): partitioning then starts
  * below them, as the reference's recursion masks off consumed bits (radix_hash.h:219-220).
  * bits = -1 (the default): the executor samples both relations and skips the top bits all sampled
  * keys share (dense / small-integer keys would otherwise all fall into partition 0).
