@@ -533,6 +533,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   const u32 nb = (u32)n_build, np = (u32)n_probe;
   const u32 np_plan = c->prepare_only ? (u32)c->probe_hint : np;  // probe size the plan is made for
 
+  // a build side partitioned ahead by hmj_prepare_build pins the partitioning path of the join that uses it (a
+  // slab cool-down that ran out in between must not make the join partition the build side a second time)
+  if (!c->prepare_only && c->prep.valid && !c->prep.slab && c->prep.ptr == R && c->prep.n == nb) allow_slab = false;
+  if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;  // before the plan: one decision per join
+
   int B, passes, pass_bits[4];
   plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
   if (c->force_bits < 0 && np_plan > nb && nb > 0) {
@@ -643,7 +648,6 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   if (hot_hint) c->timing.path |= HMJ_PATH_HOT_KEY_HINT;
   if (((u64)nb >> B) > hmj::PB_CAP) c->timing.path |= HMJ_PATH_CHUNKED_BUILD;
   // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
-  if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;
   hmj::SlabGeom gr, gs;
   // materialising joins whose build keys are unique take the unique-key write mode (one probe pass,
   // no count pass); it works on either partition layout
