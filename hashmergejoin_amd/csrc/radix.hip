@@ -769,16 +769,24 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 }
 
 #ifndef HMJ_B_ADDR
-#define HMJ_B_ADDR 1  // 1: per-round slab lookup, planned one tile ahead; 0: per-row walk (round 1)
+#define HMJ_B_ADDR 2  // 2: ONE wave-uniform lookup per wave and tile (64-entry window, ballot); 1: per-round slab
+                      // lookup in lanes 0..3, planned one tile ahead; 0: per-row walk (round 1)
 #endif
 #ifndef HMJ_B_NT
 #define HMJ_B_NT 0    // nontemporal loads of the A-slab rows
+#endif
+#ifdef HMJ_DEV
+// developer builds: timing-only ablations of pass B's gather, switched between joins of one process (the same
+// buffers, so the placement lottery cancels).  1 = read the bucket contiguously, 2 = 128-byte aligned gather.
+// Results are wrong while it is set.
+__device__ u32 g_b_ablate;
+static bool g_b_addr_alt = false;  // launch the slab lookup that is NOT the default (HMJ_B_ADDR)
 #endif
 constexpr int SLAB_KB = 4;        // pass-B workers per bucket == pieces per final partition (the pipelined probe
                                   // kernel reads exactly 4; the generic kernel takes any KB as its probe slices)
 constexpr int SLAB_MAXSEG = 512;  // A-slabs one pass-B worker gathers (WA / KB <= 512)
 
-template <int THREADS, int MAXD, bool HI>
+template <int THREADS, int MAXD, bool HI, int ADDR>
 __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_b_kernel(
     const Tup* __restrict__ slab_a, const u32* __restrict__ cnt_a, u32 CA, u32 WA, int bits_a, int shift,
     int bits, Tup* __restrict__ slab_b, u32 CB, u32* __restrict__ cnt_b, u64* __restrict__ accum, u32 KB) {
@@ -809,9 +817,13 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   }
   __syncthreads();
   const u32 total = pre[ns];
-#if !HMJ_B_ADDR
-  const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
+#ifdef HMJ_DEV
+  const u32 abl = g_b_ablate;
+#else
+  constexpr u32 abl = 0;
 #endif
+  const u32 wbase = (u32)w * (WC_ITEMS * 64) + lane;
+  (void)wbase;
   const Tup* __restrict__ bucket = slab_a + (u64)(dA * WA + w0) * CA;  // A-slab j of this worker: + j*CA
   bool ovf = false;
 #ifdef HMJ_STAMPS
@@ -820,7 +832,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 #endif
   if (total) {
     Tup t[WC_ITEMS];
-#if HMJ_B_ADDR
+    if constexpr (ADDR != 0) {
     // Row q of the worker's input (the concatenation of its A-slabs) lives in slab s = the last one with
     // pre[s] <= q, at bucket[s * CA + (q - pre[s])].  A wave reads 4 ROUNDS of 64 consecutive rows per tile;
     // lane r < 4 of every wave looks up round r's first slab by binary search ONE TILE AHEAD (nine dependent
@@ -829,7 +841,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     // two slab starts (else: the per-row walk below), and a lane finds its slab with two compares.
     u32 d_s0 = 0, d_b0 = 0, d_b1 = 0, d_b2 = 0, d_b3 = 0;  // descriptors of the tile to load next (lanes 0..3)
     const float slabs_per_row = (float)ns / (float)total;
-    auto plan = [&](u32 tile_begin) {
+    auto plan1 = [&](u32 tile_begin) {
       u32 q0 = tile_begin + (u32)w * (WC_ITEMS * 64) + (u32)(lane & 3) * 64;
       q0 = q0 < total ? q0 : total - 1;
       // evenly filled slabs: slab(q0) ~ q0 * ns / total, off by a slab or two (the prefix sums wander by
@@ -863,20 +875,26 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
       d_b2 = pre[lo + 2 < ns ? lo + 2 : ns];
       d_b3 = pre[lo + 3 < ns ? lo + 3 : ns];  // (pre[ns] = total: never <= a row index)
     };
-    auto issue = [&](u32 tile_begin) {
+    auto issue1 = [&](u32 tile_begin) {
       u64 off[WC_ITEMS];
       const u32 wq0 = tile_begin + (u32)w * (WC_ITEMS * 64);  // the wave's first row of the tile
       u32 wlast = wq0 + WC_ITEMS * 64 - 1;
       wlast = wlast < total ? wlast : total - 1;
       const u32 s00 = (u32)__builtin_amdgcn_readlane((int)d_s0, 0), b00 = (u32)__builtin_amdgcn_readlane((int)d_b0, 0),
                 b10 = (u32)__builtin_amdgcn_readlane((int)d_b1, 0);
-      if (b10 > wlast) {  // wave-uniform, the common case: all 256 rows of the wave lie in one slab
+      if (abl == 4) {  // (developer ablation: no gather, no plan)
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          u32 q = wq0 + lane + r * 64;
+          off[r] = q < total ? q : total - 1;
+        }
+      } else if (b10 > wlast) {  // wave-uniform, the common case: all 256 rows of the wave lie in one slab
         const u64 o0 = (u64)s00 * CA;
 #pragma unroll
         for (int r = 0; r < WC_ITEMS; r++) {
           u32 q = wq0 + lane + r * 64;
           q = q < total ? q : total - 1;
-          off[r] = o0 + (q - b00);
+          off[r] = abl == 1 ? (u64)q : o0 + (q - (abl == 2 ? b00 & ~7u : b00));
         }
       } else {
 #pragma unroll
@@ -891,7 +909,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
           if (b3 > qlast) {  // wave-uniform: the round crosses at most the slab starts b1 and b2
             const u32 j = (q >= b1 ? 1u : 0u) + (q >= b2 ? 1u : 0u);
             const u32 base = j == 0 ? b0 : (j == 1 ? b1 : b2);
-            off[r] = (u64)(s0 + j) * CA + (q - base);
+            off[r] = abl == 1 ? (u64)q : (u64)(s0 + j) * CA + (q - (abl == 2 ? base & ~7u : base));
           } else {  // tiny or empty slabs in a row: walk
             u32 sx = s0;
             while (sx + 1 < ns && pre[sx + 1] <= q) sx++;
@@ -902,9 +920,104 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 #pragma unroll
       for (int r = 0; r < WC_ITEMS; r++) t[r] = HMJ_B_NT ? load_stream(&bucket[off[r]]) : bucket[off[r]];
     };
-    plan(0);
+    // ADDR == 2: the same lookup ONCE per wave and tile, in scalar registers, and mostly without touching memory.
+    // Each wave keeps a WINDOW of 64 consecutive slab starts in one vector register (lane i: pre[win_lo + i]).  A
+    // ballot of "start <= first row" counts the slabs before the wave's first row of the next tile, and five
+    // readlanes fetch that slab's start and the next four.  The wave's first row advances by one tile (four
+    // average slabs) at a time, so the window serves about a dozen tiles before it is read again (one LDS
+    // instruction at the interpolated position; a binary search if that misses).  The wave's 256 rows cross at
+    // most three slab starts (else: the per-row walk), so a row finds its slab with three compares against
+    // scalars -- no per-round descriptors, no lane 0..3 detour.
+    u32 u_s0 = 0, u_b0 = 0, u_b1 = 0, u_b2 = 0, u_b3 = 0, u_b4 = 0;  // the tile to load next (wave-uniform)
+    const u32 wq = (u32)__builtin_amdgcn_readfirstlane(w) * (WC_ITEMS * 64);
+    u32 win_lo = 0;
+    u32 win_v = pre[(u32)lane < ns ? (u32)lane : ns];
+    auto plan2 = [&](u32 tile_begin) {
+      u32 q0 = tile_begin + wq;
+      q0 = q0 < total ? q0 : total - 1;
+      u64 m = __ballot(win_v <= q0);  // pre[] is nondecreasing: a prefix of ones (pre[ns] = total > q0)
+      u32 j = (u32)__popcll(m) - 1;
+      if (!(m & 1) || j > 59) {  // q0 has left the window (or is too near its end): move it
+        u32 g = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((float)q0 * slabs_per_row));
+        g = g < ns ? g : ns - 1;
+        win_lo = g >= 8 ? g - 8 : 0;
+        win_v = pre[win_lo + (u32)lane < ns ? win_lo + (u32)lane : ns];
+        m = __ballot(win_v <= q0);
+        j = (u32)__popcll(m) - 1;
+        if (!(m & 1) || j > 59) {  // the guess is off by more than the window: binary search
+          u32 lo = 0, hi = ns;     // pre[lo] <= q0, and hi == ns or pre[hi] > q0
+#pragma unroll
+          for (int it = 0; it < 9; it++) {  // ns <= SLAB_MAXSEG = 512
+            const u32 mid = (lo + hi) >> 1;
+            const bool le = pre[mid] <= q0, act = hi - lo > 1;
+            lo = (act && le) ? mid : lo;
+            hi = (act && !le) ? mid : hi;
+          }
+          win_lo = (u32)__builtin_amdgcn_readfirstlane((int)lo);
+          // slabs lo + 1 ... may be empty (same start): the last one with pre <= q0 is what the ballot counts
+          win_v = pre[win_lo + (u32)lane < ns ? win_lo + (u32)lane : ns];
+          m = __ballot(win_v <= q0);
+          j = (u32)__popcll(m) - 1;
+          j = j > 59 ? 59 : j;  // (60 empty slabs in a row: the per-row walk below finds the way)
+        }
+      }
+      u_s0 = win_lo + j;
+      u_b0 = (u32)__builtin_amdgcn_readlane((int)win_v, (int)j);
+      u_b1 = (u32)__builtin_amdgcn_readlane((int)win_v, (int)j + 1);
+      u_b2 = (u32)__builtin_amdgcn_readlane((int)win_v, (int)j + 2);
+      u_b3 = (u32)__builtin_amdgcn_readlane((int)win_v, (int)j + 3);
+      u_b4 = (u32)__builtin_amdgcn_readlane((int)win_v, (int)j + 4);
+    };
+    auto issue2 = [&](u32 tile_begin) {
+      u64 off[WC_ITEMS];
+      const u32 wq0 = tile_begin + wq;
+      u32 wlast = wq0 + WC_ITEMS * 64 - 1;
+      wlast = wlast < total ? wlast : total - 1;
+      if (abl == 4) {  // (developer ablation: no gather, no plan)
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          u32 q = wq0 + lane + r * 64;
+          off[r] = q < total ? q : total - 1;
+        }
+      } else if (u_b1 > wlast) {  // the common case: all 256 rows of the wave lie in one slab
+        const u64 o0 = (u64)u_s0 * CA;
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          u32 q = wq0 + lane + r * 64;
+          q = q < total ? q : total - 1;
+          off[r] = o0 + (q - u_b0);
+        }
+      } else if (u_b4 > wlast) {  // at most the slab starts b1, b2, b3 inside the wave's rows
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          u32 q = wq0 + lane + r * 64;
+          q = q < total ? q : total - 1;
+          const u32 j = (q >= u_b1 ? 1u : 0u) + (q >= u_b2 ? 1u : 0u) + (q >= u_b3 ? 1u : 0u);
+          const u32 base = j == 0 ? u_b0 : (j == 1 ? u_b1 : (j == 2 ? u_b2 : u_b3));
+          off[r] = (u64)(u_s0 + j) * CA + (q - base);
+        }
+      } else {  // tiny or empty slabs in a row: walk
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          u32 q = wq0 + lane + r * 64;
+          q = q < total ? q : total - 1;
+          u32 sx = u_s0;
+          while (sx + 1 < ns && pre[sx + 1] <= q) sx++;
+          off[r] = (u64)sx * CA + (q - pre[sx]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < WC_ITEMS; r++) t[r] = HMJ_B_NT ? load_stream(&bucket[off[r]]) : bucket[off[r]];
+    };
+    auto plan = [&](u32 tb) {
+      if constexpr (ADDR == 2) plan2(tb); else plan1(tb);
+    };
+    auto issue = [&](u32 tb) {
+      if constexpr (ADDR == 2) issue2(tb); else issue1(tb);
+    };
+    if (abl != 4) plan(0);
     issue(0);
-    if ((u32)TILE < total) plan(TILE);
+    if ((u32)TILE < total && abl != 4) plan(TILE);
     for (u32 tile = 0; tile < total; tile += TILE) {
       const u32 tile_n = (total - tile < (u32)TILE) ? total - tile : (u32)TILE;
       auto prefetch = [&]() {
@@ -913,15 +1026,22 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 #ifdef HMJ_STAMPS
           stamps.mark(13);
 #endif
-          if (tile + 2 * TILE < total) plan(tile + 2 * TILE);
+          if (tile + 2 * TILE < total && abl != 4) plan(tile + 2 * TILE);
         }
       };
+#ifdef HMJ_DEV
+      if (abl == 1 || abl == 4) {  // never-written slab tails hold zero keys: give them spread digits (the rank phase waits for the rows anyway)
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++)
+          if (t[r].key == 0) t[r].key = (u64)(tile + (u32)tid + r * THREADS + blockIdx.x * 7919u + 1) * 0x9E3779B97F4A7C15ull;
+      }
+#endif
       if (HMJ_WC_FULLTILE && tile_n == (u32)TILE)
         wc_tile<THREADS, MAXD, HI, true, true>(sm, t, tile_n, slab_b, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
       else
         wc_tile<THREADS, MAXD, HI, false, true>(sm, t, tile_n, slab_b, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
     }
-#else
+    } else {
     u32 seg = 0;  // first A-slab overlapping the tile being loaded (same value in every thread)
     auto load = [&](u32 tile_begin) {
       const u32 tn = (total - tile_begin < (u32)TILE) ? total - tile_begin : (u32)TILE;
@@ -948,7 +1068,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
           },
           limit, &ovf WC_STAMP_PASS);
     }
-#endif
+    }
     wc_flush_carry(sm, slab_b, D);
   }
 #ifdef HMJ_STAMPS
@@ -958,7 +1078,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     const u32 pid = (((u32)tid << bits_a) | dA) * KB + k;
     cnt_b[pid] = sm.cflush[tid] + sm.pend[tid] - pid * CB;
   }
-  if (ovf) atomicOr(&accum[ACC_ERR], ERR_SLAB);
+  if (ovf && !abl) atomicOr(&accum[ACC_ERR], ERR_SLAB);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1059,9 +1179,20 @@ static hipError_t launch_slab_b_t(const void* slab_a, const u32* cnt_a, u32 CA, 
                                   int bits, void* slab_b, u32 CB, u32* cnt_b, u64* accum, hipStream_t st, u32 KB) {
   typedef WcSmem<512, 256> Smem;
   const size_t smem = sizeof(Smem) + (256 + SLAB_MAXSEG + 1) * sizeof(u32);
+#ifdef HMJ_DEV
+  if (g_b_addr_alt) {  // the other lookup, for A/B timing inside one process (hmj_dev_set_b_addr_alt)
+    constexpr int ALT = HMJ_B_ADDR == 2 ? 1 : 2;
+    static SmemAttrOnce attr_alt;
+    if (hipError_t e = ensure_max_smem(attr_alt, reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI, ALT>), (size_t)smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI, ALT>), dim3((1u << bits_a) * KB), dim3(512), smem, st,
+                       static_cast<const Tup*>(slab_a), cnt_a, CA, WA, bits_a, shift, bits,
+                       static_cast<Tup*>(slab_b), CB, cnt_b, accum, KB);
+    return hipGetLastError();
+  }
+#endif
   static SmemAttrOnce attr_once;
-  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI>), (size_t)smem); e != hipSuccess) return e;
-  hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI>), dim3((1u << bits_a) * KB), dim3(512), smem, st,
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI, HMJ_B_ADDR>), (size_t)smem); e != hipSuccess) return e;
+  hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI, HMJ_B_ADDR>), dim3((1u << bits_a) * KB), dim3(512), smem, st,
                      static_cast<const Tup*>(slab_a), cnt_a, CA, WA, bits_a, shift, bits,
                      static_cast<Tup*>(slab_b), CB, cnt_b, accum, KB);
   return hipGetLastError();
@@ -1294,6 +1425,15 @@ hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off
 
 }  // namespace hmj
 
+#ifdef HMJ_DEV
+extern "C" int hmj_dev_set_b_addr_alt(int on) {
+  hmj::g_b_addr_alt = on != 0;
+  return 0;
+}
+extern "C" int hmj_dev_set_b_ablate(unsigned v) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(hmj::g_b_ablate), &v, sizeof(v));
+}
+#endif
 #ifdef HMJ_STAMPS
 // developer builds only: read (and clear) the phase stamps summed by the write-combining scatter kernels
 extern "C" int hmj_dev_stamps(unsigned long long out[32], int reset) {
