@@ -13,6 +13,7 @@ HMJ_PATH_SLAB, HMJ_PATH_EXACT, HMJ_PATH_UNIQ_WRITE, HMJ_PATH_SPLIT, HMJ_PATH_WIN
 HMJ_PATH_ORDER_DEFERRED, HMJ_PATH_ORDER_BY_KEY, HMJ_PATH_PREPARED, HMJ_PATH_CHUNKED_BUILD = 0x20, 0x40, 0x80, 0x100
 HMJ_PATH_HOT_KEY_HINT = 0x200
 HMJ_PATH_SLAB_PROBE = 0x400
+HMJ_PATH_SORTED_WRITE = 0x800
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _U64P = C.POINTER(C.c_uint64)

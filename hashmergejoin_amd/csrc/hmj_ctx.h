@@ -45,7 +45,7 @@ struct hmj_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
       out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
-      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs;
+      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int host_threads = 0;  // staging threads for pageable input (0 = default)
   std::vector<hipStream_t> up_streams;
@@ -63,6 +63,11 @@ struct hmj_ctx {
   } prep;
   bool prepare_only = false;
   int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
+  int sorted_cooldown = 0;   // ordered joins left before the one-pass ordered write is tried again
+  bool sorted_mode = true;   // HMJ_SORTED_WRITE=0: ordered joins always take write + order epilogue
+  bool sorted_chained = false;  // dense output offsets by a chained scan over the partitions (adaptive: on after an
+                                // ordered join with unmatched probe rows; HMJ_SORTED_WRITE=2 always, 3 never)
+  bool sorted_chained_forced = false;
   u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged

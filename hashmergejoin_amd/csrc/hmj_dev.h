@@ -72,6 +72,7 @@ enum { ACC_N = 0, ACC_SUM_R, ACC_SUM_S, ACC_XOR, ACC_MIX, ACC_SUM_P, ACC_ERR, AC
 constexpr u64 ERR_SLAB = 2;    // slab path: a slab overflowed or a partition does not fit -> exact path
 constexpr u64 ERR_ORDER_DEFER = 16;  // ordered epilogue left a very large segment unsorted: the host sorts the result
 constexpr u64 ERR_ORDER_FAIL = 32;   // ordered epilogue: a segment too large to sort in place AND to defer (result > 2^32-1 rows)
+constexpr u64 ERR_SORTED = 64;   // one-pass ordered write met duplicate keys / clustered keys / an oversized partition
 constexpr u64 ERR_FASTPATH = 8;  // unique-key write mode met duplicate build keys / an oversized partition
 constexpr u64 ERR_PREFIX = 4;  // a key does not carry the sampled common prefix (ordered mode re-plans)
 

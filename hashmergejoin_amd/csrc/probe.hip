@@ -755,6 +755,352 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
   block_accumulate(sm.red, a.accum, v, 1u << ACC_XOR);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ordered unique-key write in ONE pass: probe, sort and write (HMJ_ORDERED; build keys unique, probe keys unique).
+//
+// The two-step form (probe_count_fast_kernel<OUT=1> writes rows in probe order at the slots of their probe rows,
+// order_kernel sorts every partition and closes the gaps) moves every result row twice: 32 B read + 24 B written,
+// then 24 B read + 24 B written.  Here the result rows leave once, already sorted and dense:
+//   * the partition's BUILD rows are bucket-sorted by key into LDS (bucket = the 12 key bits below the partition
+//     bits, a counting pass + a rank among the handful of rows of a bucket): the sorted array IS the table --
+//     a probe row scans its key's bucket, a contiguous run of about one row;
+//   * a matching probe row sets its build row's bit in a bitmap (a bit set twice = two probe rows with that key:
+//     not this kernel's case) and leaves its payload beside it; a popcount prefix of the bitmap then gives every
+//     matched build row its rank among the partition's result rows -- in key order;
+//   * the partition's first output row is the number of result rows of all partitions before it: partitions are
+//     handed out by a ticket counter and chained by a decoupled look-back over their published counts (a
+//     partition waits only for partitions with smaller tickets, all of which are running or done);
+//   * copy-out by sorted build index: consecutive lanes write consecutive output rows.
+// Anything else -- duplicate build or probe keys, a bucket of more than SW_MAXBUCKET rows (keys that do not vary
+// in those 12 bits), a partition that does not fit -- raises ERR_SORTED: the caller re-runs the two-step form.
+// ---------------------------------------------------------------------------------------------
+constexpr int SW_LOGB = 12, SW_NB = 1 << SW_LOGB, SW_MAXBUCKET = 32;
+constexpr u64 LB_AGG = 1ull << 62, LB_PFX = 2ull << 62, LB_MASK = (1ull << 62) - 1;
+constexpr u32 LB_SPIN_LIMIT = 1u << 20;  // ~ a second of polling: a predecessor that never publishes is a bug
+
+template <int THREADS>
+struct SortedSmem {
+  static constexpr int CAP = THREADS * FP_ROWS;
+  u64 key[CAP];   // build keys, sorted
+  u64 val[CAP];   // build payloads, same order
+  u64 sval[CAP];  // bucket-grouped keys while ranking; then the payload of the probe row that matched build row i
+  u32 cnt[SW_NB];
+  u16 bstart[SW_NB + 2];
+  u32 mbits[2][CAP / 32];   // build row i was matched (double-buffered by partition parity)
+  u32 mpre[CAP / 32 + 1];   // matched rows before word w
+  u32 scratch[THREADS / kWave + 1];
+  u32 tick[2];
+  u32 flag;
+  u64 obase;
+  u64 red[8];
+};
+
+// Publish partition p's row count and return the number of result rows of partitions 0 .. p-1.  Called by one
+// whole wave: lane l inspects partition p-1-l, 64 predecessors per round, back to the nearest one that has
+// published its inclusive prefix (typically within the few hundred partitions in flight).
+__device__ __forceinline__ u64 lookback_publish(u64* __restrict__ state, u32 p, u64 total, int lane, bool* timeout) {
+  unsigned long long* st = reinterpret_cast<unsigned long long*>(state);
+  if (lane == 0) atomicExch(&st[p], LB_AGG | total);
+  u64 excl = 0;
+  for (long long base = (long long)p - 1; base >= 0; base -= kWave) {
+    const long long q = base - lane;
+    u64 v = LB_PFX;  // lanes before partition 0: "prefix 0"
+    if (q >= 0) v = atomicAdd(&st[q], 0ull);  // (an RMW: always served by the coherent level)
+    u32 spins = 0;
+    while (__any((v >> 62) == 0)) {
+      if (++spins > LB_SPIN_LIMIT) {  // a predecessor that never publishes: give up loudly instead of hanging
+        *timeout = true;
+        if ((v >> 62) == 0) v = LB_PFX;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      if ((v >> 62) == 0) v = atomicAdd(&st[q], 0ull);
+    }
+    const u64 pfx = __ballot((v >> 62) == 2);
+    const int first = pfx ? __ffsll((unsigned long long)pfx) - 1 : kWave;  // nearest published prefix
+    excl += wave_sum_u64(lane <= first ? (v & LB_MASK) : 0ull);
+    if (pfx) break;
+  }
+  if (lane == 0) atomicExch(&st[p], LB_PFX | ((excl + total) & LB_MASK));
+  return excl;
+}
+
+template <int THREADS, bool SLAB>
+__global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArgs a, u64* __restrict__ lookback, int bsh, bool chained) {
+  typedef SortedSmem<THREADS> Smem;
+  constexpr u32 CAP = Smem::CAP, WORDS = CAP / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
+  const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
+  const Tup* __restrict__ S = static_cast<const Tup*>(a.S);
+  const u32* __restrict__ r_off = a.r_off;
+  const u32* __restrict__ s_off = a.s_off;
+  const u32* __restrict__ r_end = (SLAB || a.r_end == nullptr) ? a.r_off + 1 : a.r_end;
+  const u32* __restrict__ s_end = (SLAB || a.s_end == nullptr) ? a.s_off + 1 : a.s_end;
+  const u32 P = a.P;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned long long* ticket = reinterpret_cast<unsigned long long*>(lookback);
+  u64* state = lookback + 1;
+  u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
+  bool pfx_bad = false, giveup = false, slab_bad = false, lb_timeout = false;
+
+  if (tid == 0) sm.tick[0] = (u32)atomicAdd(ticket, 1ull);
+  if (tid < 8) sm.red[tid] = 0;
+  reinterpret_cast<uint4*>(sm.cnt)[tid] = make_uint4(0, 0, 0, 0);  // SW_NB / 4 == THREADS
+  if ((u32)tid < WORDS) sm.mbits[0][tid] = 0;
+  if (tid == 0) sm.flag = 0;
+  __syncthreads();
+  u32 p = sm.tick[0], par = 0;
+  u32 rb = 0, nb = 0, sb = 0, np = 0;
+  u32 r1 = 0, r2 = 0, r3 = 0, s1 = 0, s2 = 0, s3 = 0, r1n = 0, r2n = 0, r3n = 0, s1n = 0, s2n = 0, s3n = 0;
+  bool regular = false;
+  Tup br[FP_ROWS], pr[FP_ROWS];
+  const Tup* __restrict__ dummy = reinterpret_cast<const Tup*>(a.accum);
+  if (p < P) {
+    if (SLAB) {
+      const u32* rc = a.r_cnt + (u64)p * 4;
+      const u32* sc = a.s_cnt + (u64)p * 4;
+      r1 = rc[0]; r2 = r1 + rc[1]; r3 = r2 + rc[2]; nb = r3 + rc[3];
+      s1 = sc[0]; s2 = s1 + sc[1]; s3 = s2 + sc[2]; np = s3 + sc[3];
+      if (nb > CAP || np > CAP) slab_bad = true;
+    } else {
+      rb = r_off[p]; nb = r_end[p] - rb;
+      sb = s_off[p]; np = s_end[p] - sb;
+    }
+    regular = nb && np && nb <= CAP && np <= CAP;
+    if (SLAB)
+      fp_load_slab<THREADS>(br, regular ? R + (u64)p * 4 * a.r_cap : dummy, regular ? a.r_cap : 0u, regular ? r1 : 1u,
+                            regular ? r2 : 1u, regular ? r3 : 1u, regular ? nb : 1u, tid);
+    else
+      fp_load<THREADS>(br, regular ? R + rb : dummy, regular ? nb : 1u, tid);
+  }
+  while (p < P) {
+    if (tid == 0) sm.tick[par ^ 1] = (u32)atomicAdd(ticket, 1ull);  // the partition after this one
+    // this partition's probe rows (unconditional loads: see probe_count_fast_kernel)
+    if (SLAB)
+      fp_load_slab<THREADS>(pr, regular ? S + (u64)p * 4 * a.s_cap : dummy, regular ? a.s_cap : 0u, regular ? s1 : 1u,
+                            regular ? s2 : 1u, regular ? s3 : 1u, regular ? np : 1u, tid);
+    else
+      fp_load<THREADS>(pr, regular ? S + sb : dummy, regular ? np : 1u, tid);
+    // (no barrier here: the first LDS arrays this partition writes -- cnt, then bstart -- are not read by the
+    //  previous partition's copy-out, and two barriers lie between here and the first write to sval / key / val)
+    u32 h[FP_ROWS], arr[FP_ROWS];
+    if (regular) {
+      // count the build rows per bucket; the old count is the row's arrival number inside its bucket
+#pragma unroll
+      for (int k = 0; k < FP_ROWS; k++) {
+        const u32 i = k * THREADS + tid;
+        h[k] = 0;
+        arr[k] = 0;
+        if (i < nb) {
+          if (a.pfx_shift && (br[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+          h[k] = (u32)(br[k].key >> bsh) & (SW_NB - 1);
+          arr[k] = atomicAdd(&sm.cnt[h[k]], 1u);
+        }
+      }
+    }
+    lds_barrier();  // bucket counts complete; the next ticket is visible
+    if ((u32)tid < WORDS) sm.mbits[par ^ 1][tid] = 0;  // the next partition's bitmap (the previous one's copy-out is over)
+    const u32 pn = (u32)__builtin_amdgcn_readfirstlane((int)sm.tick[par ^ 1]);
+    u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
+    bool regular2 = false;
+    if (pn < P) {
+      if (SLAB) {
+        const u32* rc = a.r_cnt + (u64)pn * 4;
+        const u32* sc = a.s_cnt + (u64)pn * 4;
+        r1n = rc[0]; r2n = r1n + rc[1]; r3n = r2n + rc[2]; nb2 = r3n + rc[3];
+        s1n = sc[0]; s2n = s1n + sc[1]; s3n = s2n + sc[2]; np2 = s3n + sc[3];
+        if (nb2 > CAP || np2 > CAP) slab_bad = true;
+      } else {
+        rb2 = r_off[pn]; nb2 = r_end[pn] - rb2;
+        sb2 = s_off[pn]; np2 = s_end[pn] - sb2;
+      }
+      regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
+    }
+    auto load_next_build = [&]() {
+      if (SLAB)
+        fp_load_slab<THREADS>(br, regular2 ? R + (u64)pn * 4 * a.r_cap : dummy, regular2 ? a.r_cap : 0u,
+                              regular2 ? r1n : 1u, regular2 ? r2n : 1u, regular2 ? r3n : 1u, regular2 ? nb2 : 1u, tid);
+      else
+        fp_load<THREADS>(br, regular2 ? R + rb2 : dummy, regular2 ? nb2 : 1u, tid);
+    };
+    u32 total = 0;       // result rows of this partition (thread 0 of wave 0)
+    bool sorted_ok = false;
+    if (regular) {
+      {  // exclusive scan of the 4096 bucket counts, 4 per thread (and the counts go back to zero for the next partition)
+        u32 c[4], sum = 0, mx = 0;
+        const uint4 c4 = reinterpret_cast<uint4*>(sm.cnt)[tid];
+        reinterpret_cast<uint4*>(sm.cnt)[tid] = make_uint4(0, 0, 0, 0);
+        c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          sum += c[q];
+          mx = c[q] > mx ? c[q] : mx;
+        }
+        if (mx > (u32)SW_MAXBUCKET) sm.flag = 1;
+        u32 tot;
+        u32 ex = block_excl_scan_u32<THREADS>(sum, sm.scratch, &tot);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          sm.bstart[tid * 4 + q] = (u16)ex;
+          ex += c[q];
+        }
+        if (tid == 0) sm.bstart[SW_NB] = (u16)nb;
+      }
+      lds_barrier();
+      if (sm.flag == 0) {  // uniform
+        // the keys grouped by bucket, in arrival order (sval[] is free until the probe phase)
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          const u32 i = k * THREADS + tid;
+          if (i < nb) sm.sval[(u32)sm.bstart[h[k]] + arr[k]] = br[k].key;
+        }
+        lds_barrier();
+        // rank among the rows of the bucket (equal keys -- not this kernel's case -- by arrival, so that every row
+        // still gets its own place), then key and payload go to their sorted position
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          const u32 i = k * THREADS + tid;
+          if (i < nb) {
+            const u32 s0 = sm.bstart[h[k]], e0 = sm.bstart[h[k] + 1];
+            u32 rank = 0;
+            for (u32 j = s0; j < e0; j++) {
+              const u64 ok = sm.sval[j];
+              rank += (ok < br[k].key || (ok == br[k].key && j - s0 < arr[k])) ? 1u : 0u;
+            }
+            sm.key[s0 + rank] = br[k].key;
+            sm.val[s0 + rank] = br[k].val;
+          }
+        }
+      }
+      load_next_build();
+      lds_barrier();  // table complete (and nobody reads the grouped keys in sval[] any more)
+      if (sm.flag == 0) {
+        // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap)
+        u32 cur[FP_ROWS], end[FP_ROWS], found[FP_ROWS], hits[FP_ROWS];
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          const u32 j = k * THREADS + tid;
+          cur[k] = end[k] = found[k] = hits[k] = 0;
+          if (j < np) {
+            if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+            if (a.extra & 1u) acc_p += pr[k].val;
+            const u32 hh = (u32)(pr[k].key >> bsh) & (SW_NB - 1);
+            cur[k] = sm.bstart[hh];
+            end[k] = sm.bstart[hh + 1];
+          }
+        }
+        for (;;) {
+          bool any = false;
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) any |= cur[k] < end[k];
+          if (!__any(any)) break;
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            if (cur[k] < end[k]) {
+              if (sm.key[cur[k]] == pr[k].key) {
+                found[k] = cur[k];
+                hits[k]++;
+              }
+              cur[k]++;
+            }
+          }
+        }
+        bool dup = false;
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          if (hits[k]) {
+            const u32 si = found[k], bit = 1u << (si & 31);
+            dup |= hits[k] > 1;                                       // two build rows with this key
+            dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
+            sm.sval[si] = pr[k].val;
+            const u64 vv = sm.val[si];
+            acc_n++;
+            acc_r += vv;
+            acc_s += pr[k].val;
+            if (a.extra & 1u) {
+              const u64 m = tmix(pr[k].key, vv, pr[k].val);
+              acc_x ^= m;
+              acc_m += m;
+            }
+          }
+        }
+        if (dup) sm.flag = 2;
+      }
+      lds_barrier();
+      sorted_ok = sm.flag == 0;
+      if (!sorted_ok) giveup = true;
+      if (wv == 0) {  // matched rows before every bitmap word; the partition's row count
+        u32 run = 0;
+        for (int r = 0; r < (int)((WORDS + kWave - 1) / kWave); r++) {
+          const u32 w = (u32)r * kWave + lane;
+          const u32 c = (sorted_ok && w < WORDS) ? (u32)__popc(sm.mbits[par][w]) : 0u;
+          const u32 incl = wave_incl_scan_u32(c, lane);
+          if (w < WORDS) sm.mpre[w] = run + incl - c;
+          run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        total = run;
+      }
+    } else {
+      if (nb && np) giveup = true;  // does not fit the pipeline
+      if ((a.extra & 1u) && !nb) {  // probe rows without a build partition still count in sum_probe_all
+        if (SLAB) {
+          const Tup* base = S + (u64)p * 4 * a.s_cap;
+          for (u32 j = tid; j < np; j += THREADS) {
+            const u32 pc = (j >= s1) + (j >= s2) + (j >= s3);
+            const u32 pre = pc == 0 ? 0 : pc == 1 ? s1 : pc == 2 ? s2 : s3;
+            acc_p += base[(u64)pc * a.s_cap + (j - pre)].val;
+          }
+        } else {
+          for (u32 j = tid; j < np; j += THREADS) acc_p += S[sb + j].val;
+        }
+      }
+      load_next_build();
+    }
+    // every partition publishes its count (zero if it has no rows or gave up): its successors wait for it
+    if (wv == 0) {
+      // chained: the rows of all partitions before this one; slots: the partition's own probe-row slots (the
+      // result is then dense only if every probe row matched -- the caller checks and closes the gaps otherwise)
+      const u64 excl = chained ? lookback_publish(state, p, (u64)total, lane, &lb_timeout)
+                               : (SLAB ? a.item_base[p] : (u64)sb);
+      if (lane == 0) {
+        a.part_count[p] = total;
+        sm.obase = excl;
+      }
+    }
+    lds_barrier();
+    if (sorted_ok) {
+      const u64 ob = sm.obase;
+#pragma unroll
+      for (int k = 0; k < FP_ROWS; k++) {
+        const u32 si = k * THREADS + tid;
+        if (si < nb) {
+          const u32 w = sm.mbits[par][si >> 5], b = si & 31;
+          if ((w >> b) & 1u) {
+            const u64 d = ob + sm.mpre[si >> 5] + (u32)__popc(w & ((1u << b) - 1u));
+            a.out_key[d] = sm.key[si];
+            a.out_rval[d] = sm.val[si];
+            a.out_sval[d] = sm.sval[si];
+          }
+        }
+      }
+    }
+    p = pn; par ^= 1;
+    rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
+    r1 = r1n; r2 = r2n; r3 = r3n; s1 = s1n; s2 = s2n; s3 = s3n;
+  }
+  if (SLAB && slab_bad && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_SLAB);
+  if (__any(giveup || lb_timeout) && lane == 0) {  // (bits 7..10: why, for HMJ_TRACE)
+    const u32 f = sm.flag;
+    atomicOr(&a.accum[ACC_ERR], ERR_SORTED | (f == 1 ? 128u : 0u) | (f == 2 ? 256u : 0u) | (lb_timeout ? 1024u : 0u) |
+                                    (giveup && f == 0 ? 512u : 0u));
+  }
+  if (__any(pfx_bad) && lane == 0) atomicOr(&a.accum[ACC_ERR], ERR_PREFIX);
+  lds_barrier();
+  const u64 v[6] = {acc_n, acc_r, acc_s, acc_x, acc_m, acc_p};
+  block_accumulate(sm.red, a.accum, v, 1u << ACC_XOR);
+}
+
 // Exclusive scan of n u64 counts into n+1 offsets (single workgroup; n = partition count).
 __global__ __launch_bounds__(1024) void scan_u64_kernel(const u64* __restrict__ in,
                                                         u64* __restrict__ out, u32 n) {
@@ -1246,6 +1592,28 @@ hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_ir
 hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, hipStream_t st) {
   if (slab) return launch_fast_t<1024, BIG_LOG_NB, false, true, 1>(a, nullptr, nullptr, num_cus * 4, st);
   return launch_fast_t<1024, BIG_LOG_NB, false, false, 1>(a, nullptr, nullptr, num_cus * 4, st);
+}
+
+// ordered unique-key write in one pass (probe_write_sorted_kernel); lookback: P + 1 words, zeroed by the caller
+hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, u64* lookback, bool chained, int key_low, int num_cus,
+                                     hipStream_t st) {
+  typedef SortedSmem<1024> Smem;
+  static_assert(SW_NB / 4 == 1024, "one uint4 of bucket counts per thread");
+  const int bsh = key_low - SW_LOGB;
+  if (bsh < 0) return hipErrorInvalidValue;
+  int grid = num_cus;  // one workgroup per CU fits (LDS); partitions are handed out by ticket
+  if ((u32)grid > a.P) grid = (int)a.P;
+  if (grid < 1) grid = 1;
+  if (slab) {
+    static SmemAttrOnce attr_once;
+    if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, true>), sizeof(Smem)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((probe_write_sorted_kernel<1024, true>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, bsh, chained);
+  } else {
+    static SmemAttrOnce attr_once;
+    if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, false>), sizeof(Smem)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((probe_write_sorted_kernel<1024, false>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, bsh, chained);
+  }
+  return hipGetLastError();
 }
 
 // np of every slab partition (sum of its 4 piece counts) as u64, for the exclusive scan that gives

@@ -873,6 +873,71 @@ def test_ordered_unique_key_write_mode(ex, H, oracle):
     run_out_cooldown()
 
 
+def test_one_pass_ordered_write(ex_fresh, H, oracle):
+    # HMJ_ORDERED with unique keys on both sides: probe_write_sorted_kernel probes, sorts and writes in one pass
+    # (HMJ_PATH_SORTED_WRITE).  Every probe row matched: rows go to the probe rows' own slots.  Unmatched rows: the
+    # epilogue closes the gaps once, and the executor chains the output offsets from the next ordered join on
+    # (no epilogue).  Duplicate probe keys, duplicate build keys, keys that do not vary in the twelve bits under
+    # the partition bits: the kernel gives up and the two-step form (write + order epilogue) delivers the rows.
+    ex = ex_fresh
+    fl = H.HMJ_ORDERED | H.HMJ_CHECKSUM
+
+    def run(B, P, flags=fl):
+        ck, rows = oracle.equijoin(B, P)
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), flags)
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        got = ex.columns_to_numpy(r, host=False)
+        assert r.checks() == ck
+        assert np.array_equal(got, rows)  # the reference's iteration order, row for row
+        ex.release_result()
+        return t
+
+    for nb, npb in [(300000, 300000), ((1 << 22) + 4321, 1 << 22), (9000, 1000)]:  # exact and slab layouts
+        t = run(oracle.gen_build(nb), oracle.gen_probe(npb, nb))  # every probe row matches
+        assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0 and t["ms_probe_count"] == 0.0
+    B, P = oracle.gen_build(400000), oracle.gen_probe(350000, 400000, miss_mod=3)
+    t = run(B, P)      # first join with unmatched rows: slots + epilogue
+    assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] > 0.0
+    t = run(B, P)      # from then on: chained output offsets, dense without an epilogue
+    assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0
+    B2, P2 = oracle.gen_build((1 << 22) + 5), oracle.gen_probe((1 << 22) - 77, (1 << 22) + 5, miss_mod=7)
+    t = run(B2, P2)    # chained, slab layout, 1/7 unmatched
+    assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0
+    t = run(oracle.gen_build(1 << 22), oracle.gen_probe(1 << 22, 1 << 22))  # chained, nothing unmatched
+    assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0
+    # an empty side, a single row
+    assert run(oracle.gen_build(5000), oracle.gen_probe(1, 5000))["path"] & H.HMJ_PATH_UNIQ_WRITE
+    # a foreign-key join: probe keys repeat -> two-step form, same rows; the executor remembers for a while
+    Pf = oracle.gen_uniform_domain(600000, 200000)
+    Bf = oracle.gen_build(200000)
+    for _ in range(2):
+        t = run(Bf, Pf)
+        assert not (t["path"] & H.HMJ_PATH_SORTED_WRITE) and t["ms_order"] > 0.0
+
+
+def test_one_pass_ordered_write_gives_up_on_clustered_keys(ex_fresh, H, oracle):
+    # a tag in the top six bits, zeros below it, an id in the low forty: whatever window the planner takes, the
+    # rows of a partition agree in the twelve bits under it or the partitions are no key ranges -> not this
+    # kernel's case; the rows must come out right either way
+    ex = ex_fresh
+    n = 200000
+    B = oracle.gen_build(n)
+    i = np.arange(n, dtype=np.uint64)
+    B[:, 0] = ((i % np.uint64(64)) << np.uint64(58)) | ((i * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(24))
+    B = B[np.sort(np.unique(B[:, 0], return_index=True)[1])]
+    P = B.copy()
+    P[:, 1] ^= np.uint64(0x5555)
+    ck, rows = oracle.equijoin(B, P)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    ex.set_profiling(False)
+    assert r.checks() == ck and np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+    ex.release_result()
+
+
 def test_prepared_build_side(ex, H, oracle):
     # hmj_prepare_build_u64_device: partition R ahead of the join (one-shot), for both partitioning paths
     for nb, npb in [(1 << 22, (1 << 22) + 999), (300000, 200000)]:
