@@ -957,7 +957,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
         lds_barrier();
         // rank among the rows of the bucket (equal keys -- not this kernel's case -- by arrival, so that every row
-        // still gets its own place), then key and payload go to their sorted position
+        // still gets its own place), then key and payload go to their sorted position.  (Row after row: walking
+        // the five buckets in lockstep, as the probe phase does, measured 1 % slower here.)
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 i = k * THREADS + tid;
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       lds_barrier();  // table complete (and nobody reads the grouped keys in sval[] any more)
       if (sm.flag == 0) {
         // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap)
-        u32 cur[FP_ROWS], end[FP_ROWS], found[FP_ROWS], hits[FP_ROWS];
+        u32 cur[FP_ROWS], end[FP_ROWS], found[FP_ROWS], hits[FP_ROWS];  // (cur: the bucket's start)
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 j = k * THREADS + tid;
@@ -990,19 +991,16 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
             end[k] = sm.bstart[hh + 1];
           }
         }
-        for (;;) {
+        for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
           bool any = false;
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) any |= cur[k] < end[k];
+          for (int k = 0; k < FP_ROWS; k++) any |= cur[k] + step < end[k];
           if (!__any(any)) break;
 #pragma unroll
           for (int k = 0; k < FP_ROWS; k++) {
-            if (cur[k] < end[k]) {
-              if (sm.key[cur[k]] == pr[k].key) {
-                found[k] = cur[k];
-                hits[k]++;
-              }
-              cur[k]++;
+            if (cur[k] + step < end[k] && sm.key[cur[k] + step] == pr[k].key) {
+              found[k] = cur[k] + step;
+              hits[k]++;
             }
           }
         }
