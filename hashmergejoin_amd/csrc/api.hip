@@ -484,11 +484,17 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   };
   // ---- ordered joins: probe, sort and write in one pass (probe_write_sorted_kernel) when the keys allow it
   if (ordered && c->sorted_cooldown > 0) c->sorted_cooldown--;
-  if (ordered && c->sorted_mode && c->sorted_cooldown == 0 && low >= 12) {
+  // two forms of the kernel: unique probe keys (a match bitmap), and repeating probe keys (a foreign-key join:
+  // match counts and a rank by payload inside every key's run).  The context remembers which one the last join
+  // needed, and asks the cheaper one again every 64 ordered joins.
+  if (ordered && c->sorted_fk && ++c->sorted_fk_age >= 64) c->sorted_fk = false;
+  for (int form = c->sorted_fk ? 1 : 0; form < 2 && ordered && c->sorted_mode && c->sorted_cooldown == 0 && low >= 12;
+       form++) {
+    const bool fk = form == 1;
     if ((rc = ensure_dev(c, c->lookback, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->lookback.p, 0, ((size_t)P + 1) * 8, c->stream));
     int sp = span_begin(c, K_PROBE_WRITE, -1);
-    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
+    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
     span_end(c, sp);
     HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -505,7 +511,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
       out->mix_sum = h[hmj::ACC_MIX];
       out->sum_probe_all = h[hmj::ACC_SUM_P];
       c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
-      c->timing.path |= HMJ_PATH_UNIQ_WRITE | HMJ_PATH_SORTED_WRITE;
+      c->timing.path |= HMJ_PATH_UNIQ_WRITE | HMJ_PATH_SORTED_WRITE | (fk ? HMJ_PATH_SORTED_FK : 0u);
       if (out->n_matches == 0) return HMJ_OK;
       const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
       // the next ordered join: chained output offsets if this one had unmatched probe rows (dense without an
@@ -522,12 +528,22 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
       }
       return deliver(rk, rr, rs);
     }
-    // duplicate or clustered keys: the partitions stay valid, take the two-step form (and remember for a while)
-    c->sorted_cooldown = 64;  // (a foreign-key join's probe keys repeat every time: ask again rarely)
+    // the partitions stay valid: repeating probe keys -> the foreign-key form; anything else (duplicate build keys,
+    // clustered keys, a hot key, an oversized partition) -> the two-step form, and do not ask again for a while
+    const u64 why = h[hmj::ACC_ERR];
+    const bool try_fk = !fk && (why & 256) && !(why & (128 | 512 | 1024 | 2048));
+    if (try_fk) {
+      c->sorted_fk = true;
+      c->sorted_fk_age = 0;
+    } else {
+      c->sorted_cooldown = 64;
+      form = 2;
+    }
     if (c->trace)
-      std::fprintf(stderr, "[hmj]   one-pass ordered write gave up (%s%s%s%s) -> write + order epilogue\n",
-                   (h[hmj::ACC_ERR] & 128) ? "a bucket too long " : "", (h[hmj::ACC_ERR] & 256) ? "duplicate keys " : "",
-                   (h[hmj::ACC_ERR] & 512) ? "a partition does not fit " : "", (h[hmj::ACC_ERR] & 1024) ? "look-back timeout" : "");
+      std::fprintf(stderr, "[hmj]   one-pass ordered write%s gave up (%s%s%s%s%s) -> %s\n", fk ? " (foreign-key form)" : "",
+                   (why & 128) ? "a bucket too long " : "", (why & 256) ? "repeating probe keys " : "",
+                   (why & 512) ? "a partition does not fit " : "", (why & 1024) ? "look-back timeout " : "",
+                   (why & 2048) ? "duplicate build keys or a hot key" : "", try_fk ? "foreign-key form" : "write + order epilogue");
     std::vector<Span> keep;
     for (const Span& s2 : c->spans)
       if (s2.kind != K_PROBE_WRITE) keep.push_back(s2);

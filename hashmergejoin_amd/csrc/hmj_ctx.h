@@ -68,6 +68,8 @@ struct hmj_ctx {
   bool sorted_chained = false;  // dense output offsets by a chained scan over the partitions (adaptive: on after an
                                 // ordered join with unmatched probe rows; HMJ_SORTED_WRITE=2 always, 3 never)
   bool sorted_chained_forced = false;
+  bool sorted_fk = false;  // the last ordered join's probe keys repeated: start with the foreign-key form of the kernel
+  int sorted_fk_age = 0;
   u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged

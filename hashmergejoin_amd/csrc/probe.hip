@@ -11,6 +11,7 @@
 // the probe partition per chunk.
 #include "hmj_dev.h"
 #include "hmj_launch.h"
+#include <type_traits>
 
 namespace hmj {
 
@@ -780,7 +781,7 @@ constexpr u32 LB_SPIN_LIMIT = 1u << 20;  // ~ a second of polling: a predecessor
 
 template <int THREADS>
 struct SortedSmem {
-  static constexpr int CAP = THREADS * FP_ROWS;
+  static constexpr int CAP = THREADS * FP_ROWS, CAPB = CAP, LOGB = SW_LOGB;
   u64 key[CAP];   // build keys, sorted
   u64 val[CAP];   // build payloads, same order
   u64 sval[CAP];  // bucket-grouped keys while ranking; then the payload of the probe row that matched build row i
@@ -791,6 +792,33 @@ struct SortedSmem {
   u32 scratch[THREADS / kWave + 1];
   u32 tick[2];
   u32 flag;
+  u64 obase;
+  u64 red[8];
+};
+
+// FK = true: the probe keys may repeat (a foreign-key join: every build key is hit by f probe rows).  A build row
+// then counts its matches (the old count is the probe row's arrival number among the rows of its key), an exclusive
+// scan of the counts in sorted build order gives every key its run of output slots, the probe rows drop their
+// payloads there, rank themselves inside the run by payload (the result order is (key, rval, sval), and rval is
+// the same for the whole run) and move to their final slot; the copy-out walks the OUTPUT slots and finds key and
+// rval through the slot's build row.  Build rows: at most 4608 per partition (a foreign-key join has far fewer),
+// 2048 buckets -- that is what fits beside the per-slot arrays.
+constexpr int SWF_LOGB = 11, SWF_CAPB = 4608, SWF_MAXDUP = 64;
+template <int THREADS>
+struct SortedFkSmem {
+  static constexpr int CAP = THREADS * FP_ROWS, CAPB = SWF_CAPB, LOGB = SWF_LOGB;
+  u64 key[CAPB];   // build keys, sorted
+  u64 val[CAPB];   // build payloads, same order
+  u64 sval[CAP];   // bucket-grouped build keys while ranking; then the probe payload of every OUTPUT slot
+  u32 mcnt[CAPB];  // matches of build row i, then the first output slot of its run
+  u16 owner[CAP];  // build row of every output slot
+  u32 cnt[1 << SWF_LOGB];
+  u16 bstart[(1 << SWF_LOGB) + 2];
+  u32 scratch[THREADS / kWave + 1];
+  u32 tick[2];
+  u32 flag;
+  u32 anydup;  // some key has more than one probe row
+  u32 hot;     // some key has more than SWF_MAXDUP probe rows
   u64 obase;
   u64 red[8];
 };
@@ -825,10 +853,12 @@ __device__ __forceinline__ u64 lookback_publish(u64* __restrict__ state, u32 p, 
   return excl;
 }
 
-template <int THREADS, bool SLAB>
-__global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArgs a, u64* __restrict__ lookback, int bsh, bool chained) {
-  typedef SortedSmem<THREADS> Smem;
-  constexpr u32 CAP = Smem::CAP, WORDS = CAP / 32;
+template <int THREADS, bool SLAB, bool FK>
+__global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArgs a, u64* __restrict__ lookback, int key_low, bool chained) {
+  typedef typename std::conditional<FK, SortedFkSmem<THREADS>, SortedSmem<THREADS>>::type Smem;
+  constexpr u32 CAP = Smem::CAP, CAPB = Smem::CAPB, WORDS = CAP / 32, NB = 1u << Smem::LOGB, BPT = NB / THREADS;
+  static_assert(BPT * THREADS == NB && BPT >= 1, "whole buckets per thread in the scan");
+  const int bsh = key_low - Smem::LOGB;  // bucket = the key bits right under the partition bits
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
@@ -843,11 +873,15 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
   u64* state = lookback + 1;
   u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
   bool pfx_bad = false, giveup = false, slab_bad = false, lb_timeout = false;
+  u32 why = 0;  // why the kernel gave up (bits 7..11 of the error word, for HMJ_TRACE and the choice of the next form)
 
   if (tid == 0) sm.tick[0] = (u32)atomicAdd(ticket, 1ull);
   if (tid < 8) sm.red[tid] = 0;
-  reinterpret_cast<uint4*>(sm.cnt)[tid] = make_uint4(0, 0, 0, 0);  // SW_NB / 4 == THREADS
-  if ((u32)tid < WORDS) sm.mbits[0][tid] = 0;
+#pragma unroll
+  for (u32 q = 0; q < BPT; q++) sm.cnt[tid * BPT + q] = 0;
+  if constexpr (!FK) {
+    if ((u32)tid < WORDS) sm.mbits[0][tid] = 0;
+  }
   if (tid == 0) sm.flag = 0;
   __syncthreads();
   u32 p = sm.tick[0], par = 0;
@@ -862,12 +896,12 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       const u32* sc = a.s_cnt + (u64)p * 4;
       r1 = rc[0]; r2 = r1 + rc[1]; r3 = r2 + rc[2]; nb = r3 + rc[3];
       s1 = sc[0]; s2 = s1 + sc[1]; s3 = s2 + sc[2]; np = s3 + sc[3];
-      if (nb > CAP || np > CAP) slab_bad = true;
+      if (nb > CAPB || np > CAP) slab_bad = true;
     } else {
       rb = r_off[p]; nb = r_end[p] - rb;
       sb = s_off[p]; np = s_end[p] - sb;
     }
-    regular = nb && np && nb <= CAP && np <= CAP;
+    regular = nb && np && nb <= CAPB && np <= CAP;
     if (SLAB)
       fp_load_slab<THREADS>(br, regular ? R + (u64)p * 4 * a.r_cap : dummy, regular ? a.r_cap : 0u, regular ? r1 : 1u,
                             regular ? r2 : 1u, regular ? r3 : 1u, regular ? nb : 1u, tid);
@@ -894,13 +928,18 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         arr[k] = 0;
         if (i < nb) {
           if (a.pfx_shift && (br[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-          h[k] = (u32)(br[k].key >> bsh) & (SW_NB - 1);
+          h[k] = (u32)(br[k].key >> bsh) & (NB - 1);
           arr[k] = atomicAdd(&sm.cnt[h[k]], 1u);
         }
       }
     }
     lds_barrier();  // bucket counts complete; the next ticket is visible
-    if ((u32)tid < WORDS) sm.mbits[par ^ 1][tid] = 0;  // the next partition's bitmap (the previous one's copy-out is over)
+    if constexpr (FK) {  // the match counts (the previous partition's copy-out does not read them)
+      for (u32 i = tid; i < CAPB; i += THREADS) sm.mcnt[i] = 0;
+      if (tid == 0) sm.anydup = sm.hot = 0;
+    } else {
+      if ((u32)tid < WORDS) sm.mbits[par ^ 1][tid] = 0;  // the next partition's bitmap (the previous one's copy-out is over)
+    }
     const u32 pn = (u32)__builtin_amdgcn_readfirstlane((int)sm.tick[par ^ 1]);
     u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
     bool regular2 = false;
@@ -910,12 +949,12 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         const u32* sc = a.s_cnt + (u64)pn * 4;
         r1n = rc[0]; r2n = r1n + rc[1]; r3n = r2n + rc[2]; nb2 = r3n + rc[3];
         s1n = sc[0]; s2n = s1n + sc[1]; s3n = s2n + sc[2]; np2 = s3n + sc[3];
-        if (nb2 > CAP || np2 > CAP) slab_bad = true;
+        if (nb2 > CAPB || np2 > CAP) slab_bad = true;
       } else {
         rb2 = r_off[pn]; nb2 = r_end[pn] - rb2;
         sb2 = s_off[pn]; np2 = s_end[pn] - sb2;
       }
-      regular2 = nb2 && np2 && nb2 <= CAP && np2 <= CAP;
+      regular2 = nb2 && np2 && nb2 <= CAPB && np2 <= CAP;
     }
     auto load_next_build = [&]() {
       if (SLAB)
@@ -924,16 +963,18 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       else
         fp_load<THREADS>(br, regular2 ? R + rb2 : dummy, regular2 ? nb2 : 1u, tid);
     };
-    u32 total = 0;       // result rows of this partition (thread 0 of wave 0)
+    u32 total = 0;       // result rows of this partition (FK: every thread; else wave 0)
     bool sorted_ok = false;
-    if (regular) {
-      {  // exclusive scan of the 4096 bucket counts, 4 per thread (and the counts go back to zero for the next partition)
-        u32 c[4], sum = 0, mx = 0;
-        const uint4 c4 = reinterpret_cast<uint4*>(sm.cnt)[tid];
-        reinterpret_cast<uint4*>(sm.cnt)[tid] = make_uint4(0, 0, 0, 0);
-        c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+    u32 found[FP_ROWS], hits[FP_ROWS], slot[FP_ROWS];  // the build row a probe row matched; FK: its arrival number
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+    for (int k = 0; k < FP_ROWS; k++) found[k] = hits[k] = slot[k] = 0;
+    if (regular) {
+      {  // exclusive scan of the bucket counts, BPT per thread (and the counts go back to zero for the next partition)
+        u32 c[BPT], sum = 0, mx = 0;
+#pragma unroll
+        for (u32 q = 0; q < BPT; q++) {
+          c[q] = sm.cnt[tid * BPT + q];
+          sm.cnt[tid * BPT + q] = 0;
           sum += c[q];
           mx = c[q] > mx ? c[q] : mx;
         }
@@ -941,11 +982,11 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         u32 tot;
         u32 ex = block_excl_scan_u32<THREADS>(sum, sm.scratch, &tot);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          sm.bstart[tid * 4 + q] = (u16)ex;
+        for (u32 q = 0; q < BPT; q++) {
+          sm.bstart[tid * BPT + q] = (u16)ex;
           ex += c[q];
         }
-        if (tid == 0) sm.bstart[SW_NB] = (u16)nb;
+        if (tid == 0) sm.bstart[NB] = (u16)nb;
       }
       lds_barrier();
       if (sm.flag == 0) {  // uniform
@@ -978,15 +1019,15 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       lds_barrier();  // table complete (and nobody reads the grouped keys in sval[] any more)
       if (sm.flag == 0) {
         // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap)
-        u32 cur[FP_ROWS], end[FP_ROWS], found[FP_ROWS], hits[FP_ROWS];  // (cur: the bucket's start)
+        u32 cur[FP_ROWS], end[FP_ROWS];  // (cur: the bucket's start)
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 j = k * THREADS + tid;
-          cur[k] = end[k] = found[k] = hits[k] = 0;
+          cur[k] = end[k] = 0;
           if (j < np) {
             if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             if (a.extra & 1u) acc_p += pr[k].val;
-            const u32 hh = (u32)(pr[k].key >> bsh) & (SW_NB - 1);
+            const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
             cur[k] = sm.bstart[hh];
             end[k] = sm.bstart[hh + 1];
           }
@@ -1004,14 +1045,18 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
             }
           }
         }
-        bool dup = false;
+        bool dup = false, dupb = false;
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           if (hits[k]) {
             const u32 si = found[k], bit = 1u << (si & 31);
-            dup |= hits[k] > 1;                                       // two build rows with this key
-            dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
-            sm.sval[si] = pr[k].val;
+            dupb |= hits[k] > 1;                                      // two build rows with this key
+            if constexpr (FK) {
+              slot[k] = atomicAdd(&sm.mcnt[si], 1u);                  // arrival number among the probe rows of the key
+            } else {
+              dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
+              sm.sval[si] = pr[k].val;
+            }
             const u64 vv = sm.val[si];
             acc_n++;
             acc_r += vv;
@@ -1024,8 +1069,76 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           }
         }
         if (dup) sm.flag = 2;
+        if (dupb) sm.flag = 3;
       }
       lds_barrier();
+      if constexpr (FK) {
+        if (sm.flag == 0) {  // uniform
+          // every build row's run of output slots: exclusive scan of the match counts in sorted build order
+          u32 c[FP_ROWS], sum = 0, mx = 0;
+#pragma unroll
+          for (int q = 0; q < FP_ROWS; q++) {
+            const u32 i = (u32)tid * FP_ROWS + q;
+            c[q] = i < CAPB ? sm.mcnt[i] : 0u;
+            sum += c[q];
+            mx = c[q] > mx ? c[q] : mx;
+          }
+          if (mx > (u32)SWF_MAXDUP) sm.hot = 1;  // (its own word: sm.flag is being read by slower threads right now)
+          if (mx > 1) sm.anydup = 1;
+          u32 ex = block_excl_scan_u32<THREADS>(sum, sm.scratch, &total);
+#pragma unroll
+          for (int q = 0; q < FP_ROWS; q++) {
+            const u32 i = (u32)tid * FP_ROWS + q;
+            if (i < CAPB) sm.mcnt[i] = ex;
+            ex += c[q];
+          }
+          lds_barrier();
+        }
+        if (sm.flag == 0 && sm.hot == 0) {
+          // payloads to their key's run, in arrival order
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            if (hits[k]) {
+              const u32 o = sm.mcnt[found[k]] + slot[k];
+              sm.sval[o] = pr[k].val;
+              sm.owner[o] = (u16)found[k];
+            }
+          }
+          if (sm.anydup) {  // uniform: order every run by payload
+            lds_barrier();
+            // (row after row: walking the five runs of a thread in lockstep measured 15 % slower, eight reads of
+            //  a run in flight at once no faster -- the cost of this step is its two barriers, ~2 us each)
+            u32 rnk[FP_ROWS];
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; k++) {
+              rnk[k] = 0xFFFFFFFFu;
+              if (hits[k]) {
+                const u32 si = found[k], base = sm.mcnt[si];
+                const u32 c = (si + 1 < CAPB ? sm.mcnt[si + 1] : total) - base;
+                if (c > 1) {
+                  u32 r = 0;
+                  for (u32 j = 0; j < c; j++) {
+                    const u64 ov = sm.sval[base + j];
+                    r += (ov < pr[k].val || (ov == pr[k].val && j < slot[k])) ? 1u : 0u;
+                  }
+                  rnk[k] = base + r;
+                }
+              }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; k++)
+              if (rnk[k] != 0xFFFFFFFFu) sm.sval[rnk[k]] = pr[k].val;
+          }
+        }
+        sorted_ok = sm.flag == 0 && sm.hot == 0;
+        if (!sorted_ok) {
+          giveup = true;
+          if (sm.flag == 0) why |= 2048u;
+          total = 0;
+        }
+      }
+      if constexpr (!FK) {
       sorted_ok = sm.flag == 0;
       if (!sorted_ok) giveup = true;
       if (wv == 0) {  // matched rows before every bitmap word; the partition's row count
@@ -1039,8 +1152,12 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
         total = run;
       }
+      }
     } else {
-      if (nb && np) giveup = true;  // does not fit the pipeline
+      if (nb && np) {  // does not fit the pipeline
+        giveup = true;
+        why |= 512u;
+      }
       if ((a.extra & 1u) && !nb) {  // probe rows without a build partition still count in sum_probe_all
         if (SLAB) {
           const Tup* base = S + (u64)p * 4 * a.s_cap;
@@ -1067,7 +1184,22 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       }
     }
     lds_barrier();
-    if (sorted_ok) {
+    if (FK && sorted_ok) {
+      if constexpr (FK) {
+        const u64 ob = sm.obase;
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          const u32 j = k * THREADS + tid;
+          if (j < total) {
+            const u32 si = sm.owner[j];
+            a.out_key[ob + j] = sm.key[si];
+            a.out_rval[ob + j] = sm.val[si];
+            a.out_sval[ob + j] = sm.sval[j];
+          }
+        }
+      }
+    } else if (sorted_ok) {
+      if constexpr (!FK) {
       const u64 ob = sm.obase;
 #pragma unroll
       for (int k = 0; k < FP_ROWS; k++) {
@@ -1082,16 +1214,17 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           }
         }
       }
+      }
     }
     p = pn; par ^= 1;
     rb = rb2; nb = nb2; sb = sb2; np = np2; regular = regular2;
     r1 = r1n; r2 = r2n; r3 = r3n; s1 = s1n; s2 = s2n; s3 = s3n;
   }
   if (SLAB && slab_bad && tid == 0) atomicOr(&a.accum[ACC_ERR], ERR_SLAB);
-  if (__any(giveup || lb_timeout) && lane == 0) {  // (bits 7..10: why, for HMJ_TRACE)
-    const u32 f = sm.flag;
-    atomicOr(&a.accum[ACC_ERR], ERR_SORTED | (f == 1 ? 128u : 0u) | (f == 2 ? 256u : 0u) | (lb_timeout ? 1024u : 0u) |
-                                    (giveup && f == 0 ? 512u : 0u));
+  if (__any(giveup || lb_timeout) && lane == 0) {
+    const u32 f = sm.flag;  // 1: a bucket too long, 2: repeating probe keys (bitmap form), 3: duplicate build keys
+    atomicOr(&a.accum[ACC_ERR], ERR_SORTED | why | (f == 1 ? 128u : 0u) | (f == 2 ? 256u : 0u) | (f == 3 ? 2048u : 0u) |
+                                    (lb_timeout ? 1024u : 0u));
   }
   if (__any(pfx_bad) && lane == 0) atomicOr(&a.accum[ACC_ERR], ERR_PREFIX);
   lds_barrier();
@@ -1593,25 +1726,26 @@ hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, h
 }
 
 // ordered unique-key write in one pass (probe_write_sorted_kernel); lookback: P + 1 words, zeroed by the caller
-hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, u64* lookback, bool chained, int key_low, int num_cus,
-                                     hipStream_t st) {
-  typedef SortedSmem<1024> Smem;
-  static_assert(SW_NB / 4 == 1024, "one uint4 of bucket counts per thread");
-  const int bsh = key_low - SW_LOGB;
-  if (bsh < 0) return hipErrorInvalidValue;
+template <bool SLAB, bool FK>
+static hipError_t launch_sorted_t(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
+  typedef typename std::conditional<FK, SortedFkSmem<1024>, SortedSmem<1024>>::type Smem;
+  static_assert(sizeof(Smem) <= 160 * 1024, "one workgroup's LDS");
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, SLAB, FK>), sizeof(Smem)); e != hipSuccess) return e;
+  hipLaunchKernelGGL((probe_write_sorted_kernel<1024, SLAB, FK>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, key_low, chained);
+  return hipGetLastError();
+}
+// fk: the probe keys may repeat (SortedFkSmem); key_low: the partition id's lowest key bit
+hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, u64* lookback, bool chained, int key_low,
+                                     int num_cus, hipStream_t st) {
+  if (key_low < SW_LOGB) return hipErrorInvalidValue;
   int grid = num_cus;  // one workgroup per CU fits (LDS); partitions are handed out by ticket
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
-  if (slab) {
-    static SmemAttrOnce attr_once;
-    if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, true>), sizeof(Smem)); e != hipSuccess) return e;
-    hipLaunchKernelGGL((probe_write_sorted_kernel<1024, true>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, bsh, chained);
-  } else {
-    static SmemAttrOnce attr_once;
-    if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, false>), sizeof(Smem)); e != hipSuccess) return e;
-    hipLaunchKernelGGL((probe_write_sorted_kernel<1024, false>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, bsh, chained);
-  }
-  return hipGetLastError();
+  if (slab) return fk ? launch_sorted_t<true, true>(a, lookback, chained, key_low, grid, st)
+                      : launch_sorted_t<true, false>(a, lookback, chained, key_low, grid, st);
+  return fk ? launch_sorted_t<false, true>(a, lookback, chained, key_low, grid, st)
+            : launch_sorted_t<false, false>(a, lookback, chained, key_low, grid, st);
 }
 
 // np of every slab partition (sum of its 4 piece counts) as u64, for the exclusive scan that gives

@@ -909,12 +909,27 @@ def test_one_pass_ordered_write(ex_fresh, H, oracle):
     assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0
     # an empty side, a single row
     assert run(oracle.gen_build(5000), oracle.gen_probe(1, 5000))["path"] & H.HMJ_PATH_UNIQ_WRITE
-    # a foreign-key join: probe keys repeat -> two-step form, same rows; the executor remembers for a while
-    Pf = oracle.gen_uniform_domain(600000, 200000)
+    # a foreign-key join: probe keys repeat -> the kernel's foreign-key form (match counts, every key's run of
+    # output slots ordered by payload); the executor remembers and starts with that form the next time
     Bf = oracle.gen_build(200000)
-    for _ in range(2):
-        t = run(Bf, Pf)
-        assert not (t["path"] & H.HMJ_PATH_SORTED_WRITE) and t["ms_order"] > 0.0
+    for npf, dom in [(600000, 200000), (3000000, 200000), (1 << 22, 1 << 18)]:
+        Bf = oracle.gen_build(dom)
+        Pf = oracle.gen_uniform_domain(npf, dom)
+        Pf[::5, 1] = Pf[1::5, 1][: len(Pf[::5])]  # equal payloads inside a key's run happen too
+        for _ in range(2):
+            t = run(Bf, Pf)
+            assert t["path"] & H.HMJ_PATH_SORTED_FK and t["ms_order"] == 0.0, hex(t["path"])
+    # ... with unmatched probe rows (keys outside the build side's domain)
+    Pm = oracle.gen_uniform_domain(900000, 300000)
+    t = run(oracle.gen_build(200000), Pm)
+    assert t["path"] & H.HMJ_PATH_SORTED_FK
+    t = run(oracle.gen_build(200000), Pm)  # chained offsets now
+    assert t["path"] & H.HMJ_PATH_SORTED_FK and t["ms_order"] == 0.0
+    # a key with hundreds of probe rows is not this kernel's case: write + order epilogue, same rows
+    Ph = oracle.gen_uniform_domain(400000, 200000)
+    Ph[:700, 0] = Ph[0, 0]
+    t = run(oracle.gen_build(200000), Ph)
+    assert not (t["path"] & H.HMJ_PATH_SORTED_WRITE)
 
 
 def test_one_pass_ordered_write_gives_up_on_clustered_keys(ex_fresh, H, oracle):
