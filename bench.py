@@ -131,7 +131,15 @@ def extra_runs(ex, H, torch):
         assert int(r.n_matches) == n
         out["configs2_2p28_%s_ms" % name] = ms
     ex.release_result()
-    del R, S
+    del S
+    # the same build side as the dimension table of a foreign-key join: 2^24 keys, 2^28 probe rows, ordered rows
+    Rf = ex.gen_build(1 << 24)
+    Sf = ex.gen_uniform_domain(1 << 28, 1 << 24)
+    ms, r = timed(lambda: ex.join_device(Rf, Sf, H.HMJ_ORDERED), reps=2)
+    assert int(r.n_matches) == 1 << 28
+    out["fk_2p24_x_2p28_ordered_ms"] = ms
+    ex.release_result()
+    del R, Rf, Sf
     torch.cuda.empty_cache()
     # configs[4]: Zipf(0.9) build side of 2^24 rows over 2^24 distinct values, probe 2^30 uniform over the domain
     nb, npb, theta = 1 << 24, 1 << 30, 0.9
