@@ -782,13 +782,13 @@ constexpr u32 LB_SPIN_LIMIT = 1u << 20;  // ~ a second of polling: a predecessor
 template <int THREADS>
 struct SortedSmem {
   static constexpr int CAP = THREADS * FP_ROWS, CAPB = CAP, LOGB = SW_LOGB;
-  u64 key[CAP];   // build keys, sorted
+  u64 key[CAP];   // build keys, grouped by bucket (buckets ascend; inside a bucket: order of arrival)
   u64 val[CAP];   // build payloads, same order
-  u64 sval[CAP];  // bucket-grouped keys while ranking; then the payload of the probe row that matched build row i
+  u64 sval[CAP];  // the payload of the probe row that matched the build row of sorted rank i
   u32 cnt[SW_NB];
   u16 bstart[SW_NB + 2];
-  u32 mbits[2][CAP / 32];   // build row i was matched (double-buffered by partition parity)
-  u32 mpre[CAP / 32 + 1];   // matched rows before word w
+  u16 perm[CAP];  // where the build row of sorted rank i lies in key[] / val[] (written by the probe row that matched it)
+  u32 mbits[2][CAP / 32];   // the build row of sorted rank i was matched (double-buffered by partition parity)
   u32 scratch[THREADS / kWave + 1];
   u32 tick[2];
   u32 flag;
@@ -807,11 +807,11 @@ constexpr int SWF_LOGB = 11, SWF_CAPB = 4608, SWF_MAXDUP = 64;
 template <int THREADS>
 struct SortedFkSmem {
   static constexpr int CAP = THREADS * FP_ROWS, CAPB = SWF_CAPB, LOGB = SWF_LOGB;
-  u64 key[CAPB];   // build keys, sorted
+  u64 key[CAPB];   // build keys, grouped by bucket (buckets ascend; inside a bucket: order of arrival)
   u64 val[CAPB];   // build payloads, same order
-  u64 sval[CAP];   // bucket-grouped build keys while ranking; then the probe payload of every OUTPUT slot
-  u32 mcnt[CAPB];  // matches of build row i, then the first output slot of its run
-  u16 owner[CAP];  // build row of every output slot
+  u64 sval[CAP];   // the probe payload of every OUTPUT slot
+  u32 mcnt[CAPB];  // matches of the build row of sorted rank i, then the first output slot of its run
+  u16 owner[CAP];  // position in key[] / val[] of every output slot's build row
   u32 cnt[1 << SWF_LOGB];
   u16 bstart[(1 << SWF_LOGB) + 2];
   u32 scratch[THREADS / kWave + 1];
@@ -963,11 +963,16 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       else
         fp_load<THREADS>(br, regular2 ? R + rb2 : dummy, regular2 ? nb2 : 1u, tid);
     };
-    u32 total = 0;       // result rows of this partition (FK: every thread; else wave 0)
-    bool sorted_ok = false;
-    u32 found[FP_ROWS], hits[FP_ROWS], slot[FP_ROWS];  // the build row a probe row matched; FK: its arrival number
+    u32 total = 0;       // result rows of this partition
+    constexpr int WROUNDS = (int)((WORDS + kWave - 1) / kWave);
+    u32 wpre[WROUNDS];   // bitmap form: matched rows before words lane, lane + 64, ...
 #pragma unroll
-    for (int k = 0; k < FP_ROWS; k++) found[k] = hits[k] = slot[k] = 0;
+    for (int r = 0; r < WROUNDS; r++) wpre[r] = 0;
+    bool sorted_ok = false;
+    // a probe row's match: sorted rank and position of the build row; FK: the probe row's arrival number in its key's run
+    u32 found[FP_ROWS], mpos[FP_ROWS], hits[FP_ROWS], slot[FP_ROWS];
+#pragma unroll
+    for (int k = 0; k < FP_ROWS; k++) found[k] = mpos[k] = hits[k] = slot[k] = 0;
     if (regular) {
       {  // exclusive scan of the bucket counts, BPT per thread (and the counts go back to zero for the next partition)
         u32 c[BPT], sum = 0, mx = 0;
@@ -980,7 +985,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
         if (mx > (u32)SW_MAXBUCKET) sm.flag = 1;
         u32 tot;
-        u32 ex = block_excl_scan_u32<THREADS>(sum, sm.scratch, &tot);
+        u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &tot);  // (a barrier follows below)
 #pragma unroll
         for (u32 q = 0; q < BPT; q++) {
           sm.bstart[tid * BPT + q] = (u16)ex;
@@ -990,40 +995,28 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       }
       lds_barrier();
       if (sm.flag == 0) {  // uniform
-        // the keys grouped by bucket, in arrival order (sval[] is free until the probe phase)
-#pragma unroll
-        for (int k = 0; k < FP_ROWS; k++) {
-          const u32 i = k * THREADS + tid;
-          if (i < nb) sm.sval[(u32)sm.bstart[h[k]] + arr[k]] = br[k].key;
-        }
-        lds_barrier();
-        // rank among the rows of the bucket (equal keys -- not this kernel's case -- by arrival, so that every row
-        // still gets its own place), then key and payload go to their sorted position.  (Row after row: walking
-        // the five buckets in lockstep, as the probe phase does, measured 1 % slower here.)
+        // key and payload go to their bucket, in order of arrival.  A row's sorted rank -- its bucket's start plus
+        // the number of smaller keys in the bucket -- is what the output order needs; the probe row that matches it
+        // scans the whole bucket anyway and counts them on the way, so the build rows are never moved again.
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 i = k * THREADS + tid;
           if (i < nb) {
-            const u32 s0 = sm.bstart[h[k]], e0 = sm.bstart[h[k] + 1];
-            u32 rank = 0;
-            for (u32 j = s0; j < e0; j++) {
-              const u64 ok = sm.sval[j];
-              rank += (ok < br[k].key || (ok == br[k].key && j - s0 < arr[k])) ? 1u : 0u;
-            }
-            sm.key[s0 + rank] = br[k].key;
-            sm.val[s0 + rank] = br[k].val;
+            const u32 pos = (u32)sm.bstart[h[k]] + arr[k];
+            sm.key[pos] = br[k].key;
+            sm.val[pos] = br[k].val;
           }
         }
       }
       load_next_build();
-      lds_barrier();  // table complete (and nobody reads the grouped keys in sval[] any more)
+      lds_barrier();  // table complete
       if (sm.flag == 0) {
         // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap)
-        u32 cur[FP_ROWS], end[FP_ROWS];  // (cur: the bucket's start)
+        u32 cur[FP_ROWS], end[FP_ROWS], less[FP_ROWS];  // (cur: the bucket's start; less: smaller keys in the bucket)
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 j = k * THREADS + tid;
-          cur[k] = end[k] = 0;
+          cur[k] = end[k] = less[k] = 0;
           if (j < np) {
             if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             if (a.extra & 1u) acc_p += pr[k].val;
@@ -1039,9 +1032,13 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           if (!__any(any)) break;
 #pragma unroll
           for (int k = 0; k < FP_ROWS; k++) {
-            if (cur[k] + step < end[k] && sm.key[cur[k] + step] == pr[k].key) {
-              found[k] = cur[k] + step;
-              hits[k]++;
+            if (cur[k] + step < end[k]) {
+              const u64 kk = sm.key[cur[k] + step];
+              less[k] += kk < pr[k].key ? 1u : 0u;
+              if (kk == pr[k].key) {
+                mpos[k] = cur[k] + step;
+                hits[k]++;
+              }
             }
           }
         }
@@ -1049,15 +1046,17 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           if (hits[k]) {
-            const u32 si = found[k], bit = 1u << (si & 31);
+            const u32 si = cur[k] + less[k], bit = 1u << (si & 31);    // the matched build row's sorted rank
+            found[k] = si;
             dupb |= hits[k] > 1;                                      // two build rows with this key
             if constexpr (FK) {
               slot[k] = atomicAdd(&sm.mcnt[si], 1u);                  // arrival number among the probe rows of the key
             } else {
               dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
               sm.sval[si] = pr[k].val;
+              sm.perm[si] = (u16)mpos[k];
             }
-            const u64 vv = sm.val[si];
+            const u64 vv = sm.val[mpos[k]];
             acc_n++;
             acc_r += vv;
             acc_s += pr[k].val;
@@ -1085,7 +1084,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           }
           if (mx > (u32)SWF_MAXDUP) sm.hot = 1;  // (its own word: sm.flag is being read by slower threads right now)
           if (mx > 1) sm.anydup = 1;
-          u32 ex = block_excl_scan_u32<THREADS>(sum, sm.scratch, &total);
+          u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &total);  // (a barrier follows below)
 #pragma unroll
           for (int q = 0; q < FP_ROWS; q++) {
             const u32 i = (u32)tid * FP_ROWS + q;
@@ -1101,7 +1100,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
             if (hits[k]) {
               const u32 o = sm.mcnt[found[k]] + slot[k];
               sm.sval[o] = pr[k].val;
-              sm.owner[o] = (u16)found[k];
+              sm.owner[o] = (u16)mpos[k];
             }
           }
           if (sm.anydup) {  // uniform: order every run by payload
@@ -1139,19 +1138,20 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
       }
       if constexpr (!FK) {
-      sorted_ok = sm.flag == 0;
-      if (!sorted_ok) giveup = true;
-      if (wv == 0) {  // matched rows before every bitmap word; the partition's row count
+        sorted_ok = sm.flag == 0;
+        if (!sorted_ok) giveup = true;
+        // matched rows before every bitmap word, and the partition's row count: every wave scans the 160 words for
+        // itself (lane l keeps the prefixes of words l, l + 64, l + 128), so nobody waits for anybody
         u32 run = 0;
-        for (int r = 0; r < (int)((WORDS + kWave - 1) / kWave); r++) {
+#pragma unroll
+        for (int r = 0; r < WROUNDS; r++) {
           const u32 w = (u32)r * kWave + lane;
           const u32 c = (sorted_ok && w < WORDS) ? (u32)__popc(sm.mbits[par][w]) : 0u;
           const u32 incl = wave_incl_scan_u32(c, lane);
-          if (w < WORDS) sm.mpre[w] = run + incl - c;
+          wpre[r] = run + incl - c;
           run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
         }
         total = run;
-      }
       }
     } else {
       if (nb && np) {  // does not fit the pipeline
@@ -1173,20 +1173,23 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       load_next_build();
     }
     // every partition publishes its count (zero if it has no rows or gave up): its successors wait for it
-    if (wv == 0) {
-      // chained: the rows of all partitions before this one; slots: the partition's own probe-row slots (the
-      // result is then dense only if every probe row matched -- the caller checks and closes the gaps otherwise)
-      const u64 excl = chained ? lookback_publish(state, p, (u64)total, lane, &lb_timeout)
-                               : (SLAB ? a.item_base[p] : (u64)sb);
-      if (lane == 0) {
-        a.part_count[p] = total;
-        sm.obase = excl;
+    // chained: the rows of all partitions before this one (wave 0 finds out, the others wait); slots: the
+    // partition's own probe-row slots (the result is then dense only if every probe row matched -- the caller
+    // checks and closes the gaps otherwise)
+    u64 ob = SLAB ? a.item_base[p] : (u64)sb;
+    if (tid == 0) a.part_count[p] = total;
+    if (chained) {
+      if (wv == 0) {
+        const u64 excl = lookback_publish(state, p, (u64)total, lane, &lb_timeout);
+        if (lane == 0) sm.obase = excl;
       }
+      lds_barrier();
+      ob = sm.obase;
+    } else if (FK) {
+      lds_barrier();  // the payloads and owners of all output slots are in place
     }
-    lds_barrier();
     if (FK && sorted_ok) {
       if constexpr (FK) {
-        const u64 ob = sm.obase;
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 j = k * THREADS + tid;
@@ -1200,16 +1203,19 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       }
     } else if (sorted_ok) {
       if constexpr (!FK) {
-      const u64 ob = sm.obase;
+      static_assert(THREADS == 1024, "word of slot k: 32 k + tid / 32");
 #pragma unroll
       for (int k = 0; k < FP_ROWS; k++) {
         const u32 si = k * THREADS + tid;
+        // word si / 32 = 32 k + tid / 32: scan round k / 2, lane 32 (k & 1) + tid / 32 of this wave's registers
+        const u32 before = (u32)__shfl((int)wpre[k >> 1], (int)((k & 1) * 32 + ((u32)tid >> 5) % 32u), kWave);
         if (si < nb) {
           const u32 w = sm.mbits[par][si >> 5], b = si & 31;
           if ((w >> b) & 1u) {
-            const u64 d = ob + sm.mpre[si >> 5] + (u32)__popc(w & ((1u << b) - 1u));
-            a.out_key[d] = sm.key[si];
-            a.out_rval[d] = sm.val[si];
+            const u64 d = ob + before + (u32)__popc(w & ((1u << b) - 1u));
+            const u32 m = sm.perm[si];
+            a.out_key[d] = sm.key[m];
+            a.out_rval[d] = sm.val[m];
             a.out_sval[d] = sm.sval[si];
           }
         }
