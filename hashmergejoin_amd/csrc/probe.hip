@@ -803,7 +803,7 @@ struct SortedSmem {
 // the same for the whole run) and move to their final slot; the copy-out walks the OUTPUT slots and finds key and
 // rval through the slot's build row.  Build rows: at most 4608 per partition (a foreign-key join has far fewer),
 // 2048 buckets -- that is what fits beside the per-slot arrays.
-constexpr int SWF_LOGB = 11, SWF_CAPB = 4608, SWF_MAXDUP = 64;
+constexpr int SWF_LOGB = 11, SWF_CAPB = 4608, SWF_MAXDUP = 1024;
 template <int THREADS>
 struct SortedFkSmem {
   static constexpr int CAP = THREADS * FP_ROWS, CAPB = SWF_CAPB, LOGB = SWF_LOGB;

@@ -925,9 +925,13 @@ def test_one_pass_ordered_write(ex_fresh, H, oracle):
     assert t["path"] & H.HMJ_PATH_SORTED_FK
     t = run(oracle.gen_build(200000), Pm)  # chained offsets now
     assert t["path"] & H.HMJ_PATH_SORTED_FK and t["ms_order"] == 0.0
-    # a key with hundreds of probe rows is not this kernel's case: write + order epilogue, same rows
+    # a key with hundreds of probe rows still is (a run is ranked in time linear in its length, up to 1024 rows) ...
     Ph = oracle.gen_uniform_domain(400000, 200000)
     Ph[:700, 0] = Ph[0, 0]
+    t = run(oracle.gen_build(200000), Ph)
+    assert t["path"] & H.HMJ_PATH_SORTED_FK
+    # ... one with thousands is not: write + order epilogue, same rows
+    Ph[:1500, 0] = Ph[0, 0]
     t = run(oracle.gen_build(200000), Ph)
     assert not (t["path"] & H.HMJ_PATH_SORTED_WRITE)
 
