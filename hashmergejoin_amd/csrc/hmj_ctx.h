@@ -63,6 +63,7 @@ struct hmj_ctx {
   } prep;
   bool prepare_only = false;
   int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
+  bool dense_plan = true;    // HMJ_DENSE_PLAN=0: never size the plan by the build keys' share of the key range
   int sorted_cooldown = 0;   // ordered joins left before the one-pass ordered write is tried again
   bool sorted_mode = true;   // HMJ_SORTED_WRITE=0: ordered joins always take write + order epilogue
   bool sorted_chained = false;  // dense output offsets by a chained scan over the partitions (adaptive: on after an

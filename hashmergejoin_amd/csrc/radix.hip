@@ -1113,6 +1113,7 @@ __global__ void part_offsets_kernel(const Tup* __restrict__ a, u32 n, int low, i
 // out[0] = OR, out[1] = reference key.  A sample can miss outliers: the join stays correct for any
 // prefix (the partition id is a function of the key); ordered output additionally verifies it.
 // ---------------------------------------------------------------------------------------------
+// out[4] / out[5]: smallest / largest sampled build key (the planner's estimate of the build side's key range).
 // out[2] / out[3]: number of neighbouring sample positions of the build / probe relation that carry the SAME
 // key (a hint that costs two shuffles: unique keys give 0; a key that holds 5 % of a relation makes ~5 of the
 // 2048 neighbouring pairs equal).
@@ -1120,15 +1121,24 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
                                                           const Tup* __restrict__ S, u32 np,
                                                           u64* __restrict__ out) {
   __shared__ u64 acc;
+  __shared__ unsigned long long rng[2];  // smallest / largest sampled build key
+  __shared__ u32 bins[64];               // sampled build keys per 64th of that range
   __shared__ u32 same[2];
   const int tid = threadIdx.x, lane = tid & 63;
   const u64* rk = reinterpret_cast<const u64*>(R);
   const u64* sk = reinterpret_cast<const u64*>(S);
   const u64 ref = nb ? rk[0] : (np ? sk[0] : 0);
-  if (tid == 0) acc = 0;
+  if (tid == 0) {
+    acc = 0;
+    rng[0] = ~0ull;
+    rng[1] = 0;
+  }
   if (tid < 2) same[tid] = 0;
+  if (tid < 64) bins[tid] = 0;
   __syncthreads();
-  u64 x = 0;
+  u64 x = 0, mn = ~0ull, mx = 0;
+  u64 mykey[2] = {0, 0};
+  bool myvalid[2] = {false, false};
   u32 eq_r = 0, eq_s = 0;
   const u32 sr = nb / 2048 + 1, ss = np / 2048 + 1;  // ~2048 samples per relation
 #pragma unroll
@@ -1136,26 +1146,63 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
     const u64 i = (u64)(tid + k * 1024) * sr, j = (u64)(tid + k * 1024) * ss;
     const bool vr = i < nb, vs = j < np;
     const u64 kr = vr ? rk[2 * i] : 0, ks = vs ? sk[2 * j] : 0;
-    if (vr) x |= kr ^ ref;
+    if (vr) {
+      x |= kr ^ ref;
+      mn = kr < mn ? kr : mn;
+      mx = kr > mx ? kr : mx;
+      mykey[k] = kr;
+      myvalid[k] = true;
+    }
     if (vs) x |= ks ^ ref;
     const u64 kr_next = __shfl_down(kr, 1, kWave), ks_next = __shfl_down(ks, 1, kWave);
     const bool vr_next = __shfl_down((int)vr, 1, kWave) != 0, vs_next = __shfl_down((int)vs, 1, kWave) != 0;
     if (lane < 63 && vr && vr_next && kr == kr_next) eq_r++;
     if (lane < 63 && vs && vs_next && ks == ks_next) eq_s++;
   }
-  if (nb) x |= rk[2 * (u64)(nb - 1)] ^ ref;
+  if (nb) {
+    const u64 kl = rk[2 * (u64)(nb - 1)];
+    x |= kl ^ ref;
+    mn = kl < mn ? kl : mn;
+    mx = kl > mx ? kl : mx;
+  }
   if (np) x |= sk[2 * (u64)(np - 1)] ^ ref;
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) x |= __shfl_xor(x, o, kWave);
   if ((tid & 63) == 0 && x) atomicOr(&acc, x);
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    const u64 a2 = __shfl_xor(mn, o, kWave), b2 = __shfl_xor(mx, o, kWave);
+    mn = a2 < mn ? a2 : mn;
+    mx = b2 > mx ? b2 : mx;
+  }
+  if ((tid & 63) == 0 && nb) {
+    atomicMin(&rng[0], (unsigned long long)mn);
+    atomicMax(&rng[1], (unsigned long long)mx);
+  }
   if (eq_r) atomicAdd(&same[0], eq_r);
   if (eq_s) atomicAdd(&same[1], eq_s);
+  __syncthreads();
+  {  // how evenly the sampled build keys fill their range: 64 equal bins
+    const u64 lo = rng[0], span = rng[1] - rng[0];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (myvalid[k] && span) atomicAdd(&bins[(u32)((mykey[k] - lo) / ((span >> 6) + 1)) & 63u], 1u);
+  }
   __syncthreads();
   if (tid == 0) {
     out[0] = acc;
     out[1] = ref;
     out[2] = same[0];
     out[3] = same[1];
+    out[4] = rng[0];  // (~0, 0 without build rows)
+    out[5] = rng[1];
+    u32 nonempty = 0, big = 0;
+    for (int i = 0; i < 64; i++) {
+      nonempty += bins[i] ? 1u : 0u;
+      big = bins[i] > big ? bins[i] : big;
+    }
+    out[6] = nonempty;  // bins (64ths of the build key range) that hold a sampled build key
+    out[7] = big;       // ... and the fullest bin
   }
 }
 

@@ -113,6 +113,7 @@ typedef struct {
 #define HMJ_PATH_SLAB_PROBE 0x400u     /* probe-heavy count join: build side exact, probe side in slabs   */
 #define HMJ_PATH_SORTED_WRITE 0x800u   /* ordered join probed, sorted and written in one pass             */
 #define HMJ_PATH_SORTED_FK 0x1000u     /* ... in its foreign-key form (probe keys repeat)                 */
+#define HMJ_PATH_DENSE_BUILD 0x2000u   /* build keys cover part of the key range: plan sized by their density */
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* Replaces: nothing in the reference (no device); one ctx per GPU. device_id < 0 = current.     */

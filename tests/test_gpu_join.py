@@ -957,6 +957,38 @@ def test_one_pass_ordered_write_gives_up_on_clustered_keys(ex_fresh, H, oracle):
     ex.release_result()
 
 
+def test_build_keys_in_part_of_the_key_range_get_a_denser_plan(ex_fresh, H, oracle):
+    # build keys below 2^62 (a quarter of the range the probe keys span), evenly spread: every build partition would
+    # hold four times the planned rows and overflow the LDS table.  The key sample reports the build side's range
+    # and how evenly it is filled; the plan then spends two more bits (HMJ_PATH_DENSE_BUILD) and the join stays on
+    # the pipelined kernels.  Clustered build keys (three tags) do not qualify.
+    ex = ex_fresh
+    n = 600000
+    B, P = oracle.gen_build(n), oracle.gen_probe(n, n, miss_mod=3)
+    B[:, 0] >>= np.uint64(2)
+    P[::2, 0] = B[::2, 0][: len(P[::2])]  # half of the probe rows hit the squeezed keys, the rest stay wide
+    ck, rows = oracle.equijoin(B, P)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    assert r.checks() == ck
+    assert t["path"] & H.HMJ_PATH_DENSE_BUILD and not (t["path"] & H.HMJ_PATH_SPLIT), hex(t["path"])
+    bits_dense = t["radix_bits"]
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    assert r.checks() == ck and np.array_equal(sorted_rows(ex.columns_to_numpy(r, host=False)), rows)
+    ex.release_result()
+    Bw = oracle.gen_build(n)  # the same size over the whole range: two bits fewer
+    r = ex.join_device(to_dev(Bw), to_dev(oracle.gen_probe(n, n)), 0)
+    assert ex.last_timing()["radix_bits"] == bits_dense - 2 and not (ex.last_timing()["path"] & H.HMJ_PATH_DENSE_BUILD)
+    Bt = oracle.gen_build(n)
+    Bt[:, 0] = ((np.arange(n, dtype=np.uint64) % np.uint64(3)) << np.uint64(61)) | (Bt[:, 0] >> np.uint64(30))
+    Bt = Bt[np.sort(np.unique(Bt[:, 0], return_index=True)[1])]
+    ck, _ = oracle.equijoin(Bt, Bt, cap=0)
+    r = ex.join_device(to_dev(Bt), to_dev(Bt), H.HMJ_CHECKSUM)
+    assert r.checks() == ck and not (ex.last_timing()["path"] & H.HMJ_PATH_DENSE_BUILD)
+    ex.set_profiling(False)
+
+
 def test_prepared_build_side(ex, H, oracle):
     # hmj_prepare_build_u64_device: partition R ahead of the join (one-shot), for both partitioning paths
     for nb, npb in [(1 << 22, (1 << 22) + 999), (300000, 200000)]:
