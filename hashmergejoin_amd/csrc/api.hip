@@ -522,8 +522,8 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
         // unmatched probe rows left gaps at the end of every partition's slots: the ordered epilogue closes them
         HIP_TRY(hmj::launch_scan_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p, P, c->stream));
         int retry = 0;
-        if ((rc = order_rows(c, nullptr, in_base32, in_base64, P, 1, low, out->n_matches, false, false, &rk, &rr, &rs,
-                             &retry)) != HMJ_OK)
+        if ((rc = order_rows(c, nullptr, in_base32, in_base64, P, 1, low, out->n_matches, false, out->n_matches > 2ull * nb,
+                             &rk, &rr, &rs, &retry)) != HMJ_OK)
           return rc;
       }
       return deliver(rk, rr, rs);
