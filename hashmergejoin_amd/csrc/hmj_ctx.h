@@ -63,6 +63,14 @@ struct hmj_ctx {
   } prep;
   bool prepare_only = false;
   int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
+  // placement of the big slab buffers (api.hip, slab branch): the buffer a role was last tuned for
+  struct Place {
+    void* ptr = nullptr;
+    size_t cap = 0;
+  } place[3];  // slab_a, slab_br, slab_bs
+  int place_tries = 4;     // candidates per buffer (HMJ_PLACE=n)
+  hipEvent_t place_ev[2] = {nullptr, nullptr};
+  bool place_tune = true;  // HMJ_PLACE=0: take the buffers as the driver hands them out
   bool dense_plan = true;    // HMJ_DENSE_PLAN=0: never size the plan by the build keys' share of the key range
   int sorted_cooldown = 0;   // ordered joins left before the one-pass ordered write is tried again
   bool sorted_mode = true;   // HMJ_SORTED_WRITE=0: ordered joins always take write + order epilogue
