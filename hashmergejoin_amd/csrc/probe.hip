@@ -1115,10 +1115,16 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
                 const u32 si = found[k], base = sm.mcnt[si];
                 const u32 c = (si + 1 < CAPB ? sm.mcnt[si + 1] : total) - base;
                 if (c > 1) {
-                  u32 r = 0;
+                  u32 r = 0, e = 0;  // smaller payloads; equal ones (the row itself is one of them)
                   for (u32 j = 0; j < c; j++) {
                     const u64 ov = sm.sval[base + j];
-                    r += (ov < pr[k].val || (ov == pr[k].val && j < slot[k])) ? 1u : 0u;
+                    r += ov < pr[k].val ? 1u : 0u;
+                    e += ov == pr[k].val ? 1u : 0u;
+                  }
+                  if (e > 1) {  // equal payloads inside the run (rare): they line up by arrival
+                    e = 0;
+                    for (u32 j = 0; j < slot[k]; j++) e += sm.sval[base + j] == pr[k].val ? 1u : 0u;
+                    r += e;
                   }
                   rnk[k] = base + r;
                 }
