@@ -68,6 +68,59 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
     return fail(c, HMJ_E_OOM, "hipMalloc", e);
   }
   b.cap = want;
+  // ---- placement.  How fast a buffer can be WRITTEN depends on the physical memory the driver backs it with
+  // (tools/micro/place_bw.hip: ten 5.6 GiB allocations of one process fill at 4.4-4.6 TB/s or
+  // at 5.3-5.7 TB/s, the same buffer always the same; reads do not care).  The partition passes write every big
+  // buffer they touch, so a big allocation is probed -- filled twice, the second fill timed -- and, while it
+  // fills slower than a good one does, another candidate is allocated (with the previous ones still held, so it is
+  // other memory) and the best is kept.  At most c->place_tries candidates (HMJ_PLACE=n; 0 = take what comes).
+  if (c && c->place_tune && want >= (512ull << 20) && &b != &c->in_r && &b != &c->in_s) {  // (not the upload targets)
+    if (!c->place_ev[0]) {
+      if (hipEventCreate(&c->place_ev[0]) != hipSuccess || hipEventCreate(&c->place_ev[1]) != hipSuccess) {
+        (void)hipGetLastError();
+        c->place_tune = false;
+      }
+    }
+    const double good = 5.2e9;  // bytes per ms
+    auto probe = [&](void* p) -> double {
+      float ms = 0.f;
+      if (hmj::launch_fill_probe(p, want, c->stream) != hipSuccess) return 0.0;  // (first touch)
+      if (hipEventRecord(c->place_ev[0], c->stream) != hipSuccess) return 0.0;
+      if (hmj::launch_fill_probe(p, want, c->stream) != hipSuccess) return 0.0;
+      if (hipEventRecord(c->place_ev[1], c->stream) != hipSuccess) return 0.0;
+      if (hipEventSynchronize(c->place_ev[1]) != hipSuccess) return 0.0;
+      if (hipEventElapsedTime(&ms, c->place_ev[0], c->place_ev[1]) != hipSuccess || ms <= 0.f) return 0.0;
+      return (double)want / (double)ms;
+    };
+    double best_rate = c->place_tune ? probe(b.p) : 0.0;
+    void* held = nullptr;  // the latest loser: freed only after the next candidate exists
+    int tried = 1;
+    for (; c->place_tune && tried < c->place_tries && best_rate > 0.0 && best_rate < good; tried++) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < want + (8ull << 30)) break;
+      void* cand = nullptr;
+      if (hipMalloc(&cand, want) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      if (held) {
+        (void)hipFree(held);
+        held = nullptr;
+      }
+      const double r = probe(cand);
+      if (r > best_rate) {
+        held = b.p;
+        b.p = cand;
+        best_rate = r;
+      } else {
+        held = cand;
+      }
+    }
+    if (held) (void)hipFree(held);
+    if (c->trace)
+      std::fprintf(stderr, "[hmj]   placement: %.1f MiB fill at %.2f TB/s after %d candidate%s\n", (double)want / 1048576.0,
+                   best_rate * 1e-9, tried, tried == 1 ? "" : "s");
+  }
   if (c && c->trace && want >= (64u << 20))
     std::fprintf(stderr, "[hmj] hipMalloc %.1f MiB -> %p (low 30 bits %#llx)\n", (double)want / 1048576.0, b.p,
                  (unsigned long long)((uintptr_t)b.p & ((1ull << 30) - 1)));
@@ -777,69 +830,6 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     u64* acc = (u64*)c->accum.p;
     struct { const void* in; u32 n; const hmj::SlabGeom* g; DevBuf* sb; u32* cb; int rel; } side[2] = {
         {R, nb, &gr, &c->slab_br, (u32*)c->cnt_br.p, 0}, {S, np, &gs, &c->slab_bs, (u32*)c->cnt_bs.p, 1}};
-    // ---- placement of the three big slab buffers.  How fast a pass writes a buffer depends on which physical
-    // memory the driver gave it (the same virtual address freed and allocated again takes
-    // pass A 1.49 ms one time and 1.75 ms the next; on some boxes every allocation is a slow one, on most they are
-    // mixed).  So the first join that uses a freshly allocated buffer times the pass that writes it (second
-    // launch: the first touches fresh memory) and, while the rate is below what a good buffer gives, allocates
-    // another candidate -- the best one so far stays allocated, so the next one gets other memory -- and runs the
-    // pass again into it.  At most c->place_tries candidates per buffer (4; HMJ_PLACE=n, 0 = off), only for
-    // relations of 2^26 rows and more, only while the device has room; every later join just uses the buffers.
-    // Measured over seven process pairs at 2^28 rows: 7.90 ms per join with, 8.08 ms without (and 8.26 -> 8.03 ms
-    // for the worst process); the first join pays 50-80 ms for it.
-    const bool tune = c->place_tune && c->arrive_ev.empty() && nb >= (1u << 26) && np_plan >= (1u << 26);
-    auto placed_launch = [&](int role, DevBuf& buf, u64 n_rows, double good_bytes_per_ms, auto&& launch) -> int {
-      hmj_ctx::Place& pl = c->place[role];
-      if (!tune || (pl.ptr == buf.p && pl.cap == buf.cap)) {
-        HIP_TRY(launch());
-        return HMJ_OK;
-      }
-      if (!c->place_ev[0]) {
-        HIP_TRY(hipEventCreate(&c->place_ev[0]));
-        HIP_TRY(hipEventCreate(&c->place_ev[1]));
-      }
-      const size_t cap = buf.cap;
-      void* best = nullptr;
-      float best_ms = 0.f;
-      bool in_best = false;  // the pass's output is in `best`
-      for (int t = 0; t < c->place_tries; t++) {
-        HIP_TRY(launch());  // (first touch of fresh memory: not what later joins will see)
-        HIP_TRY(hipEventRecord(c->place_ev[0], c->stream));
-        HIP_TRY(launch());
-        HIP_TRY(hipEventRecord(c->place_ev[1], c->stream));
-        HIP_TRY(hipEventSynchronize(c->place_ev[1]));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->place_ev[0], c->place_ev[1]));
-        if (c->trace)
-          std::fprintf(stderr, "[hmj]   placement %s candidate %d at %p: %.3f ms (%.2f TB/s)\n",
-                       role == 0 ? "slab_a" : role == 1 ? "slab_br" : "slab_bs", t, buf.p, ms, 32e-9 * (double)n_rows / ms);
-        if (!best || ms < best_ms) {
-          if (best) (void)hipFree(best);
-          best = buf.p;
-          best_ms = ms;
-          in_best = true;
-        } else {
-          (void)hipFree(buf.p);
-          in_best = false;
-        }
-        buf.p = best;
-        if (32.0 * (double)n_rows / best_ms >= good_bytes_per_ms || t + 1 == c->place_tries) break;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < cap + (8ull << 30)) break;
-        void* cand = nullptr;
-        if (hipMalloc(&cand, cap) != hipSuccess) {
-          (void)hipGetLastError();
-          break;
-        }
-        buf.p = cand;  // the next round writes into the candidate
-      }
-      buf.p = best;
-      buf.cap = cap;
-      pl.ptr = buf.p;
-      pl.cap = buf.cap;
-      if (!in_best) HIP_TRY(launch());  // (the last candidate lost: the pass's output belongs into the buffer kept)
-      return HMJ_OK;
-    };
     for (auto& sd : side) {
       if (sd.rel == 0 && reuse) continue;            // build side already in slab_br / cnt_br
       if (sd.rel == 1 && c->prepare_only) continue;  // hmj_prepare_build: build side only
@@ -858,18 +848,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
           }
         }
       } else {
-        if ((rc = placed_launch(0, c->slab_a, sd.n, 5.58e9, [&]() {
-               return hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream);
-             })) != HMJ_OK)
-          return rc;
+        HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
       }
       span_end(c, sp);
       sp = span_begin(c, K_SCATTER, sd.rel, 1);
-      if ((rc = placed_launch(1 + sd.rel, *sd.sb, sd.n, 5.30e9, [&]() {
-             return hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, *sd.g, sd.sb->p, sd.cb, acc,
-                                       c->stream);
-           })) != HMJ_OK)
-        return rc;
+      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, *sd.g, sd.sb->p, sd.cb, acc,
+                                 c->stream));
       span_end(c, sp);
       c->timing.bytes_scatter += 2 * 32ull * sd.n;
     }
@@ -1307,7 +1291,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
-  if (const char* e = getenv("HMJ_PLACE")) {  // 0: off; n: at most n candidates per buffer
+  if (const char* e = getenv("HMJ_PLACE")) {  // 0: off; n: at most n candidates per big allocation
     c->place_tune = atoi(e) != 0;
     if (atoi(e) > 0) c->place_tries = atoi(e);
   }

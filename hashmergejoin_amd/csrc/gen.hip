@@ -138,6 +138,20 @@ __global__ void rows_gather_kernel(const u64* __restrict__ in, const Tup* __rest
 __global__ void pairs_val_u32_kernel(const Tup* __restrict__ sorted, u64 n, u32* __restrict__ out) {
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = (u32)sorted[i].val;
 }
+// Fill a buffer with 16-byte nontemporal stores (the allocator's write-bandwidth probe, api.hip ensure_dev).
+__global__ __launch_bounds__(512) void fill_probe_kernel(uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    __builtin_nontemporal_store(0u, &dst[i].x);
+    __builtin_nontemporal_store(0u, &dst[i].y);
+    __builtin_nontemporal_store(0u, &dst[i].z);
+    __builtin_nontemporal_store(0u, &dst[i].w);
+  }
+}
+hipError_t launch_fill_probe(void* p, size_t bytes, hipStream_t st) {
+  hipLaunchKernelGGL(fill_probe_kernel, dim3(4096), dim3(512), 0, st, static_cast<uint4*>(p), bytes / 16);
+  return hipGetLastError();
+}
+
 hipError_t launch_rows_key_idx(const void* rows, u64 n, u32 words, u32 key_word, void* out, hipStream_t st) {
   hipLaunchKernelGGL(rows_key_idx_kernel, dim3(2048), dim3(256), 0, st, static_cast<const u64*>(rows), n, words, key_word,
                      static_cast<Tup*>(out));

@@ -63,12 +63,8 @@ struct hmj_ctx {
   } prep;
   bool prepare_only = false;
   int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
-  // placement of the big slab buffers (api.hip, slab branch): the buffer a role was last tuned for
-  struct Place {
-    void* ptr = nullptr;
-    size_t cap = 0;
-  } place[3];  // slab_a, slab_br, slab_bs
-  int place_tries = 4;     // candidates per buffer (HMJ_PLACE=n)
+  // placement of big allocations (ensure_dev, api.hip): candidates are probed with a fill and the fastest kept
+  int place_tries = 3;     // candidates per allocation (HMJ_PLACE=n); a fresh candidate of 6 GB costs ~150 ms (the driver clears it)
   hipEvent_t place_ev[2] = {nullptr, nullptr};
   bool place_tune = true;  // HMJ_PLACE=0: take the buffers as the driver hands them out
   bool dense_plan = true;    // HMJ_DENSE_PLAN=0: never size the plan by the build keys' share of the key range

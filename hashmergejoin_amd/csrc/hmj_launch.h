@@ -124,6 +124,7 @@ hipError_t launch_split_parts(const u32* r_off, const u32* s_off, u32 P, u32 thr
                               u32 build_slice, u32 cap_v, u32* vstart, u32* vr_beg, u32* vr_end, u32* vs_beg,
                               u32* vs_end, u32* nv_out, hipStream_t st);
 hipError_t launch_key_idx(const u64* key, u64 n, void* out, hipStream_t st);
+hipError_t launch_fill_probe(void* p, size_t bytes, hipStream_t st);
 hipError_t launch_rows_key_idx(const void* rows, u64 n, u32 words, u32 key_word, void* out, hipStream_t st);
 hipError_t launch_rows_gather(const void* in, const void* sorted, u64 n, u32 words, void* out, hipStream_t st);
 hipError_t launch_pairs_val_u32(const void* sorted, u64 n, u32* out, hipStream_t st);
