@@ -81,7 +81,9 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
         c->place_tune = false;
       }
     }
-    const double good = 5.2e9;  // bytes per ms
+    // "good": 5.2 TB/s (bytes per ms) -- or, once this context has seen what the box gives, 92 % of the best fill so
+    // far if that is less (a box where every allocation writes slowly should not pay for two more candidates each time)
+    const double good = c->place_best > 0.0 && 0.92 * c->place_best < 5.2e9 ? 0.92 * c->place_best : 5.2e9;
     auto probe = [&](void* p) -> double {
       float ms = 0.f;
       if (hmj::launch_fill_probe(p, want, c->stream) != hipSuccess) return 0.0;  // (first touch)
@@ -117,6 +119,7 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
       }
     }
     if (held) (void)hipFree(held);
+    if (best_rate > c->place_best) c->place_best = best_rate;
     if (c->trace)
       std::fprintf(stderr, "[hmj]   placement: %.1f MiB fill at %.2f TB/s after %d candidate%s\n", (double)want / 1048576.0,
                    best_rate * 1e-9, tried, tried == 1 ? "" : "s");
