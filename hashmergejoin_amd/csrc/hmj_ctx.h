@@ -64,7 +64,7 @@ struct hmj_ctx {
   bool prepare_only = false;
   int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
   // placement of big allocations (ensure_dev, api.hip): candidates are probed with a fill and the fastest kept
-  int place_tries = 3;     // candidates per allocation (HMJ_PLACE=n); a fresh candidate of 6 GB costs ~150 ms (the driver clears it)
+  int place_tries = 4;     // candidates per allocation (HMJ_PLACE=n); a fresh candidate of 6 GB costs ~150 ms (the driver clears it)
   hipEvent_t place_ev[2] = {nullptr, nullptr};
   double place_best = 0.0;  // best fill rate (bytes per ms) any probed allocation of this context reached
   bool place_tune = true;  // HMJ_PLACE=0: take the buffers as the driver hands them out
