@@ -150,16 +150,73 @@ def extra_runs(ex, H, torch):
     thr[~big] = (cdf[~big] * 2.0 ** 64).astype(np.uint64)
     thr[big] = np.uint64((1 << 64) - 1)
     thr[-1] = np.uint64((1 << 64) - 1)
-    Rz = ex.gen_from_cdf(nb, torch.from_numpy(thr.view(np.int64).copy()).cuda())
+    thr_dev = torch.from_numpy(thr.view(np.int64).copy()).cuda()
+    Rz = ex.gen_from_cdf(nb, thr_dev)
     Sz = ex.gen_uniform_domain(npb, nb)
     ms, r = timed(lambda: ex.join_device(Rz, Sz, 0), reps=2)
     out["configs4_zipf_2p24_x_2p30_count_ms"] = ms
     out["configs4_matches"] = int(r.n_matches)
+    cross = {k: int(getattr(r, k)) for k in ("n_matches", "sum_r", "sum_s")}
     ms, r = timed(lambda: ex.join_device(Rz, Sz, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE), reps=2)
     out["configs4_first_wins_ms"] = ms
+    # checked, not just printed: counts and sums recomputed in the generators' rank domain with plain torch ops
+    # (tools/closed_forms.py; independent of the join kernels), cross product and first-wins (partitioned_hash.h:166-170)
+    from tools.closed_forms import config5_checks
+
+    want = config5_checks(torch, nb, npb, nb, thr_dev)
+    assert cross == want["cross"], ("configs[4] cross product", cross, want["cross"])
+    fwv = {k: int(getattr(r, k)) for k in ("n_matches", "sum_r", "sum_s")}
+    assert fwv == want["first_wins"] and int(r.sum_probe_all) == want["sum_probe_all"], ("configs[4] first-wins", fwv, want)
+    out["configs4_checked"] = "n_matches / sum_r / sum_s of both modes == torch rank-domain closed forms"
     del Rz, Sz
     torch.cuda.empty_cache()
     return out
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this parent starts N fresh child processes
+    -- one rank each, the same command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- relays rank 0's JSON line
+    and returns the worst child status.  The parent never touches the GPU (no torch import, no HIP call): every
+    rank initialises its GPU in a process of its own, as under torch.distributed.run.  The reference reaches all
+    of its workers from one call the same way (hashjoin.h:56-68 -> radix_hash.h:375-405)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HMJ_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # rank 0 prints the line; EOF when it exits
+    # a rank that dies leaves the others in a collective: once one child has failed, the rest get 30 s, then are
+    # stopped (each by its own handle)
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    worst = 0
+    for p in procs:
+        rc = p.returncode
+        if rc != 0 and (worst == 0 or abs(rc) > abs(worst)):
+            worst = rc
+    sys.stdout.write(b"".join(out0).decode(errors="replace"))
+    sys.stdout.flush()
+    return worst if worst >= 0 else 128 - worst
 
 
 def main():
@@ -175,6 +232,9 @@ def main():
     ap.add_argument("--bits", type=int, default=-1, help="force total radix bits")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))  # before anything touches the GPU
+
     import torch
     import torch.distributed as dist
 
@@ -185,11 +245,12 @@ def main():
     force_dist = os.environ.get("HMJ_FORCE_DIST") == "1"  # dev: run the exchange path with 1 rank (RCCL self send/recv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-    backend = os.environ.get("HMJ_DIST_BACKEND", "nccl")  # "gloo": rehearse N ranks on one GPU (callback transport)
-    ndev = torch.cuda.device_count()
+    if a.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running %d ranks" % (a.gpus, world, world), file=sys.stderr)
+    ndev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    # RCCL refuses two ranks on one device: with fewer GPUs than ranks (rehearsals on a one-GPU box) the ranks share
+    # the GPUs and the exchange runs over the library's callback transport on gloo; HMJ_DIST_BACKEND overrides
+    backend = os.environ.get("HMJ_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
     local_dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -224,8 +285,13 @@ def main():
         loc, glob = ex.exchange_join(R, S, flags)  # owner split, exchange rounds, prepared build, local join
         return glob, ex.last_timing(), ex.last_exchange_info()
 
-    for _ in range(a.warmup):
+    first_ms = None
+    for i in range(a.warmup):
+        t_w = time.perf_counter()
         res, _, _ = step()
+        if i == 0:
+            torch.cuda.synchronize()
+            first_ms = (time.perf_counter() - t_w) * 1e3  # creates the workspace (and probes its placement)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -327,6 +393,11 @@ def main():
             "roofline_probe": dict(roof(pr_bytes, pr_ms), kernel=pr_kernel,
                                    probe_tuples_per_s=round(last_tm["bytes_probe_count"] / 32.0 / (pr_ms * 1e-3)) if pr_ms > 0 else None),
             "phases_ms_per_step": {k[3:]: round(v / K, 4) for k, v in agg.items() if k.startswith("ms_")},
+            # why the scatter passes ran at the rate they did on THIS box: the fill rate of each partition buffer the
+            # library kept (write bandwidth is a property of the physical memory behind a buffer)
+            "placement": {"probing": os.environ.get("HMJ_PLACE", "default (on, <= 4 candidates)"),
+                          "buffers": ex.placement_info(),
+                          "first_join_ms": None if first_ms is None else round(first_ms, 2)},
         }
         if distributed:
             line["exchange"] = dict({k[3:]: round(v / K, 3) for k, v in xagg.items()}, unit="ms per step on rank 0",

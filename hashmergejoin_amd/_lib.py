@@ -53,6 +53,11 @@ class Timing(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class PlaceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 16), ("bytes", C.c_uint64), ("fill_TBps", C.c_float), ("candidates", C.c_int),
+                ("ms_search", C.c_float)]
+
+
 def lib_path():
     # HMJ_LIB: developer override to A/B an alternative build of the same library
     return os.environ.get("HMJ_LIB") or os.path.join(_HERE, "libhmj_hip.so")
@@ -113,6 +118,8 @@ def load_library():
     L.hmj_set_profiling.argtypes = [vp, i]
     L.hmj_last_timing.restype = i
     L.hmj_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.hmj_placement_info.restype = i
+    L.hmj_placement_info.argtypes = [vp, C.POINTER(PlaceInfo), i]
     L.hmj_strerror.restype = cp
     L.hmj_strerror.argtypes = [i]
     L.hmj_last_error.restype = cp

@@ -69,18 +69,25 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
   }
   b.cap = want;
   // ---- placement.  How fast a buffer can be WRITTEN depends on the physical memory the driver backs it with
-  // (tools/micro/place_bw.hip: ten 5.6 GiB allocations of one process fill at 4.4-4.6 TB/s or
-  // at 5.3-5.7 TB/s, the same buffer always the same; reads do not care).  The partition passes write every big
-  // buffer they touch, so a big allocation is probed -- filled twice, the second fill timed -- and, while it
-  // fills slower than a good one does, another candidate is allocated (with the previous ones still held, so it is
-  // other memory) and the best is kept.  At most c->place_tries candidates (HMJ_PLACE=n; 0 = take what comes).
-  if (c && c->place_tune && want >= (512ull << 20) && &b != &c->in_r && &b != &c->in_s) {  // (not the upload targets)
+  // (tools/micro/place_bw.hip, place_vmm.hip: allocations of one process fill at 4.4-4.6 TB/s or
+  // at 5.3-5.7 TB/s, the same buffer always the same, whichever API created it; reads do not care).  Only the buffers
+  // the partition passes write -- where the effect was measured -- are probed: filled twice, the second fill timed,
+  // and while one fills slower than a good one does, another candidate is allocated (the previous one still held, so
+  // it is other memory) and the best is kept.  At most c->place_tries candidates (HMJ_PLACE=n; 0 = take what comes).
+  // Exchange buffers, result columns and upload targets are never probed (their (re)growth must not stall
+  // in-flight rounds with extra device-synchronising hipMalloc / hipFree calls).
+  const char* pname = !c ? nullptr
+                      : &b == &c->slab_a ? "slab_a" : &b == &c->slab_br ? "slab_b_build" : &b == &c->slab_bs ? "slab_b_probe"
+                      : &b == &c->rbuf[0] ? "rbuf0" : &b == &c->rbuf[1] ? "rbuf1" : &b == &c->sbuf[0] ? "sbuf0"
+                      : &b == &c->sbuf[1] ? "sbuf1" : nullptr;
+  if (c && c->place_tune && pname && want >= (512ull << 20)) {
     if (!c->place_ev[0]) {
       if (hipEventCreate(&c->place_ev[0]) != hipSuccess || hipEventCreate(&c->place_ev[1]) != hipSuccess) {
         (void)hipGetLastError();
         c->place_tune = false;
       }
     }
+    const auto t_search = std::chrono::steady_clock::now();
     // "good": 5.2 TB/s (bytes per ms) -- or, once this context has seen what the box gives, 92 % of the best fill so
     // far if that is less (a box where every allocation writes slowly should not pay for two more candidates each time)
     const double good = c->place_best > 0.0 && 0.92 * c->place_best < 5.2e9 ? 0.92 * c->place_best : 5.2e9;
@@ -95,11 +102,17 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
       return (double)want / (double)ms;
     };
     double best_rate = c->place_tune ? probe(b.p) : 0.0;
-    void* held = nullptr;  // the latest loser: freed only after the next candidate exists
+    void* held = nullptr;  // the latest loser: freed only after the next candidate exists (so that one is other memory)
     int tried = 1;
     for (; c->place_tune && tried < c->place_tries && best_rate > 0.0 && best_rate < good; tried++) {
       size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < want + (8ull << 30)) break;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+      if (held && free_b < 3 * want) {  // memory is getting tight: at most two candidates alive at a time
+        (void)hipFree(held);
+        held = nullptr;
+        free_b += want;
+      }
+      if (free_b < want + (8ull << 30)) break;
       void* cand = nullptr;
       if (hipMalloc(&cand, want) != hipSuccess) {
         (void)hipGetLastError();
@@ -120,9 +133,23 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
     }
     if (held) (void)hipFree(held);
     if (best_rate > c->place_best) c->place_best = best_rate;
+    hmj_place_info pi;
+    std::memset(&pi, 0, sizeof(pi));
+    std::snprintf(pi.name, sizeof(pi.name), "%s", pname);
+    pi.bytes = want;
+    pi.fill_TBps = (float)(best_rate * 1e-9);
+    pi.candidates = tried;
+    pi.ms_search = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_search).count();
+    bool replaced = false;
+    for (hmj_place_info& e : c->place_log)
+      if (std::strcmp(e.name, pi.name) == 0) {
+        e = pi;
+        replaced = true;
+      }
+    if (!replaced) c->place_log.push_back(pi);
     if (c->trace)
-      std::fprintf(stderr, "[hmj]   placement: %.1f MiB fill at %.2f TB/s after %d candidate%s\n", (double)want / 1048576.0,
-                   best_rate * 1e-9, tried, tried == 1 ? "" : "s");
+      std::fprintf(stderr, "[hmj]   placement: %s %.1f MiB fill at %.2f TB/s after %d candidate%s (%.1f ms)\n", pname,
+                   (double)want / 1048576.0, best_rate * 1e-9, tried, tried == 1 ? "" : "s", pi.ms_search);
   }
   if (c && c->trace && want >= (64u << 20))
     std::fprintf(stderr, "[hmj] hipMalloc %.1f MiB -> %p (low 30 bits %#llx)\n", (double)want / 1048576.0, b.p,
@@ -828,11 +855,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     if ((rc = ensure_dev(c, c->cnt_a, ((size_t)wa << ba) * 4)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->slab_br, gr.rows_b * 16)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->slab_bs, gs.rows_b * 16)) != HMJ_OK) return rc;
-    if ((rc = ensure_dev(c, c->cnt_br, (size_t)P * 4 * 4)) != HMJ_OK) return rc;
-    if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * 4 * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_br, (size_t)P * gr.KB * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * gs.KB * 4)) != HMJ_OK) return rc;
     u64* acc = (u64*)c->accum.p;
-    struct { const void* in; u32 n; const hmj::SlabGeom* g; DevBuf* sb; u32* cb; int rel; } side[2] = {
-        {R, nb, &gr, &c->slab_br, (u32*)c->cnt_br.p, 0}, {S, np, &gs, &c->slab_bs, (u32*)c->cnt_bs.p, 1}};
+    struct { const void* in; u32 n; const hmj::SlabGeom* g; DevBuf* sb; DevBuf* cb; int rel; } side[2] = {
+        {R, nb, &gr, &c->slab_br, &c->cnt_br, 0}, {S, np, &gs, &c->slab_bs, &c->cnt_bs, 1}};
+    const u64 a_rows = c->slab_a.cap / 16, a_cnt = c->cnt_a.cap / 4;  // what is allocated: the launchers check it
     for (auto& sd : side) {
       if (sd.rel == 0 && reuse) continue;            // build side already in slab_br / cnt_br
       if (sd.rel == 1 && c->prepare_only) continue;  // hmj_prepare_build: build side only
@@ -846,17 +874,17 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
           const bool last = i + 1 == c->arrive_ev.size();
           const u32 w_end = last ? sd.g->WA : (u32)std::min<u64>(sd.g->WA, c->arrive_rows[i] / sd.g->rpw);
           if (w_end > w_done) {
-            HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream, w_done, w_end));
+            HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, a_rows, (u32*)c->cnt_a.p, a_cnt, acc, c->stream, w_done, w_end));
             w_done = w_end;
           }
         }
       } else {
-        HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
+        HIP_TRY(hmj::launch_slab_a(sd.in, sd.n, low, ba, *sd.g, c->slab_a.p, a_rows, (u32*)c->cnt_a.p, a_cnt, acc, c->stream));
       }
       span_end(c, sp);
       sp = span_begin(c, K_SCATTER, sd.rel, 1);
-      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, *sd.g, sd.sb->p, sd.cb, acc,
-                                 c->stream));
+      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, *sd.g, sd.sb->p, sd.sb->cap / 16,
+                                 (u32*)sd.cb->p, sd.cb->cap / 4, acc, c->stream));
       span_end(c, sp);
       c->timing.bytes_scatter += 2 * 32ull * sd.n;
     }
@@ -885,6 +913,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       wa.s_cnt = (const u32*)c->cnt_bs.p;
       wa.r_cap = gr.CB;
       wa.s_cap = gs.CB;
+      wa.r_cnt_n = c->cnt_br.cap / 4;
+      wa.s_cnt_n = c->cnt_bs.cap / 4;
+      wa.r_rows = c->slab_br.cap / 16;
+      wa.s_rows = c->slab_bs.cap / 16;
       wa.P = P;
       wa.Q = 1;
       wa.accum = acc;
@@ -899,6 +931,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     sa.s_cnt = (const u32*)c->cnt_bs.p;
     sa.r_cap = gr.CB;
     sa.s_cap = gs.CB;
+    sa.r_cnt_n = c->cnt_br.cap / 4;
+    sa.s_cnt_n = c->cnt_bs.cap / 4;
+    sa.r_rows = c->slab_br.cap / 16;
+    sa.s_rows = c->slab_bs.cap / 16;
     sa.P = P;
     sa.Q = 1;
     sa.accum = acc;
@@ -960,7 +996,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // partition's KB slab pieces as its KB probe slices.  Skewed probe keys overflow a slab: exact path.
   {
     hmj::SlabGeom gp;
-    const u32 kb = pass_bits[0] < 7 ? (512u >> pass_bits[0]) : 4u;  // 2^bits_a * KB >= 512 pass-B workers
+    // 2^bits_a * KB >= 512 pass-B workers (HMJ_SLAB_PROBE_KB: any piece count, for the bounds regression tests)
+    const u32 kb = c->slab_probe_kb ? c->slab_probe_kb : (pass_bits[0] < 7 ? (512u >> pass_bits[0]) : 4u);
     if (c->slab_probe_cooldown > 0 && allow_slab_probe) c->slab_probe_cooldown--;
     if (allow_slab_probe && c->slab_mode && c->slab_probe_cooldown == 0 && !materialize && !probe_fits && Q == 1 && passes == 2 &&
         pass_bits[0] <= 8 && pass_bits[1] <= 8 && np >= c->slab_min_rows && (u64)np >= 4ull * nb &&
@@ -973,11 +1010,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * kb * 4)) != HMJ_OK) return rc;
       u64* acc = (u64*)c->accum.p;
       int sp = span_begin(c, K_SCATTER, 1, 0);
-      HIP_TRY(hmj::launch_slab_a(S, np, low, ba, gp, c->slab_a.p, (u32*)c->cnt_a.p, acc, c->stream));
+      HIP_TRY(hmj::launch_slab_a(S, np, low, ba, gp, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->stream));
       span_end(c, sp);
       sp = span_begin(c, K_SCATTER, 1, 1);
-      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, gp, c->slab_bs.p, (u32*)c->cnt_bs.p,
-                                 acc, c->stream));
+      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, low + ba, bb, gp, c->slab_bs.p, c->slab_bs.cap / 16,
+                                 (u32*)c->cnt_bs.p, c->cnt_bs.cap / 4, acc, c->stream));
       span_end(c, sp);
       c->timing.bytes_scatter += 2 * 32ull * np;
       c->timing.path |= HMJ_PATH_SLAB_PROBE;
@@ -988,6 +1025,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       a.S = c->slab_bs.p;
       a.s_cnt = (const u32*)c->cnt_bs.p;
       a.s_cap = gp.CB;
+      a.s_cnt_n = c->cnt_bs.cap / 4;
+      a.s_rows = c->slab_bs.cap / 16;
       a.P = P;
       a.Q = kb;
       a.accum = acc;
@@ -1311,6 +1350,10 @@ int hmj_create(hmj_ctx** out, int device_id) {
     const int l = atoi(e);
     if (l >= 16 && l <= 31) c->slab_min_rows = 1u << l;
   }
+  if (const char* e = getenv("HMJ_SLAB_PROBE_KB")) {
+    const int k = atoi(e);
+    if (k >= 1 && k <= 512) c->slab_probe_kb = (u32)k;
+  }
   if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
   if (const char* e = getenv("HMJ_TRACE")) c->trace = atoi(e) != 0;
 #ifdef HMJ_DEV
@@ -1438,6 +1481,14 @@ int hmj_set_profiling(hmj_ctx* c, int enabled) {
   return HMJ_OK;
 }
 
+int hmj_placement_info(hmj_ctx* c, hmj_place_info* out, int max_entries) {
+  if (!c || !out || max_entries <= 0) return 0;
+  int n = 0;
+  for (const hmj_place_info& e : c->place_log)
+    if (n < max_entries) out[n++] = e;
+  return n;
+}
+
 int hmj_last_timing(hmj_ctx* c, hmj_timing* out) {
   if (!c || !out) return HMJ_E_ARG;
   *out = c->timing;
@@ -1506,8 +1557,8 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
       if ((rc = ensure_dev(c, c->cnt_a, ((size_t)wa << pass_bits[0]) * 4)) != HMJ_OK) return rc;
       if ((rc = ensure_dev(c, c->slab_br, gr.rows_b * 16)) != HMJ_OK) return rc;
       if ((rc = ensure_dev(c, c->slab_bs, gs.rows_b * 16)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->cnt_br, P * 4 * 4)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->cnt_bs, P * 4 * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_br, P * gr.KB * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_bs, P * gs.KB * 4)) != HMJ_OK) return rc;
     }
   }
   return HMJ_OK;

@@ -68,6 +68,7 @@ struct hmj_ctx {
   hipEvent_t place_ev[2] = {nullptr, nullptr};
   double place_best = 0.0;  // best fill rate (bytes per ms) any probed allocation of this context reached
   bool place_tune = true;  // HMJ_PLACE=0: take the buffers as the driver hands them out
+  std::vector<hmj_place_info> place_log;  // one entry per probed buffer (hmj_placement_info)
   bool dense_plan = true;    // HMJ_DENSE_PLAN=0: never size the plan by the build keys' share of the key range
   int sorted_cooldown = 0;   // ordered joins left before the one-pass ordered write is tried again
   bool sorted_mode = true;   // HMJ_SORTED_WRITE=0: ordered joins always take write + order epilogue
@@ -84,6 +85,7 @@ struct hmj_ctx {
   u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
                                  // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
+  u32 slab_probe_kb = 0;  // HMJ_SLAB_PROBE_KB: pieces per partition of the probe-side slabs (0 = 512 >> bits of pass A)
   int slab_probe_cooldown = 0;  // the same for the probe-side-only slab partitioning of probe-heavy count joins
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;

@@ -67,6 +67,14 @@ constexpr int PB_PLAN_SLACK = 256;     // planner: tolerated excess of that aver
 // write-combining passes) 12.45 ms per join vs 17 bits (avg 2048, 9+8) 13.02 ms, 18 bits 13.9 ms,
 // 15 bits 14.6 ms: fewer, larger partitions win as long as one still fits the LDS table.
 
+// ---- slab layout (radix.hip slab kernels -> probe.hip pipelined kernels) -------------------------------------
+// A final partition of the histogram-free path is SLAB_KB pieces (one per pass-B worker of its bucket).  The pipelined
+// probe kernels unroll exactly this many pieces; every count array is P * SLAB_KB entries, every slab buffer
+// P * SLAB_KB * cap rows.  ONE definition: the host sizes its buffers from it (api.hip, SlabGeom::KB) and the
+// launchers check the operands against it before a kernel runs.  (The generic probe kernel takes any KB as its
+// number of probe slices: probe-side slabs of probe-heavy joins.)
+constexpr int SLAB_KB = 4;
+
 // accumulator slots (global u64[8])
 enum { ACC_N = 0, ACC_SUM_R, ACC_SUM_S, ACC_XOR, ACC_MIX, ACC_SUM_P, ACC_ERR, ACC_PAD };
 constexpr u64 ERR_SLAB = 2;    // slab path: a slab overflowed or a partition does not fit -> exact path

@@ -56,10 +56,13 @@ struct SlabGeom {
 // kb: pieces per final partition (0 = 4, what the pipelined probe kernel reads)
 // fan: expected rows per distinct key (>= 1): widens the slabs by sqrt(fan) standard deviations
 bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb = 0, double fan = 1.0);
-hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a,
-                         u32* cnt_a, u64* accum, hipStream_t st, u32 w_begin = 0, u32 w_end = 0xFFFFFFFFu);
+// slab_*_rows / cnt_*_n: what the caller ALLOCATED (rows of 16 bytes, u32 entries).  The launchers compare them with
+// what the kernel and its grid will touch for this geometry and refuse (hipErrorInvalidValue) instead of launching
+// a kernel that would write past a buffer.
+hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows,
+                         u32* cnt_a, u64 cnt_a_n, u64* accum, hipStream_t st, u32 w_begin = 0, u32 w_end = 0xFFFFFFFFu);
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
-                         const SlabGeom& g, void* slab_b, u32* cnt_b, u64* accum, hipStream_t st);
+                         const SlabGeom& g, void* slab_b, u64 slab_b_rows, u32* cnt_b, u64 cnt_b_n, u64* accum, hipStream_t st);
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st);
 hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st);
 
@@ -84,6 +87,8 @@ struct ProbeArgs {
   const u32* r_cnt;
   const u32* s_cnt;
   u32 r_cap, s_cap;
+  u64 r_cnt_n, s_cnt_n;    // slab layout: u32 entries allocated behind r_cnt / s_cnt, rows allocated behind R / S --
+  u64 r_rows, s_rows;      // checked by the launchers against P * pieces (* cap) before a kernel runs
   const u64* item_base;    // unique-key write mode, slab layout: first output slot of partition p
   const u32* r_end;        // optional: end of partition p's build rows (NULL: r_off[p + 1]); with s_end this lets
   const u32* s_end;        // several "virtual" partitions share one build range (oversized probe partitions are split)

@@ -378,6 +378,7 @@ __device__ __forceinline__ void fp_load(Tup (&t)[FP_ROWS], const Tup* __restrict
 // <1024, 12>: partitions up to 5120 rows, 106 KiB LDS, 1 workgroup/CU
 // Slab layout loader: the partition is 4 pieces of up to `cap` rows; p1..p3 = prefix sums of the
 // first three piece counts (wave-uniform).
+static_assert(SLAB_KB == 4, "fp_load_slab / fp_load_pieces / slab_np_kernel unroll exactly four pieces per partition");
 template <int THREADS>
 __device__ __forceinline__ void fp_load_slab(Tup (&t)[FP_ROWS], const Tup* __restrict__ base, u32 cap,
                                              u32 p1, u32 p2, u32 p3, u32 n, int tid) {
@@ -459,8 +460,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
   bool slab_bad = false;
   if (p < P) {
     if (SLAB) {
-      const u32* rc = a.r_cnt + (u64)p * 4;
-      const u32* sc = a.s_cnt + (u64)p * 4;
+      const u32* rc = a.r_cnt + (u64)p * SLAB_KB;
+      const u32* sc = a.s_cnt + (u64)p * SLAB_KB;
       r1 = rc[0]; r2 = r1 + rc[1]; r3 = r2 + rc[2]; nb = r3 + rc[3];
       s1 = sc[0]; s2 = s1 + sc[1]; s3 = s2 + sc[2]; np = s3 + sc[3];
       if (nb > CAP || np > CAP) slab_bad = true;
@@ -480,11 +481,11 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     regular = nb && np && nb <= CAP && np <= CAP;
     if (regular) {
       if (PIECES) {
-        fp_load_pieces<THREADS>(br, R + (u64)p * 4 * a.r_cap, a.r_cap, rm, tid);
-        fp_load_pieces<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, sm_, tid);
+        fp_load_pieces<THREADS>(br, R + (u64)p * SLAB_KB * a.r_cap, a.r_cap, rm, tid);
+        fp_load_pieces<THREADS>(pr, S + (u64)p * SLAB_KB * a.s_cap, a.s_cap, sm_, tid);
       } else if (SLAB) {
-        fp_load_slab<THREADS>(br, R + (u64)p * 4 * a.r_cap, a.r_cap, r1, r2, r3, nb, tid);
-        if (OUT == 0) fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
+        fp_load_slab<THREADS>(br, R + (u64)p * SLAB_KB * a.r_cap, a.r_cap, r1, r2, r3, nb, tid);
+        if (OUT == 0) fp_load_slab<THREADS>(pr, S + (u64)p * SLAB_KB * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
       } else {
         fp_load<THREADS>(br, R + rb, nb, tid);
         if (OUT == 0) fp_load<THREADS>(pr, S + sb, np, tid);
@@ -498,18 +499,18 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
   const Tup* __restrict__ dummy = reinterpret_cast<const Tup*>(a.accum);
   auto load_build = [&](Tup (&t)[FP_ROWS], bool ok, u32 pp, u32 rb_, u32 nb_, u32 q1, u32 q2, u32 q3, u32 mine) {
     if (PIECES)
-      fp_load_pieces<THREADS>(t, ok ? R + (u64)pp * 4 * a.r_cap : dummy, ok ? a.r_cap : 0u, ok ? mine : 1u, tid);
+      fp_load_pieces<THREADS>(t, ok ? R + (u64)pp * SLAB_KB * a.r_cap : dummy, ok ? a.r_cap : 0u, ok ? mine : 1u, tid);
     else if (SLAB)
-      fp_load_slab<THREADS>(t, ok ? R + (u64)pp * 4 * a.r_cap : dummy, ok ? a.r_cap : 0u, ok ? q1 : 1u, ok ? q2 : 1u,
+      fp_load_slab<THREADS>(t, ok ? R + (u64)pp * SLAB_KB * a.r_cap : dummy, ok ? a.r_cap : 0u, ok ? q1 : 1u, ok ? q2 : 1u,
                             ok ? q3 : 1u, ok ? nb_ : 1u, tid);
     else
       fp_load<THREADS>(t, ok ? R + rb_ : dummy, ok ? nb_ : 1u, tid);
   };
   auto load_probe = [&](Tup (&t)[FP_ROWS], bool ok, u32 pp, u32 sb_, u32 np_, u32 q1, u32 q2, u32 q3, u32 mine) {
     if (PIECES)
-      fp_load_pieces<THREADS>(t, ok ? S + (u64)pp * 4 * a.s_cap : dummy, ok ? a.s_cap : 0u, ok ? mine : 1u, tid);
+      fp_load_pieces<THREADS>(t, ok ? S + (u64)pp * SLAB_KB * a.s_cap : dummy, ok ? a.s_cap : 0u, ok ? mine : 1u, tid);
     else if (SLAB)
-      fp_load_slab<THREADS>(t, ok ? S + (u64)pp * 4 * a.s_cap : dummy, ok ? a.s_cap : 0u, ok ? q1 : 1u, ok ? q2 : 1u,
+      fp_load_slab<THREADS>(t, ok ? S + (u64)pp * SLAB_KB * a.s_cap : dummy, ok ? a.s_cap : 0u, ok ? q1 : 1u, ok ? q2 : 1u,
                             ok ? q3 : 1u, ok ? np_ : 1u, tid);
     else
       fp_load<THREADS>(t, ok ? S + sb_ : dummy, ok ? np_ : 1u, tid);
@@ -520,8 +521,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     bool regular2 = false;
     if (pn < P) {
       if (SLAB) {
-        const u32* rc = a.r_cnt + (u64)pn * 4;
-        const u32* sc = a.s_cnt + (u64)pn * 4;
+        const u32* rc = a.r_cnt + (u64)pn * SLAB_KB;
+        const u32* sc = a.s_cnt + (u64)pn * SLAB_KB;
         r1n = rc[0]; r2n = r1n + rc[1]; r3n = r2n + rc[2]; nb2 = r3n + rc[3];
         s1n = sc[0]; s2n = s1n + sc[1]; s3n = s2n + sc[2]; np2 = s3n + sc[3];
         if (nb2 > CAP || np2 > CAP) slab_bad = true;
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       load_probe(pq, regular2, pn, sb2, np2, s1n, s2n, s3n, smn);  // next partition's probe rows, a whole partition ahead
     } else if (regular) {  // write mode keeps fewer rows in flight (registers): this partition's probe rows
       if (SLAB)
-        fp_load_slab<THREADS>(pr, S + (u64)p * 4 * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
+        fp_load_slab<THREADS>(pr, S + (u64)p * SLAB_KB * a.s_cap, a.s_cap, s1, s2, s3, np, tid);
       else
         fp_load<THREADS>(pr, S + sb, np, tid);
     }
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
       if (OUT == 1 && nb && np) giveup = true;  // does not fit the pipeline: general path
       if (OUT >= 1 && (a.extra & 1u) && !nb) {  // probe rows without a build partition still count in sum_probe_all
         if (SLAB) {
-          const Tup* base = S + (u64)p * 4 * a.s_cap;
+          const Tup* base = S + (u64)p * SLAB_KB * a.s_cap;
           for (u32 j = tid; j < np; j += THREADS) {
             const u32 pc = (j >= s1) + (j >= s2) + (j >= s3);
             const u32 pre = pc == 0 ? 0 : pc == 1 ? s1 : pc == 2 ? s2 : s3;
@@ -892,8 +893,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
   const Tup* __restrict__ dummy = reinterpret_cast<const Tup*>(a.accum);
   if (p < P) {
     if (SLAB) {
-      const u32* rc = a.r_cnt + (u64)p * 4;
-      const u32* sc = a.s_cnt + (u64)p * 4;
+      const u32* rc = a.r_cnt + (u64)p * SLAB_KB;
+      const u32* sc = a.s_cnt + (u64)p * SLAB_KB;
       r1 = rc[0]; r2 = r1 + rc[1]; r3 = r2 + rc[2]; nb = r3 + rc[3];
       s1 = sc[0]; s2 = s1 + sc[1]; s3 = s2 + sc[2]; np = s3 + sc[3];
       if (nb > CAPB || np > CAP) slab_bad = true;
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     }
     regular = nb && np && nb <= CAPB && np <= CAP;
     if (SLAB)
-      fp_load_slab<THREADS>(br, regular ? R + (u64)p * 4 * a.r_cap : dummy, regular ? a.r_cap : 0u, regular ? r1 : 1u,
+      fp_load_slab<THREADS>(br, regular ? R + (u64)p * SLAB_KB * a.r_cap : dummy, regular ? a.r_cap : 0u, regular ? r1 : 1u,
                             regular ? r2 : 1u, regular ? r3 : 1u, regular ? nb : 1u, tid);
     else
       fp_load<THREADS>(br, regular ? R + rb : dummy, regular ? nb : 1u, tid);
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     if (tid == 0) sm.tick[par ^ 1] = (u32)atomicAdd(ticket, 1ull);  // the partition after this one
     // this partition's probe rows (unconditional loads: see probe_count_fast_kernel)
     if (SLAB)
-      fp_load_slab<THREADS>(pr, regular ? S + (u64)p * 4 * a.s_cap : dummy, regular ? a.s_cap : 0u, regular ? s1 : 1u,
+      fp_load_slab<THREADS>(pr, regular ? S + (u64)p * SLAB_KB * a.s_cap : dummy, regular ? a.s_cap : 0u, regular ? s1 : 1u,
                             regular ? s2 : 1u, regular ? s3 : 1u, regular ? np : 1u, tid);
     else
       fp_load<THREADS>(pr, regular ? S + sb : dummy, regular ? np : 1u, tid);
@@ -945,8 +946,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     bool regular2 = false;
     if (pn < P) {
       if (SLAB) {
-        const u32* rc = a.r_cnt + (u64)pn * 4;
-        const u32* sc = a.s_cnt + (u64)pn * 4;
+        const u32* rc = a.r_cnt + (u64)pn * SLAB_KB;
+        const u32* sc = a.s_cnt + (u64)pn * SLAB_KB;
         r1n = rc[0]; r2n = r1n + rc[1]; r3n = r2n + rc[2]; nb2 = r3n + rc[3];
         s1n = sc[0]; s2n = s1n + sc[1]; s3n = s2n + sc[2]; np2 = s3n + sc[3];
         if (nb2 > CAPB || np2 > CAP) slab_bad = true;
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     }
     auto load_next_build = [&]() {
       if (SLAB)
-        fp_load_slab<THREADS>(br, regular2 ? R + (u64)pn * 4 * a.r_cap : dummy, regular2 ? a.r_cap : 0u,
+        fp_load_slab<THREADS>(br, regular2 ? R + (u64)pn * SLAB_KB * a.r_cap : dummy, regular2 ? a.r_cap : 0u,
                               regular2 ? r1n : 1u, regular2 ? r2n : 1u, regular2 ? r3n : 1u, regular2 ? nb2 : 1u, tid);
       else
         fp_load<THREADS>(br, regular2 ? R + rb2 : dummy, regular2 ? nb2 : 1u, tid);
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       }
       if ((a.extra & 1u) && !nb) {  // probe rows without a build partition still count in sum_probe_all
         if (SLAB) {
-          const Tup* base = S + (u64)p * 4 * a.s_cap;
+          const Tup* base = S + (u64)p * SLAB_KB * a.s_cap;
           for (u32 j = tid; j < np; j += THREADS) {
             const u32 pc = (j >= s1) + (j >= s2) + (j >= s3);
             const u32 pre = pc == 0 ? 0 : pc == 1 ? s1 : pc == 2 ? s2 : s3;
@@ -1731,8 +1732,17 @@ hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_ir
   return launch_fast_t<512, 11, false>(a, irregular, n_irregular, num_cus * 3 * 4, st);
 }
 
+// Slab layout: the pipelined kernels read P * SLAB_KB counts and piece p * SLAB_KB + j at row (p * SLAB_KB + j) * cap
+// of each side -- refuse operands that were allocated for anything less
+static bool slab_operands_ok(const ProbeArgs& a) {
+  const u64 pieces = (u64)a.P * SLAB_KB;
+  return a.r_cnt && a.s_cnt && a.r_cnt_n >= pieces && a.s_cnt_n >= pieces && a.r_rows >= pieces * a.r_cap &&
+         a.s_rows >= pieces * a.s_cap;
+}
+
 // unique-build-key write mode (ordered joins); slab or dense layout
 hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, hipStream_t st) {
+  if (slab && !slab_operands_ok(a)) return hipErrorInvalidValue;
   if (slab) return launch_fast_t<1024, BIG_LOG_NB, false, true, 1>(a, nullptr, nullptr, num_cus * 4, st);
   return launch_fast_t<1024, BIG_LOG_NB, false, false, 1>(a, nullptr, nullptr, num_cus * 4, st);
 }
@@ -1751,6 +1761,7 @@ static hipError_t launch_sorted_t(const ProbeArgs& a, u64* lookback, bool chaine
 hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, u64* lookback, bool chained, int key_low,
                                      int num_cus, hipStream_t st) {
   if (key_low < SW_LOGB) return hipErrorInvalidValue;
+  if (slab && !slab_operands_ok(a)) return hipErrorInvalidValue;
   int grid = num_cus;  // one workgroup per CU fits (LDS); partitions are handed out by ticket
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
@@ -1764,7 +1775,10 @@ hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, u64
 // each partition's first output slot in the unique-key write mode
 __global__ void slab_np_kernel(const u32* __restrict__ cnt, u32 P, u64* __restrict__ out) {
   u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < P) out[p] = (u64)cnt[4 * (u64)p] + cnt[4 * (u64)p + 1] + cnt[4 * (u64)p + 2] + cnt[4 * (u64)p + 3];
+  if (p < P) {
+    const u32* q = cnt + (u64)p * SLAB_KB;
+    out[p] = (u64)q[0] + q[1] + q[2] + q[3];
+  }
 }
 hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st) {
   hipLaunchKernelGGL(slab_np_kernel, dim3((P + 255) / 256), dim3(256), 0, st, cnt, P, out);
@@ -1774,11 +1788,13 @@ hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st) {
 // count mode with checksums / sum of all probe payloads (a.extra bit 0) and first-wins (bit 1)
 hipError_t launch_probe_count_ext(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool slab,
                                   int num_cus, hipStream_t st) {
+  if (slab && !slab_operands_ok(a)) return hipErrorInvalidValue;
   if (slab) return launch_fast_t<1024, BIG_LOG_NB, false, true, 2>(a, nullptr, nullptr, num_cus * 4, st);
   return launch_fast_t<1024, BIG_LOG_NB, false, false, 2>(a, irregular, n_irregular, num_cus * 4, st);
 }
 
 hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st) {
+  if (!slab_operands_ok(a)) return hipErrorInvalidValue;
   return launch_fast_t<1024, BIG_LOG_NB, false, true>(a, nullptr, nullptr, num_cus * 4, st);
 }
 
@@ -1786,6 +1802,9 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
                         hipStream_t st) {
   if (!a.item_list && (u64)grid > (u64)a.P * a.Q) grid = (int)((u64)a.P * a.Q);
   if (grid < 1) grid = 1;
+  // probe side in slabs (probe-heavy count joins): item w = p * Q + q is piece w -- count w, rows [w * cap, + count)
+  if (a.s_cnt && (a.s_cnt_n < (u64)a.P * a.Q || a.s_rows < (u64)a.P * a.Q * a.s_cap || (u64)a.P * a.Q * a.s_cap > 0xFFFFFFFFull))
+    return hipErrorInvalidValue;
 #define HMJ_DISPATCH(M)                                                          \
   if (first_wins)                                                                \
     return extra ? launch_probe_t<M, true, true>(a, grid, st)                    \

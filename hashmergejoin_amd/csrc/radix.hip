@@ -782,8 +782,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 __device__ u32 g_b_ablate;
 static bool g_b_addr_alt = false;  // launch the slab lookup that is NOT the default (HMJ_B_ADDR)
 #endif
-constexpr int SLAB_KB = 4;        // pass-B workers per bucket == pieces per final partition (the pipelined probe
-                                  // kernel reads exactly 4; the generic kernel takes any KB as its probe slices)
+// (SLAB_KB, hmj_dev.h: pass-B workers per bucket == pieces per final partition of the full slab path)
 constexpr int SLAB_MAXSEG = 512;  // A-slabs one pass-B worker gathers (WA / KB <= 512)
 
 template <int THREADS, int MAXD, bool HI, int ADDR>
@@ -1278,14 +1277,23 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fa
 }
 
 // workers [w_begin, w_end) of the pass (default: all): worker w reads input rows [w * g.rpw, (w + 1) * g.rpw)
-hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a,
-                         u32* cnt_a, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {
+hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows,
+                         u32* cnt_a, u64 cnt_a_n, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {
+  // worker w writes slab [d][w][CA] and cnt[d * WA + w] for every digit d < 2^bits, and reads rows [w * rpw, ...)
+  if (bits < 1 || bits > 8 || g.WA == 0 || g.CA == 0 || (u64)g.WA * g.rpw < n) return hipErrorInvalidValue;
+  if (slab_a_rows < ((u64)g.WA << bits) * g.CA || cnt_a_n < ((u64)g.WA << bits)) return hipErrorInvalidValue;
   return shift >= 32 ? launch_slab_a_t<true>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st, w_begin, w_end)
                      : launch_slab_a_t<false>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st, w_begin, w_end);
 }
 
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
-                         const SlabGeom& g, void* slab_b, u32* cnt_b, u64* accum, hipStream_t st) {
+                         const SlabGeom& g, void* slab_b, u64 slab_b_rows, u32* cnt_b, u64 cnt_b_n, u64* accum, hipStream_t st) {
+  // worker (dA, k) writes piece (d << bits_a | dA) * KB + k of every digit d < 2^bits: P * KB pieces of CB rows, one
+  // count each; it gathers the A-slabs [k * WA / KB, (k + 1) * WA / KB) -- at most SLAB_MAXSEG of them
+  if (bits < 1 || bits > 8 || bits_a < 1 || bits_a > 8 || g.KB == 0 || g.WA < g.KB || (g.WA + g.KB - 1) / g.KB > (u32)SLAB_MAXSEG)
+    return hipErrorInvalidValue;
+  const u64 pieces = ((u64)g.KB << (bits_a + bits));
+  if (slab_b_rows < pieces * g.CB || cnt_b_n < pieces) return hipErrorInvalidValue;
   return shift >= 32 ? launch_slab_b_t<true>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
                                              cnt_b, accum, st, g.KB)
                      : launch_slab_b_t<false>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,

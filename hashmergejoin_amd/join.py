@@ -97,6 +97,14 @@ class Executor:
         self._check(self.L.hmj_last_timing(self.h, C.byref(t)))
         return t.as_dict()
 
+    def placement_info(self):
+        """[{name, bytes, fill_TBps, candidates, ms_search}] for the big partition buffers this executor probed
+        (hmj_placement_info; empty with HMJ_PLACE=0)."""
+        arr = (_lib.PlaceInfo * 16)()
+        n = self.L.hmj_placement_info(self.h, arr, 16)
+        return [{"name": arr[i].name.decode(), "bytes": int(arr[i].bytes), "fill_TBps": round(float(arr[i].fill_TBps), 3),
+                 "candidates": int(arr[i].candidates), "ms_search": round(float(arr[i].ms_search), 2)} for i in range(n)]
+
     # ---- joins -------------------------------------------------------------------------------
     def join_device(self, build, probe, flags=0):
         """build/probe: device tensors [n,2] {key,val}.  Returns JoinResult (columns are device

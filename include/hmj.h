@@ -149,6 +149,19 @@ int hmj_autotune_radix_bits(hmj_ctx* ctx, uint64_t n_build, uint64_t n_probe, in
 int hmj_set_key_prefix_bits(hmj_ctx* ctx, int bits);
 /* The automatic plan for a build side of n_build rows: total bits and per-pass bits (LSD order).*/
 int hmj_plan(uint64_t n_build, int* total_bits, int* n_passes, int pass_bits[4]);
+/* Placement of the big partition buffers (how fast a buffer can be written is a property of the
+ * physical memory behind it).  One entry per probed buffer of this ctx: the fill rate of the allocation that was kept,
+ * the number of candidate allocations tried and what the search cost.  Returns the number of entries (<= max_entries),
+ * 0 when probing is off (HMJ_PLACE=0) or nothing big was allocated yet.  Diagnostic only; nothing in the reference
+ * corresponds to it (its buffers are std::vector storage, hashjoin.h:62-63).                                     */
+typedef struct {
+  char name[16];      /* slab_a, slab_b_build, slab_b_probe, rbuf0/1, sbuf0/1                                   */
+  uint64_t bytes;
+  float fill_TBps;    /* second of two sequential fills                                                          */
+  int candidates;     /* allocations tried (1 = the first one was kept)                                          */
+  float ms_search;    /* host time of the probe(s), part of the join that allocated the buffer                   */
+} hmj_place_info;
+int hmj_placement_info(hmj_ctx* ctx, hmj_place_info* out, int max_entries);
 int hmj_set_profiling(hmj_ctx* ctx, int enabled);
 int hmj_last_timing(hmj_ctx* ctx, hmj_timing* out);
 const char* hmj_strerror(int code);

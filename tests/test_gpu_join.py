@@ -590,7 +590,16 @@ def test_skewed_build_side_config5(ex, H, oracle, log2b, log2p, log2dom):
     b = ex.join_device(S, R, 0)
     assert int(a.n_matches) == int(b.n_matches) > 0
     assert (int(a.sum_r), int(a.sum_s)) == (int(b.sum_s), int(b.sum_r))
-    fw = ex.join_device(R, S, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE) if log2b <= 20 else None
+    fw = ex.join_device(R, S, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE)
+    # independent of the join kernels AND of the oracle, at every size incl. the full 2^24 x 2^30: per-rank counts and
+    # sums recomputed with plain torch ops in the generators' rank domain (tools/closed_forms.py): cross product and
+    # first-wins (partitioned_hash.h:166-170) reductions, and the sum over all probe payloads (hashjoin_bench.cc:92-96)
+    from tools.closed_forms import config5_checks
+
+    want = config5_checks(torch, nb, npb, dom, thr_d)
+    assert {k: int(getattr(a, k)) for k in ("n_matches", "sum_r", "sum_s")} == want["cross"]
+    assert {k: int(getattr(fw, k)) for k in ("n_matches", "sum_r", "sum_s")} == want["first_wins"]
+    assert int(fw.sum_probe_all) == want["sum_probe_all"]
     if log2b <= 20:
         Rn, Sn = to_np(R), to_np(S)
         assert np.array_equal(Rn, oracle.gen_from_cdf(nb, thr)) and np.array_equal(Sn, oracle.gen_uniform_domain(npb, dom))
@@ -647,6 +656,44 @@ def test_probe_heavy_count_join_partitions_the_probe_side_in_slabs(ex, H, oracle
             assert bool(t["path"] & H.HMJ_PATH_SLAB_PROBE) == (not skewed_probe), (skewed_probe, fl, t)
         del R, S
     ex.release_result()
+
+
+@pytest.mark.parametrize("kb,bits,npb", [(3, 10, 6000011), (5, 10, 6000011), (12, 10, 6291456), (7, 11, 12000017)])
+def test_probe_side_slab_pieces_bounds_regression(H, oracle, kb, bits, npb):
+    # Regression for the piece-indexed arrays the slab layouts share (cnt_b[P * KB], slab piece offsets, the generic
+    # kernel's piece reads) -- VERDICT r2 item 2: a GPU memory fault during the reverted 8-piece experiment was never
+    # root-caused; the most probable cause was a count array still sized for 4 pieces.  Now every size derives from
+    # the geometry's KB, the launchers refuse operands smaller than what the grid will touch, and this test drives
+    # piece counts the planner never picks: odd KB, pass-B workers with ragged A-slab ranges (WA not a multiple of
+    # KB), P * KB far from any block multiple, ragged row counts -- against the CPU oracle.
+    import torch
+
+    assert torch.cuda.is_available()
+    os.environ["HMJ_SLAB_MIN_LOG2"] = "22"
+    os.environ["HMJ_SLAB_PROBE_KB"] = str(kb)
+    try:
+        ex = H.Executor(0)
+    finally:
+        del os.environ["HMJ_SLAB_MIN_LOG2"], os.environ["HMJ_SLAB_PROBE_KB"]
+    try:
+        nb = (1 << 20) + 333  # probe-heavy (>= 4x), ragged, probe side >= 2^22 rows, probe partitions beyond the pipelines
+        ex.set_radix_bits(bits)
+        thr = _zipf_thresholds(1 << 20)
+        R = ex.gen_from_cdf(nb, torch.from_numpy(thr.view(np.int64).copy()).cuda())  # duplicate build keys -> generic kernel
+        S = ex.gen_uniform_domain(npb, 1 << 20)
+        Rn, Sn = to_np(R), to_np(S)
+        ck, _ = oracle.equijoin(Rn, Sn, cap=0)
+        ckf, _ = oracle.equijoin(Rn, Sn, first_wins=True, cap=0)
+        for fl, want in ((0, ck), (H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE, ckf), (H.HMJ_CHECKSUM, ck)):
+            r = ex.join_device(R, S, fl)
+            t = ex.last_timing()
+            assert t["path"] & H.HMJ_PATH_SLAB_PROBE, (kb, bits, fl, t)
+            assert t["n_probe_items"] == (1 << t["radix_bits"]) * kb
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (want["n_matches"], want["sum_r"], want["sum_s"]), (kb, bits, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck
+    finally:
+        ex.close()
 
 
 @pytest.mark.parametrize("n", [0, 1, 5, 4095, 12345, 1 << 16, (1 << 20) + 3])
