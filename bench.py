@@ -7,7 +7,9 @@ resident in HBM: radix-partition R, radix-partition S, bucket-local build + prob
 
 N=1 workload: BASELINE.json configs[2]: |R|=|S|=2^28 u64 key / 8 B payload, 100 % match.
 N>1: weak scaling, 2^28 rows per relation per GPU (N=8 -> |R|=|S|=2^31, configs[3]); each step is one
-hmj_exchange_join_u64_device: owner split + RCCL grouped send/recv rounds of both relations + local join.
+hmj_exchange_join_u64_device: the first radix pass on every rank, its digit ranges as owners, RCCL grouped send/recv
+rounds of digit ranges, one join per arrived round.  `python bench.py --gpus N` starts its own N ranks when no
+launcher did (WORLD_SIZE unset).
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernels, HIP-event timed inside the
 timed region), "roofline_probe" (the build+probe kernel), "cpu_baseline" (the compiled reference timed on
@@ -311,11 +313,13 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     n_matches = int(res.n_matches)  # distributed: the reduction over all ranks (hmj_exchange_join's global_out)
+    probe_ms_slowest = agg.get("ms_probe_count", 0.0) / max(1, a.steps)
     if world > 1:
         rdev = dev if backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
+        # slowest rank: whole-step wall time, and its build+probe kernel time per step (the probe-phase rate below)
+        t = torch.tensor([dt, probe_ms_slowest], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, probe_ms_slowest = float(t[0].item()), float(t[1].item())
     assert n_matches == n_total, "every probe row must match exactly once (%d != %d)" % (n_matches, n_total)
 
     if rank == 0:
@@ -374,6 +378,16 @@ def main():
             sc_kernel = "radix_scatter_wc_kernel<512,256>"
             sc_desc = "write-combining stable scatter with histogram offsets; mean over the launches of a join"
             pr_kernel = "probe_count_fast_kernel (dense layout) + probe_kernel<0> for set-aside partitions"
+        if distributed and last_xi["owner_mode"] == 3:
+            # the digit path: one first pass per relation on the shard (radix_scatter_wc_kernel, its digit = the owner)
+            # + the remaining passes of every round's join; launch counts differ per pass, so no A / B split here
+            sc_kernel = "radix_scatter_wc_kernel<512,256> (first pass = owner) + " + sc_kernel + " (per-round joins)"
+            sc_desc = "mean over all scatter launches of a step (32 B per row and launch)"
+            pa = pb = 0.0
+            digit_bits = last_xi["digit_bits"]
+            plan_txt = "%d-bit first pass (owner) + %d-bit radix in %d LSD passes per round" % (digit_bits, last_tm["radix_bits"], last_tm["radix_passes"])
+        else:
+            plan_txt = "%d-bit radix in %d LSD passes" % (last_tm["radix_bits"], last_tm["radix_passes"])
         line = {
             "metric": "probe-side tuples/s + achieved HBM GB/s, |R|=|S|=2^28 u64 keys",
             "value": n_total * K / dt,
@@ -381,8 +395,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "|R|=|S|=2^%d x %d GPU: u64 key / 8 B payload, 100%% match, %d-bit radix in %d LSD passes, "
-                                   "LDS build+probe, %s" % (a.log2n, world, last_tm["radix_bits"], last_tm["radix_passes"],
+            "config": {"workload": "|R|=|S|=2^%d x %d GPU: u64 key / 8 B payload, 100%% match, %s, "
+                                   "LDS build+probe, %s" % (a.log2n, world, plan_txt,
                                                             "materialised columns" if a.materialize else "count+sum (hashjoin_bench.cc:131-133)"),
                        "rows_per_relation_per_gpu": n, "rows_per_relation_total": n_total,
                        "parallelism": "radix-sharded x%d" % world},
@@ -400,11 +414,26 @@ def main():
                           "first_join_ms": None if first_ms is None else round(first_ms, 2)},
         }
         if distributed:
+            transport = "rccl" if (backend == "nccl" or force_dist) else "callbacks over " + backend
+            owner = {0: "none (one rank: plain local join)", 1: "hash of the key (fallback: separate owner split)",
+                     2: "key ranges between sample quantiles", 3: "ranges of the first radix pass's digit"}[last_xi["owner_mode"]]
             line["exchange"] = dict({k[3:]: round(v / K, 3) for k, v in xagg.items()}, unit="ms per step on rank 0",
-                                    rounds_build=last_xi["rounds_build"], rounds_probe=last_xi["rounds_probe"],
-                                    owner="hash of the key" if last_xi["owner_mode"] == 1 else "key ranges",
-                                    transport="rccl" if (backend == "nccl" or force_dist) else "callbacks over " + backend,
-                                    recv_rows_rank0=[last_xi["recv_build"], last_xi["recv_probe"]])
+                                    n_ranks=last_xi["n_ranks"], rccl_ranks=last_xi["n_ranks"] if transport == "rccl" else 0,
+                                    transport=transport, owner=owner, digit_bits=last_xi["digit_bits"],
+                                    digit_low=last_xi["digit_low"], rounds_build=last_xi["rounds_build"],
+                                    rounds_probe=last_xi["rounds_probe"], joins_per_step=last_xi["n_subjoins"],
+                                    sample_max_share=round(last_xi["sample_max_share"], 3),
+                                    recv_rows_rank0=[last_xi["recv_build"], last_xi["recv_probe"]],
+                                    what={"split": "first radix pass (or owner split) of both shards + count read-back, host clock",
+                                          "exchange_build / exchange_probe": "rounds on the communication stream (HIP events)",
+                                          "kernels": "this rank's own kernels: pre-pass + per-round joins (HIP events)",
+                                          "exposed": "total - kernels: what the exchange and its synchronisation add to a step"})
+            # the probe phase alone, aggregated over the ranks: all probe rows / the slowest rank's build+probe kernel time
+            pb = last_tm["bytes_probe_count"]
+            if probe_ms_slowest > 0:
+                line["probe_phase"] = {"probe_tuples_per_s_all_ranks": round(n_total / (probe_ms_slowest * 1e-3)),
+                                       "slowest_rank_ms_per_step": round(probe_ms_slowest, 4),
+                                       "per_gpu": roof(pb, probe_ms_slowest)}
         if world == 1 and not distributed:
             del R, S
             torch.cuda.empty_cache()

@@ -67,10 +67,21 @@ class ExchangeInfo(C.Structure):
     _fields_ = [("n_ranks", C.c_int), ("owner_mode", C.c_int), ("rounds_build", C.c_uint32), ("rounds_probe", C.c_uint32),
                 ("recv_build", C.c_uint64), ("recv_probe", C.c_uint64), ("ms_split", C.c_float),
                 ("ms_exchange_build", C.c_float), ("ms_exchange_probe", C.c_float), ("ms_local", C.c_float),
-                ("ms_total", C.c_float)]
+                ("ms_total", C.c_float), ("digit_bits", C.c_int32), ("digit_low", C.c_int32), ("n_subjoins", C.c_uint32),
+                ("fallback", C.c_uint32), ("sample_max_share", C.c_float), ("ms_kernels", C.c_float),
+                ("ms_exposed", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+HMJ_MAX_RANKS, HMJ_MAX_ROUNDS = 16, 16
+
+
+class DigitPlan(C.Structure):
+    _fields_ = [("usable", C.c_int32), ("digit_bits", C.c_int32), ("digit_low", C.c_int32), ("n_rounds", C.c_uint32),
+                ("owner_first", C.c_uint32 * (HMJ_MAX_RANKS + 1)),
+                ("round_first", (C.c_uint32 * (HMJ_MAX_ROUNDS + 1)) * HMJ_MAX_RANKS), ("max_share", C.c_float)]
 
 
 # hmj_transport: the two collectives a host may supply instead of RCCL (include/hmj.h)
@@ -160,6 +171,12 @@ def load_library():
     L.hmj_owner_split_u64_device.argtypes = [vp, vp, u, i, _U64P, vp, vp]
     L.hmj_last_exchange_info.restype = i
     L.hmj_last_exchange_info.argtypes = [vp, C.POINTER(ExchangeInfo)]
+    L.hmj_comm_set_self_exchange.restype = i
+    L.hmj_comm_set_self_exchange.argtypes = [vp, i]
+    L.hmj_exchange_digit_plan.restype = i
+    L.hmj_exchange_digit_plan.argtypes = [i, _U64P, u, C.c_uint32, C.POINTER(DigitPlan)]
+    L.hmj_exchange_digit_layout.restype = i
+    L.hmj_exchange_digit_layout.argtypes = [i, i, C.POINTER(DigitPlan), _U64P, _U64P, _U64P, _U64P, _U64P, _U64P]
     L.hmj_exchange_rounds.restype = C.c_uint32
     L.hmj_exchange_rounds.argtypes = [i, _U64P, u]
     L.hmj_exchange_layout.restype = i

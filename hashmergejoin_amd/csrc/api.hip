@@ -22,7 +22,7 @@ using namespace hmj_host;
 
 namespace hmj_host {
 
-constexpr int kMaxEvents = 256;
+constexpr int kMaxEvents = 1024;  // two per span; a multi-round exchange step keeps the spans of all its sub-joins
 
 int fail(hmj_ctx* c, int code, const char* what, hipError_t e) {
   if (c) {
@@ -335,7 +335,7 @@ static inline bool slab_sizes_ok(const hmj_ctx* c, u64 nb, u64 np) {
 
 // one stable LSD pass src -> dst
 int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bits, int rel,
-               u64* offsets_out, int pass_index = 0) {
+               u64* offsets_out, int pass_index) {
   u32 nblk, rpb;
   const int variant = c->scatter_variant;
   const int tile = hmj::radix_tile_rows(bits, variant);
@@ -1504,6 +1504,7 @@ const char* hmj_strerror(int code) {
     case HMJ_E_HIP: return "HIP runtime error";
     case HMJ_E_UNSUPPORTED: return "unsupported flag combination for this input";
     case HMJ_E_RCCL: return "RCCL / transport error";
+    case HMJ_E_PEER: return "another rank of the collective failed";
     default: return "unknown error";
   }
 }

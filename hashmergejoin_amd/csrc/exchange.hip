@@ -5,7 +5,10 @@
 // parallelism from the ctor (hashjoin.h:56-68 -> radix_hash.h:375-405, threads of one address space); this is
 // the same fork-join across address spaces.
 //
-//   owner split (radix.hip, owner_digit)  ->  counts all-gather  ->  rounds of grouped send/recv  ->  local join
+//   first radix pass on every rank (digit-major, stable)  ->  counts all-gather  ->  rounds of grouped send/recv, a round =
+//   a range of digits  ->  every arrived round joined at once (remaining radix passes, build, probe)
+// Rank g owns a contiguous range of the first pass's digits (hmj_exchange_digit_plan): the radix fan-out is the owner,
+// nothing is partitioned twice.  Fallbacks: hash owner / key-range owner with a separate owner split (owner_digit).
 //
 // Transport: RCCL (ncclSend / ncclRecv per peer inside ncclGroupStart / ncclGroupEnd, on the communicator's own
 // HIP stream; librccl is loaded with dlopen, so the library has no link-time dependency on it) or callbacks
@@ -18,6 +21,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 
 #include "hmj_ctx.h"
 
@@ -42,11 +46,8 @@ struct RcclApi {
   std::string error;
 };
 
-RcclApi* rccl_api() {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.dl ? &api : nullptr;
-  tried = true;
+RcclApi g_rccl;
+bool rccl_load(RcclApi& api) {
   // a process that already holds RCCL (PyTorch bundles one under the same SONAME) gets that copy back
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
@@ -54,15 +55,16 @@ RcclApi* rccl_api() {
     if (api.dl) break;
   }
   if (!api.dl) {
-    api.error = dlerror() ? dlerror() : "librccl not found";
-    return nullptr;
+    const char* e = dlerror();
+    api.error = e ? e : "librccl not found";
+    return false;
   }
 #define HMJ_SYM(field, name)                                          \
   api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.dl, name)); \
   if (!api.field) {                                                   \
     api.error = std::string("librccl lacks ") + name;                \
     api.dl = nullptr;                                                 \
-    return nullptr;                                                   \
+    return false;                                                     \
   }
   HMJ_SYM(GetUniqueId, "ncclGetUniqueId")
   HMJ_SYM(CommInitRank, "ncclCommInitRank")
@@ -74,7 +76,14 @@ RcclApi* rccl_api() {
   HMJ_SYM(AllGather, "ncclAllGather")
   HMJ_SYM(GetErrorString, "ncclGetErrorString")
 #undef HMJ_SYM
-  return &api;
+  return true;
+}
+// loaded once per process, whichever thread / context asks first (contexts on several threads may initialise
+// their communicators at the same time)
+RcclApi* rccl_api() {
+  static std::once_flag once;
+  std::call_once(once, [] { (void)rccl_load(g_rccl); });
+  return g_rccl.dl ? &g_rccl : nullptr;
 }
 
 constexpr int kSampleKeys = 2048;  // per relation and rank, for the ordered mode's splitters
@@ -87,10 +96,16 @@ struct hmj_comm {
   hmj_transport cb;           // callback transport
   bool has_cb = false;
   hipStream_t stream = nullptr;  // communication stream
-  hipEvent_t ev_split = nullptr, ev_build = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
+  hipEvent_t ev_split = nullptr, ev_split_s = nullptr, ev_build = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr, ev_t3 = nullptr;
   std::vector<hipEvent_t> round_ev;
   DevBuf parted_r, parted_s, recv_r, recv_s, offs, gather_dev, sample_dev;
-  HostBuf gather_host;
+  HostBuf gather_host, offs_host;
+  bool self_exchange = false;  // one rank: run the whole exchange path (tests) instead of the plain local join
+  // Sizes every rank has already allocated for in an earlier successful step (per rank: shard rows and owned rows of
+  // both relations).  All ranks hold the same values, so "does any rank have to grow a buffer in this step" is
+  // decided identically everywhere -- only then is the extra status all-gather needed that keeps an out-of-memory
+  // rank from leaving its peers blocked.
+  std::vector<u64> peak_rows;  // [n_ranks][4]
   u64 max_msg_bytes = 1ull << 30;       // RCCL 2.26 truncates a single message of 2 GiB or more
   u64 target_round_bytes = 128ull << 20;  // probe side: several rounds, so the local pass A starts on arrived rows
   hmj_exchange_info info;
@@ -120,7 +135,8 @@ void comm_free(hmj_comm* m) {  // everything a (possibly half-built) communicato
   DevBuf* devs[] = {&m->parted_r, &m->parted_s, &m->recv_r, &m->recv_s, &m->offs, &m->gather_dev, &m->sample_dev};
   for (DevBuf* b : devs) free_dev(*b);
   free_host(m->gather_host);
-  hipEvent_t evs[] = {m->ev_split, m->ev_build, m->ev_t0, m->ev_t1, m->ev_t2};
+  free_host(m->offs_host);
+  hipEvent_t evs[] = {m->ev_split, m->ev_split_s, m->ev_build, m->ev_t0, m->ev_t1, m->ev_t2, m->ev_t3};
   for (hipEvent_t e : evs)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : m->round_ev) (void)hipEventDestroy(e);
@@ -134,9 +150,9 @@ int comm_ensure(hmj_ctx* c) {
   std::memset(&m->cb, 0, sizeof(m->cb));
   std::memset(&m->info, 0, sizeof(m->info));
   bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
-  hipEvent_t* evs[] = {&m->ev_split, &m->ev_build};
+  hipEvent_t* evs[] = {&m->ev_split, &m->ev_split_s, &m->ev_build};
   for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-  hipEvent_t* tevs[] = {&m->ev_t0, &m->ev_t1, &m->ev_t2};
+  hipEvent_t* tevs[] = {&m->ev_t0, &m->ev_t1, &m->ev_t2, &m->ev_t3};
   for (hipEvent_t* e : tevs) ok = ok && hipEventCreate(e) == hipSuccess;
   if (!ok) {
     comm_free(m);
@@ -188,11 +204,17 @@ int transport_round(hmj_ctx* c, int round, const void* const* sp, const u64* sb,
   for (int g = 0; g < G; g++)
     if ((g != me || self_rccl) && (sb[g] || rb[g])) any = true;
   if (!any) return HMJ_OK;
+  // No single ncclSend / ncclRecv above max_msg_bytes (RCCL 2.26 truncates a message of 2 GiB or more): a larger
+  // message goes as consecutive pieces; both sides cut the same byte count the same way, and pieces between one
+  // pair of ranks match in the order they are posted.
+  const u64 lim = m->max_msg_bytes;
   RCCL_TRY(a->GroupStart());
   for (int g = 0; g < G; g++) {
     if (g == me && !self_rccl) continue;
-    if (sb[g]) RCCL_TRY(a->Send(sp[g], (size_t)sb[g], ncclUint8, g, m->nccl, m->stream));
-    if (rb[g]) RCCL_TRY(a->Recv(rp[g], (size_t)rb[g], ncclUint8, g, m->nccl, m->stream));
+    for (u64 off = 0; off < sb[g]; off += lim)
+      RCCL_TRY(a->Send(static_cast<const char*>(sp[g]) + off, (size_t)std::min<u64>(lim, sb[g] - off), ncclUint8, g, m->nccl, m->stream));
+    for (u64 off = 0; off < rb[g]; off += lim)
+      RCCL_TRY(a->Recv(static_cast<char*>(rp[g]) + off, (size_t)std::min<u64>(lim, rb[g] - off), ncclUint8, g, m->nccl, m->stream));
   }
   RCCL_TRY(a->GroupEnd());
   return HMJ_OK;
@@ -279,6 +301,105 @@ extern "C" int hmj_exchange_layout(int n_ranks, int rank, const uint64_t* counts
       if (round_end) round_end[r] = r0;
     }
   }
+  return HMJ_OK;
+}
+
+
+// ---- digit-range owners (the radix fan-out as the owner): host arithmetic, exported ---------------------------
+extern "C" int hmj_exchange_digit_plan(int n_ranks, const uint64_t* keys, uint64_t n, uint32_t n_rounds, hmj_digit_plan* out) {
+  if (n_ranks < 1 || n_ranks > HMJ_MAX_RANKS || !out || (n && !keys) || n_rounds < 1 || n_rounds > HMJ_MAX_ROUNDS) return HMJ_E_ARG;
+  std::memset(out, 0, sizeof(*out));
+  const int G = n_ranks;
+  out->n_rounds = n_rounds;
+  // the bits all sampled keys share are no use as a digit (dense integer keys: SURVEY.md D5); the digit is the
+  // top <= 8 bits right under them -- the reference's top-bits routing (radix_hash.h:369) under a prefix
+  uint64_t diff = 0;
+  for (uint64_t i = 1; i < n; i++) diff |= keys[i] ^ keys[0];
+  const int prefix = diff ? __builtin_clzll(diff) : 64;
+  int ba = 64 - prefix < 8 ? 64 - prefix : 8;
+  if (n == 0) ba = 8;  // nothing sampled (empty relations): any window does
+  const int low = n == 0 ? 56 : 64 - prefix - ba;
+  out->digit_bits = ba;
+  out->digit_low = low;
+  const uint32_t D = 1u << (ba > 0 ? ba : 0);
+  if (ba < 1 || D < 2u * (uint32_t)G) {  // fewer than two digits per rank: no balance to be had
+    out->digit_bits = ba < 0 ? 0 : ba;
+    for (int g = 0; g <= G; g++) out->owner_first[g] = (uint32_t)((uint64_t)D * g / G);
+    for (int g = 0; g < G; g++)
+      for (uint32_t r = 0; r <= n_rounds; r++) out->round_first[g][r] = r == 0 ? out->owner_first[g] : out->owner_first[g + 1];
+    out->usable = 0;
+    return HMJ_OK;
+  }
+  std::vector<uint64_t> cum(D + 1, 0);
+  for (uint64_t i = 0; i < n; i++) cum[((keys[i] >> low) & (D - 1)) + 1]++;
+  for (uint32_t d = 0; d < D; d++) cum[d + 1] += cum[d];
+  const bool tiny = n < 64ull * G;  // too few samples to say anything: equal digit ranges
+  // boundary j of `parts` over digits [a, b): where the cumulative sample count is closest to its share
+  auto cut = [&](uint32_t a, uint32_t b, uint32_t parts, uint32_t j, uint32_t not_before) -> uint32_t {
+    if (j == 0) return a;
+    if (j >= parts) return b;
+    if (tiny || cum[b] == cum[a]) {
+      uint32_t d = a + (uint32_t)((uint64_t)(b - a) * j / parts);
+      return d < not_before ? not_before : d;
+    }
+    const unsigned __int128 target = (unsigned __int128)(cum[b] - cum[a]) * j;  // compare (cum[d] - cum[a]) * parts with it
+    uint32_t best = not_before;
+    unsigned __int128 best_err = ~(unsigned __int128)0;
+    for (uint32_t d = not_before; d <= b; d++) {
+      const unsigned __int128 v = (unsigned __int128)(cum[d] - cum[a]) * parts;
+      const unsigned __int128 err = v > target ? v - target : target - v;
+      if (err < best_err) {
+        best_err = err;
+        best = d;
+      }
+    }
+    return best;
+  };
+  out->owner_first[0] = 0;
+  for (int g = 1; g <= G; g++) out->owner_first[g] = cut(0, D, (uint32_t)G, (uint32_t)g, out->owner_first[g - 1]);
+  uint64_t biggest = 0;
+  for (int g = 0; g < G; g++) biggest = std::max<uint64_t>(biggest, cum[out->owner_first[g + 1]] - cum[out->owner_first[g]]);
+  out->max_share = n ? (float)((double)biggest * G / (double)n) : 1.0f;
+  out->usable = (tiny || out->max_share <= 1.3f) ? 1 : 0;
+  for (int g = 0; g < G; g++) {
+    const uint32_t a = out->owner_first[g], b = out->owner_first[g + 1];
+    out->round_first[g][0] = a;
+    for (uint32_t r = 1; r <= n_rounds; r++) out->round_first[g][r] = cut(a, b, n_rounds, r, out->round_first[g][r - 1]);
+  }
+  return HMJ_OK;
+}
+
+extern "C" int hmj_exchange_digit_layout(int n_ranks, int rank, const hmj_digit_plan* plan, const uint64_t* counts,
+                                         uint64_t* send_off, uint64_t* send_rows, uint64_t* recv_off, uint64_t* recv_rows,
+                                         uint64_t* round_off) {
+  if (n_ranks < 1 || n_ranks > HMJ_MAX_RANKS || rank < 0 || rank >= n_ranks || !plan || !counts || !send_off || !send_rows ||
+      !recv_off || !recv_rows || !round_off || plan->n_rounds < 1 || plan->n_rounds > HMJ_MAX_ROUNDS || plan->digit_bits < 0 ||
+      plan->digit_bits > 8)
+    return HMJ_E_ARG;
+  const int G = n_ranks;
+  const uint32_t D = 1u << plan->digit_bits, R = plan->n_rounds;
+  std::vector<uint64_t> offs(D + 1, 0);  // this rank's digit-major buffer
+  for (uint32_t d = 0; d < D; d++) offs[d + 1] = offs[d] + counts[(size_t)rank * D + d];
+  for (uint32_t r = 0; r < R; r++)
+    for (int g = 0; g < G; g++) {
+      const uint32_t d0 = plan->round_first[g][r], d1 = plan->round_first[g][r + 1];
+      if (d0 > d1 || d1 > D) return HMJ_E_ARG;
+      send_off[(size_t)r * G + g] = offs[d0];
+      send_rows[(size_t)r * G + g] = offs[d1] - offs[d0];
+    }
+  uint64_t pos = 0;
+  for (uint32_t r = 0; r < R; r++) {
+    round_off[r] = pos;
+    const uint32_t d0 = plan->round_first[rank][r], d1 = plan->round_first[rank][r + 1];
+    for (int s = 0; s < G; s++) {
+      uint64_t rows = 0;
+      for (uint32_t d = d0; d < d1; d++) rows += counts[(size_t)s * D + d];
+      recv_off[(size_t)r * G + s] = pos;
+      recv_rows[(size_t)r * G + s] = rows;
+      pos += rows;
+    }
+  }
+  round_off[R] = pos;
   return HMJ_OK;
 }
 
@@ -392,6 +513,12 @@ int hmj_comm_set_message_bytes(hmj_ctx* c, uint64_t max_message_bytes, uint64_t 
   return HMJ_OK;
 }
 
+int hmj_comm_set_self_exchange(hmj_ctx* c, int on) {
+  if (!c || !c->comm) return c ? fail(c, HMJ_E_ARG, "no communicator") : HMJ_E_ARG;
+  c->comm->self_exchange = on != 0;
+  return HMJ_OK;
+}
+
 int hmj_owner_split_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, int n_ranks, const uint64_t* splitters,
                                void* out_aos_dev, uint64_t* offsets_dev) {
   if (!c) return HMJ_E_ARG;
@@ -416,113 +543,446 @@ int hmj_last_exchange_info(hmj_ctx* c, hmj_exchange_info* out) {
   return HMJ_OK;
 }
 
-int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_dev, uint64_t n_build, const void* probe_shard_dev,
-                                 uint64_t n_probe, uint32_t flags, hmj_result* local_out, hmj_result* global_out) {
-  if (!c) return HMJ_E_ARG;
-  if (!local_out) return fail(c, HMJ_E_ARG, "local_out is NULL");
-  if (!c->comm) return fail(c, HMJ_E_ARG, "no communicator: call hmj_comm_init_rank or hmj_comm_set_transport first");
-  if (n_build > 0xFFFFFFFFull || n_probe > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "more than 2^32-1 rows in one shard");
-  if ((n_build && !build_shard_dev) || (n_probe && !probe_shard_dev)) return fail(c, HMJ_E_ARG, "shard pointer is NULL");
-  HIP_TRY(hipSetDevice(c->device));
+
+}  // extern "C"
+
+// ---- the distributed join ----------------------------------------------------------------------------------
+namespace {
+
+// Message of the first all-gather of a step: this rank's status, sample sizes, shard sizes and key sample.
+constexpr int kSampleWords = 2 * kSampleKeys + 5;  // [0] status [1] kr [2] ks [3] n_build [4] n_probe [5..] keys
+
+struct StepSample {
+  std::vector<u64> keys;    // pooled over all ranks and both relations
+  std::vector<u64> nb, np;  // shard rows of every rank
+};
+
+// A collective must be left by all ranks together.  `mine`: this rank's pending error (HMJ_OK if none); `flags[g]`:
+// what rank g reported.  Returns HMJ_OK when nobody failed, this rank's own code when it failed, HMJ_E_PEER otherwise.
+int settle(hmj_ctx* c, int mine, const std::vector<u64>& flags) {
+  int bad = -1;
+  for (size_t g = 0; g < flags.size(); g++)
+    if (flags[g] && bad < 0) bad = (int)g;
+  if (bad < 0 && mine == HMJ_OK) return HMJ_OK;
+  if (mine != HMJ_OK) return mine;  // (its message was set where it happened)
+  char msg[96];
+  std::snprintf(msg, sizeof(msg), "rank %d failed in this collective call (status %lld)", bad, (long long)(int64_t)flags[bad]);
+  return fail(c, HMJ_E_PEER, msg);
+}
+
+// One word per rank: did anybody fail since the last collective?  (Only called when every rank calls it.)
+int status_round(hmj_ctx* c, int mine) {
+  hmj_comm* m = c->comm;
+  const u64 w = mine == HMJ_OK ? 0ull : (u64)(int64_t)mine;
+  std::vector<u64> all((size_t)m->n_ranks, 0);
+  int rc = transport_allgather(c, &w, all.data(), 1);
+  if (rc != HMJ_OK) return rc;
+  return settle(c, mine, all);
+}
+
+// every rank's evenly spaced key sample of both shards + its shard sizes: one all-gather
+int gather_samples(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np, int* err, StepSample* out) {
+  hmj_comm* m = c->comm;
+  const int G = m->n_ranks, K = kSampleKeys, W = kSampleWords;
+  std::vector<u64> mine((size_t)W, 0), all((size_t)W * G, 0);
+  const u32 kr = (u32)std::min<u64>(K, nb), ks = (u32)std::min<u64>(K, np);
+  if (*err == HMJ_OK) {
+    int rc = ensure_dev(c, m->sample_dev, (size_t)2 * K * 8);
+    if (rc == HMJ_OK) {
+      u64* sd = static_cast<u64*>(m->sample_dev.p);
+      if (kr) hipLaunchKernelGGL(sample_keys_kernel, dim3((kr + 255) / 256), dim3(256), 0, c->stream, static_cast<const hmj::Tup*>(R), nb, kr, sd);
+      if (ks) hipLaunchKernelGGL(sample_keys_kernel, dim3((ks + 255) / 256), dim3(256), 0, c->stream, static_cast<const hmj::Tup*>(S), np, ks, sd + K);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(mine.data() + 5, sd, (size_t)2 * K * 8, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) rc = fail(c, HMJ_E_HIP, "key sample", e);
+    }
+    if (rc != HMJ_OK) *err = rc;
+  }
+  mine[0] = *err == HMJ_OK ? 0ull : (u64)(int64_t)*err;
+  mine[1] = kr;
+  mine[2] = ks;
+  mine[3] = nb;
+  mine[4] = np;
+  int rc = transport_allgather(c, mine.data(), all.data(), W);
+  if (rc != HMJ_OK) return rc;
+  std::vector<u64> st((size_t)G);
+  out->keys.clear();
+  out->nb.assign((size_t)G, 0);
+  out->np.assign((size_t)G, 0);
+  for (int g = 0; g < G; g++) {
+    const u64* p = &all[(size_t)g * W];
+    st[g] = p[0];
+    out->nb[g] = p[3];
+    out->np[g] = p[4];
+    if (!p[0]) {
+      out->keys.insert(out->keys.end(), p + 5, p + 5 + std::min<u64>(p[1], K));
+      out->keys.insert(out->keys.end(), p + 5 + K, p + 5 + K + std::min<u64>(p[2], K));
+    }
+  }
+  return settle(c, *err, st);
+}
+
+void add_result(hmj_result* acc, const hmj_result& r) {
+  acc->n_matches += r.n_matches;
+  acc->sum_r += r.sum_r;
+  acc->sum_s += r.sum_s;
+  acc->xor_fold ^= r.xor_fold;
+  acc->mix_sum += r.mix_sum;
+  acc->sum_probe_all += r.sum_probe_all;
+}
+
+// the per-phase times and byte counts of one (sub-)join, added to the step's totals
+void add_timing(hmj_timing* acc, const hmj_timing& t) {
+  acc->ms_total += t.ms_total;
+  acc->ms_partition_build += t.ms_partition_build;
+  acc->ms_partition_probe += t.ms_partition_probe;
+  acc->ms_hist += t.ms_hist;
+  acc->ms_scan += t.ms_scan;
+  acc->ms_scatter += t.ms_scatter;
+  acc->ms_offsets += t.ms_offsets;
+  acc->ms_probe_count += t.ms_probe_count;
+  acc->ms_out_scan += t.ms_out_scan;
+  acc->ms_probe_write += t.ms_probe_write;
+  acc->ms_order += t.ms_order;
+  acc->n_scatter_launches += t.n_scatter_launches;
+  acc->n_split_retries += t.n_split_retries;
+  acc->bytes_scatter += t.bytes_scatter;
+  acc->bytes_hist += t.bytes_hist;
+  acc->bytes_probe_count += t.bytes_probe_count;
+  acc->bytes_probe_write += t.bytes_probe_write;
+  acc->path |= t.path;
+  acc->ms_scatter_pass[0] += t.ms_scatter_pass[0];
+  acc->ms_scatter_pass[1] += t.ms_scatter_pass[1];
+  if (t.radix_passes) {  // the plan of the latest sub-join that partitioned anything
+    acc->radix_bits = t.radix_bits;
+    acc->radix_passes = t.radix_passes;
+    acc->key_prefix_bits = t.key_prefix_bits;
+    acc->key_window_low = t.key_window_low;
+  }
+  acc->n_probe_items += t.n_probe_items;
+}
+float kernel_ms(const hmj_timing& t) {
+  return t.ms_hist + t.ms_scan + t.ms_scatter + t.ms_offsets + t.ms_probe_count + t.ms_out_scan + t.ms_probe_write + t.ms_order;
+}
+
+// Does any rank have to grow one of its receive buffers in this step?  Decided from numbers all ranks hold.
+bool any_rank_grows(hmj_comm* m, int which, const std::vector<u64>& need) {
+  const int G = m->n_ranks;
+  if (m->peak_rows.size() != (size_t)G * 4) m->peak_rows.assign((size_t)G * 4, 0);
+  bool grows = false;
+  for (int g = 0; g < G; g++)
+    if (need[g] > m->peak_rows[(size_t)g * 4 + which]) grows = true;
+  return grows;
+}
+void note_peaks(hmj_comm* m, int which, const std::vector<u64>& need) {
+  for (int g = 0; g < m->n_ranks; g++)
+    m->peak_rows[(size_t)g * 4 + which] = std::max(m->peak_rows[(size_t)g * 4 + which], need[g]);
+}
+
+int ensure_round_events(hmj_ctx* c, size_t n) {
+  hmj_comm* m = c->comm;
+  while (m->round_ev.size() < n) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->round_ev.push_back(e);
+  }
+  return HMJ_OK;
+}
+
+// The reduction over all ranks that ends every step; `mine`: this rank's pending error.  All ranks return together.
+int final_reduction(hmj_ctx* c, int mine, const hmj_result* local_out, hmj_result* global_out) {
+  hmj_comm* m = c->comm;
+  const int G = m->n_ranks;
+  u64 w[7] = {mine == HMJ_OK ? 0ull : (u64)(int64_t)mine, local_out->n_matches, local_out->sum_r, local_out->sum_s,
+              local_out->xor_fold, local_out->mix_sum, local_out->sum_probe_all};
+  if (mine != HMJ_OK) std::memset(w + 1, 0, 6 * sizeof(u64));
+  std::vector<u64> all(7 * (size_t)G), st((size_t)G);
+  int rc = transport_allgather(c, w, all.data(), 7);
+  if (rc != HMJ_OK) return mine != HMJ_OK ? mine : rc;
+  for (int g = 0; g < G; g++) st[g] = all[7 * (size_t)g];
+  if ((rc = settle(c, mine, st)) != HMJ_OK) return rc;
+  if (global_out) {
+    std::memset(global_out, 0, sizeof(*global_out));
+    for (int g = 0; g < G; g++) {
+      const u64* p = &all[7 * (size_t)g + 1];
+      global_out->n_matches += p[0];
+      global_out->sum_r += p[1];
+      global_out->sum_s += p[2];
+      global_out->xor_fold ^= p[3];
+      global_out->mix_sum += p[4];
+      global_out->sum_probe_all += p[5];
+    }
+  }
+  return HMJ_OK;
+}
+
+float ms_since(std::chrono::steady_clock::time_point t) {
+  return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
+}
+
+// ---- digit path: the first radix pass is the owner --------------------------------------------------------
+// compute stream: pre-pass R | pre-pass S | join of round 0 | join of round 1 | ...
+// comm stream   :            | R rounds ..........| S round 0 | S round 1 | ...      (round = a range of digits)
+int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np, u32 flags, const hmj_digit_plan& plan,
+                        hmj_result* local_out, int* err) {
   hmj_comm* m = c->comm;
   const int G = m->n_ranks, me = m->rank;
-  if (!m->has_cb && !m->nccl) return fail(c, HMJ_E_ARG, "communicator has no transport");
-  if (flags & HMJ_ORDERED) flags |= HMJ_MATERIALIZE;
-  int rc;
-  std::memset(&m->info, 0, sizeof(m->info));
-  m->info.n_ranks = G;
-  const auto t_begin = std::chrono::steady_clock::now();
-  auto ms_since = [](std::chrono::steady_clock::time_point t) {
-    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
-  };
+  const int ba = plan.digit_bits, low = plan.digit_low;
+  const u32 D = 1u << ba, NR = plan.n_rounds;
+  const bool materialize = (flags & HMJ_MATERIALIZE) != 0;
+  m->info.owner_mode = 3;
+  m->info.digit_bits = ba;
+  m->info.digit_low = low;
+  m->info.sample_max_share = plan.max_share;
+  m->info.rounds_build = m->info.rounds_probe = NR;
+  hmj_timing acc;
+  std::memset(&acc, 0, sizeof(acc));
+  const auto t_split = std::chrono::steady_clock::now();
 
-  // ---- 1. owner function ---------------------------------------------------------------------------
-  // Ordered results: rank g owns the g-th key range between splitters all ranks agree on (their pooled key
-  // samples' quantiles), so per-rank ordered results concatenate in key order.  Every other mode: the owner
-  // is a mixing hash of the key, which spreads any key set -- dense integer keys included -- evenly.
-  hmj::OwnerFn own;
-  std::memset(&own, 0, sizeof(own));
-  own.G = (u32)G;
-  own.mode = (flags & HMJ_ORDERED) ? 2u : 1u;
-  m->info.owner_mode = (int)own.mode;
-  if (own.mode == 2 && G > 1) {
-    const int K = kSampleKeys, W = 2 * K + 2;
-    if ((rc = ensure_dev(c, m->sample_dev, (size_t)2 * K * 8)) != HMJ_OK) return rc;
-    if ((rc = ensure_host(c, m->gather_host, (size_t)W * 8 * (G + 1))) != HMJ_OK) return rc;
-    u64* mine = static_cast<u64*>(m->gather_host.p);
-    u64* all = mine + W;
-    u64* sd = static_cast<u64*>(m->sample_dev.p);
-    const u32 kr = (u32)std::min<u64>(K, n_build), ks = (u32)std::min<u64>(K, n_probe);
-    if (kr) hipLaunchKernelGGL(sample_keys_kernel, dim3((kr + 255) / 256), dim3(256), 0, c->stream,
-                               static_cast<const hmj::Tup*>(build_shard_dev), (u64)n_build, kr, sd);
-    if (ks) hipLaunchKernelGGL(sample_keys_kernel, dim3((ks + 255) / 256), dim3(256), 0, c->stream,
-                               static_cast<const hmj::Tup*>(probe_shard_dev), (u64)n_probe, ks, sd + K);
-    HIP_TRY(hipGetLastError());
-    mine[0] = kr;
-    mine[1] = ks;
-    HIP_TRY(hipMemcpyAsync(mine + 2, sd, (size_t)2 * K * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = transport_allgather(c, mine, all, W)) != HMJ_OK) return rc;
-    std::vector<u64> keys;
-    for (int g = 0; g < G; g++) {
-      const u64* p = all + (size_t)g * W;
-      keys.insert(keys.end(), p + 2, p + 2 + p[0]);
-      keys.insert(keys.end(), p + 2 + K, p + 2 + K + p[1]);
+  // ---- 1. the first radix pass of both shards (digit-major, dense, stable) + bucket starts to the host
+  const size_t noff = (size_t)D + 1;
+  u64* oh = nullptr;
+  if (*err == HMJ_OK) {
+    int rc = ensure_dev(c, m->parted_r, (size_t)nb * 16 + 16);
+    if (rc == HMJ_OK) rc = ensure_dev(c, m->parted_s, (size_t)np * 16 + 16);
+    if (rc == HMJ_OK) rc = ensure_dev(c, m->offs, 2 * noff * 8);
+    if (rc == HMJ_OK) rc = ensure_host(c, m->offs_host, 2 * noff * 8);
+    if (rc == HMJ_OK) rc = ensure_round_events(c, NR);
+    if (rc == HMJ_OK) {
+      oh = static_cast<u64*>(m->offs_host.p);
+      u64* od = static_cast<u64*>(m->offs.p);
+      spans_reset(c);
+      struct { const void* in; void* out; u64 n; u64* o_dev; u64* o_host; hipEvent_t ev; int rel; } side[2] = {
+          {R, m->parted_r.p, nb, od, oh, m->ev_split, 0}, {S, m->parted_s.p, np, od + noff, oh + noff, m->ev_split_s, 1}};
+      for (auto& sd : side) {
+        if (rc != HMJ_OK) break;
+        hipError_t e = hipSuccess;
+        if (sd.n == 0)
+          e = hipMemsetAsync(sd.o_dev, 0, noff * 8, c->stream);
+        else
+          rc = radix_pass(c, sd.in, sd.out, (u32)sd.n, low, ba, sd.rel, reinterpret_cast<hmj::u64*>(sd.o_dev), 0);
+        if (rc == HMJ_OK && e == hipSuccess) e = hipMemcpyAsync(sd.o_host, sd.o_dev, noff * 8, hipMemcpyDeviceToHost, c->stream);
+        if (rc == HMJ_OK && e == hipSuccess) e = hipEventRecord(sd.ev, c->stream);
+        if (rc == HMJ_OK && e != hipSuccess) rc = fail(c, HMJ_E_HIP, "digit pre-pass", e);
+      }
     }
-    std::sort(keys.begin(), keys.end());
-    for (int i = 0; i + 1 < G; i++)
-      own.spl[i] = keys.empty() ? ~0ull : keys[std::min(keys.size() - 1, keys.size() * (size_t)(i + 1) / (size_t)G)];
+    if (rc != HMJ_OK) *err = rc;
   }
 
-  // ---- 2. split both shards by owner, 3. counts -------------------------------------------------------
+  // ---- 2. per relation: counts all-gather -> layout -> receive buffer -> rounds queued on the communication stream.
+  // The build side's rounds are on the links while the probe side is still being partitioned.
+  std::vector<u64> so((size_t)NR * G), sr(so.size()), ro(so.size()), rr(so.size());
+  std::vector<u64> round_off_r(NR + 1, 0), round_off_s(NR + 1, 0);
+  std::vector<const void*> sp(G);
+  std::vector<void*> rp(G);
+  std::vector<u64> sb(G), rb(G);
+  for (int rel = 0; rel < 2; rel++) {
+    std::vector<u64> msg((size_t)D + 1, 0), all(((size_t)D + 1) * G, 0), st((size_t)G), need((size_t)G, 0);
+    if (*err == HMJ_OK) {
+      hipError_t e = hipEventSynchronize(rel == 0 ? m->ev_split : m->ev_split_s);
+      if (e != hipSuccess) *err = fail(c, HMJ_E_HIP, "digit pre-pass", e);
+    }
+    if (*err == HMJ_OK) {
+      const u64* o = oh + (size_t)rel * noff;
+      for (u32 d = 0; d < D; d++) msg[1 + d] = o[d + 1] - o[d];
+    }
+    if (rel == 1 && c->profiling && *err == HMJ_OK) {  // both pre-passes are complete: their spans
+      spans_collect(c);
+      add_timing(&acc, c->timing);
+      m->info.ms_split = ms_since(t_split);
+    }
+    msg[0] = *err == HMJ_OK ? 0ull : (u64)(int64_t)*err;
+    int rc = transport_allgather(c, msg.data(), all.data(), (int)D + 1);
+    if (rc != HMJ_OK) return rc;
+    std::vector<u64> counts((size_t)G * D);
+    for (int g = 0; g < G; g++) {
+      st[g] = all[(size_t)g * (D + 1)];
+      std::memcpy(&counts[(size_t)g * D], &all[(size_t)g * (D + 1) + 1], (size_t)D * 8);
+    }
+    if ((rc = settle(c, *err, st)) != HMJ_OK) return rc;
+    // rows every rank will own: the 2^32-1 limit of one local join is checked for ALL ranks by ALL ranks
+    for (int g = 0; g < G; g++)
+      for (int s = 0; s < G; s++)
+        for (u32 d = plan.owner_first[g]; d < plan.owner_first[g + 1]; d++) need[g] += counts[(size_t)s * D + d];
+    for (int g = 0; g < G; g++)
+      if (need[g] > 0xFFFFFFFFull) {
+        char msgb[96];
+        std::snprintf(msgb, sizeof(msgb), "rank %d would own more than 2^32-1 %s rows", g, rel == 0 ? "build" : "probe");
+        return fail(c, HMJ_E_UNSUPPORTED, msgb);
+      }
+    std::vector<u64>& round_off = rel == 0 ? round_off_r : round_off_s;
+    rc = hmj_exchange_digit_layout(G, me, &plan, counts.data(), so.data(), sr.data(), ro.data(), rr.data(), round_off.data());
+    if (rc != HMJ_OK) return fail(c, rc, "digit layout");  // (same inputs on every rank: all fail alike)
+    (rel == 0 ? m->info.recv_build : m->info.recv_probe) = need[me];
+    DevBuf& recv = rel == 0 ? m->recv_r : m->recv_s;
+    const bool grows = any_rank_grows(m, 2 + rel, need);
+    int mine = ensure_dev(c, recv, (size_t)need[me] * 16 + 16);
+    if (grows) {
+      if ((rc = status_round(c, mine)) != HMJ_OK) return rc;
+      note_peaks(m, 2 + rel, need);
+    } else if (mine != HMJ_OK) {
+      return mine;  // cannot happen: the buffer is at least as large as in an earlier step
+    }
+    // queue the rounds
+    HIP_TRY(hipStreamWaitEvent(m->stream, rel == 0 ? m->ev_split : m->ev_split_s, 0));
+    HIP_TRY(hipEventRecord(rel == 0 ? m->ev_t0 : m->ev_t1, m->stream));
+    const char* parted = static_cast<const char*>(rel == 0 ? m->parted_r.p : m->parted_s.p);
+    char* rbase = static_cast<char*>(recv.p);
+    const bool in_place = G == 1 && !m->self_exchange;  // (not reached today: one rank takes the plain join)
+    for (u32 r = 0; r < NR && !in_place; r++) {
+      for (int g = 0; g < G; g++) {
+        sp[g] = parted + so[(size_t)r * G + g] * 16;
+        rp[g] = rbase + ro[(size_t)r * G + g] * 16;
+        sb[g] = sr[(size_t)r * G + g] * 16;
+        rb[g] = rr[(size_t)r * G + g] * 16;
+      }
+      if ((rc = transport_round(c, (int)(rel * NR + r), sp.data(), sb.data(), rp.data(), rb.data())) != HMJ_OK) return rc;
+      if (rel == 1) HIP_TRY(hipEventRecord(m->round_ev[r], m->stream));
+    }
+    if (rel == 0) {
+      HIP_TRY(hipEventRecord(m->ev_t3, m->stream));
+      HIP_TRY(hipEventRecord(m->ev_build, m->stream));
+    } else {
+      HIP_TRY(hipEventRecord(m->ev_t2, m->stream));
+    }
+  }
+  if (!c->profiling) m->info.ms_split = ms_since(t_split);
+
+  // ---- 3. a round that has arrived is a complete key range of both relations: join it (remaining radix passes,
+  // build, probe) while later rounds are on the links.  The digit bits are consumed: the local partitions start
+  // right under them (the reference's recursion masks off consumed bits the same way, radix_hash.h:219-220).
+  const auto t_local = std::chrono::steady_clock::now();
+  std::memset(local_out, 0, sizeof(*local_out));
+  int lerr = HMJ_OK;
+  const int saved_prefix = c->prefix_bits;
+  HIP_TRY(hipStreamWaitEvent(c->stream, m->ev_build, 0));
+  for (u32 r = 0; r < NR && lerr == HMJ_OK; r++) {
+    const u64 nr_ = round_off_r[r + 1] - round_off_r[r], ns_ = round_off_s[r + 1] - round_off_s[r];
+    hipError_t e = hipStreamWaitEvent(c->stream, m->round_ev[r], 0);
+    if (e != hipSuccess) {
+      lerr = fail(c, HMJ_E_HIP, "round event", e);
+      break;
+    }
+    if (ns_ == 0) continue;                              // no probe rows: no result rows, no probe payloads
+    if (nr_ == 0 && !(flags & HMJ_SUM_PROBE)) continue;  // nothing can match (and no probe payload sum is asked for)
+    hmj_result res;
+    spans_reset(c);
+    // count modes: skip the bits the digit consumed (a round of several digits differs in them, which any
+    // partition function may ignore); materialising joins (one round) let the planner sample the keys itself
+    if (!materialize) c->prefix_bits = 64 - low;
+    const int rc = join_device(c, static_cast<const char*>(m->recv_r.p) + round_off_r[r] * 16, nr_,
+                               static_cast<const char*>(m->recv_s.p) + round_off_s[r] * 16, ns_, flags, &res, false);
+    c->prefix_bits = saved_prefix;
+    if (rc != HMJ_OK) {
+      lerr = rc;
+      break;
+    }
+    m->info.n_subjoins++;
+    if (materialize)
+      *local_out = res;  // (one round: the columns of this join)
+    else
+      add_result(local_out, res);
+    if (c->profiling) {
+      (void)hipStreamSynchronize(c->stream);
+      spans_collect(c);
+      add_timing(&acc, c->timing);
+    }
+  }
+  if (lerr != HMJ_OK) *err = lerr;
+  // the sends of this rank must have left its buffers before the next step may overwrite them
+  hipError_t e = hipStreamSynchronize(m->stream);
+  if (e != hipSuccess && *err == HMJ_OK) *err = fail(c, HMJ_E_HIP, "communication stream", e);
+  m->info.ms_local = ms_since(t_local);
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, m->ev_t0, m->ev_t3) == hipSuccess) m->info.ms_exchange_build = ms;
+  if (hipEventElapsedTime(&ms, m->ev_t1, m->ev_t2) == hipSuccess) m->info.ms_exchange_probe = ms;
+  if (c->profiling) {
+    const u32 path = acc.path;
+    c->timing = acc;
+    c->timing.path = path;
+    m->info.ms_kernels = kernel_ms(acc);
+  }
+  return HMJ_OK;
+}
+
+// ---- owner-split path: hash owner (fallback for keys the digit ranges cannot balance) or key-range owner
+// (HMJ_ORDERED): a separate stable split by owner, then ONE local join of everything this rank received.
+int exchange_owner_path(hmj_ctx* c, const void* build_shard_dev, u64 n_build, const void* probe_shard_dev, u64 n_probe,
+                        u32 flags, const hmj::OwnerFn& own, hmj_result* local_out, int* err) {
+  hmj_comm* m = c->comm;
+  const int G = m->n_ranks, me = m->rank;
+  int rc;
+  m->info.owner_mode = (int)own.mode;
+  // ---- split both shards by owner, counts
   const void *parted_r = build_shard_dev, *parted_s = probe_shard_dev;
-  std::vector<u64> cnt(2 * (size_t)G, 0), allcnt(2 * (size_t)G * G, 0);
+  std::vector<u64> cnt(2 * (size_t)G + 1, 0), allcnt((2 * (size_t)G + 1) * G, 0);
   const auto t_split = std::chrono::steady_clock::now();
   if (G > 1) {
     int bits = 0;
     while ((1 << bits) < G) bits++;
     const size_t noff = ((size_t)1 << bits) + 1;
-    if ((rc = ensure_dev(c, m->parted_r, (size_t)n_build * 16)) != HMJ_OK) return rc;
-    if ((rc = ensure_dev(c, m->parted_s, (size_t)n_probe * 16)) != HMJ_OK) return rc;
-    if ((rc = ensure_dev(c, m->offs, 2 * noff * 8)) != HMJ_OK) return rc;
-    if ((rc = ensure_host(c, m->gather_host, std::max<size_t>(2 * noff * 8, (size_t)(2 * kSampleKeys + 2) * 8 * (G + 1)))) != HMJ_OK)
-      return rc;
-    u64* od = static_cast<u64*>(m->offs.p);
-    if ((rc = owner_split(c, build_shard_dev, (u32)n_build, own, m->parted_r.p, od)) != HMJ_OK) return rc;
-    if ((rc = owner_split(c, probe_shard_dev, (u32)n_probe, own, m->parted_s.p, od + noff)) != HMJ_OK) return rc;
-    u64* oh = static_cast<u64*>(m->gather_host.p);
-    HIP_TRY(hipMemcpyAsync(oh, od, 2 * noff * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipEventRecord(m->ev_split, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int g = 0; g < G; g++) {
-      cnt[g] = oh[g + 1] - oh[g];
-      cnt[G + g] = oh[noff + g + 1] - oh[noff + g];
+    if (*err == HMJ_OK) {
+      rc = ensure_dev(c, m->parted_r, (size_t)n_build * 16);
+      if (rc == HMJ_OK) rc = ensure_dev(c, m->parted_s, (size_t)n_probe * 16);
+      if (rc == HMJ_OK) rc = ensure_dev(c, m->offs, 2 * noff * 8);
+      if (rc == HMJ_OK) rc = ensure_host(c, m->offs_host, 2 * noff * 8);
+      if (rc == HMJ_OK) {
+        u64* od = static_cast<u64*>(m->offs.p);
+        u64* oh = static_cast<u64*>(m->offs_host.p);
+        rc = owner_split(c, build_shard_dev, (u32)n_build, own, m->parted_r.p, od);
+        if (rc == HMJ_OK) rc = owner_split(c, probe_shard_dev, (u32)n_probe, own, m->parted_s.p, od + noff);
+        hipError_t e = hipSuccess;
+        if (rc == HMJ_OK) e = hipMemcpyAsync(oh, od, 2 * noff * 8, hipMemcpyDeviceToHost, c->stream);
+        if (rc == HMJ_OK && e == hipSuccess) e = hipEventRecord(m->ev_split, c->stream);
+        if (rc == HMJ_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (rc == HMJ_OK && e != hipSuccess) rc = fail(c, HMJ_E_HIP, "owner split", e);
+        if (rc == HMJ_OK)
+          for (int g = 0; g < G; g++) {
+            cnt[1 + g] = oh[g + 1] - oh[g];
+            cnt[1 + G + g] = oh[noff + g + 1] - oh[noff + g];
+          }
+      }
+      if (rc != HMJ_OK) *err = rc;
     }
     parted_r = m->parted_r.p;
     parted_s = m->parted_s.p;
   } else {
-    cnt[0] = n_build;
-    cnt[1] = n_probe;
+    cnt[1] = n_build;
+    cnt[2] = n_probe;
     HIP_TRY(hipEventRecord(m->ev_split, c->stream));
   }
   m->info.ms_split = ms_since(t_split);
-  if ((rc = transport_allgather(c, cnt.data(), allcnt.data(), 2 * G)) != HMJ_OK) return rc;
+  cnt[0] = *err == HMJ_OK ? 0ull : (u64)(int64_t)*err;
+  if ((rc = transport_allgather(c, cnt.data(), allcnt.data(), 2 * G + 1)) != HMJ_OK) return rc;
+  std::vector<u64> st((size_t)G);
+  for (int g = 0; g < G; g++) st[g] = allcnt[(size_t)g * (2 * G + 1)];
+  if ((rc = settle(c, *err, st)) != HMJ_OK) return rc;
   std::vector<u64> MR((size_t)G * G), MS((size_t)G * G);  // [src][dst]
-  u64 nr = 0, ns = 0;
   for (int s = 0; s < G; s++)
     for (int d = 0; d < G; d++) {
-      MR[(size_t)s * G + d] = allcnt[(size_t)s * 2 * G + d];
-      MS[(size_t)s * G + d] = allcnt[(size_t)s * 2 * G + G + d];
+      MR[(size_t)s * G + d] = allcnt[(size_t)s * (2 * G + 1) + 1 + d];
+      MS[(size_t)s * G + d] = allcnt[(size_t)s * (2 * G + 1) + 1 + G + d];
     }
-  for (int s = 0; s < G; s++) {
-    nr += MR[(size_t)s * G + me];
-    ns += MS[(size_t)s * G + me];
-  }
-  if (nr > 0xFFFFFFFFull || ns > 0xFFFFFFFFull) return fail(c, HMJ_E_UNSUPPORTED, "this rank would own more than 2^32-1 rows");
+  // every rank holds the whole matrix: the row limit of a local join is checked for ALL destination ranks, so
+  // all ranks fail together (a skewed key range in ordered mode is the usual way to reach it on ONE rank)
+  std::vector<u64> need_r((size_t)G, 0), need_s((size_t)G, 0);
+  for (int d = 0; d < G; d++)
+    for (int s = 0; s < G; s++) {
+      need_r[d] += MR[(size_t)s * G + d];
+      need_s[d] += MS[(size_t)s * G + d];
+    }
+  for (int d = 0; d < G; d++)
+    if (need_r[d] > 0xFFFFFFFFull || need_s[d] > 0xFFFFFFFFull) {
+      char msg[96];
+      std::snprintf(msg, sizeof(msg), "rank %d would own more than 2^32-1 rows", d);
+      return fail(c, HMJ_E_UNSUPPORTED, msg);
+    }
+  const u64 nr = need_r[me], ns = need_s[me];
   m->info.recv_build = nr;
   m->info.recv_probe = ns;
 
-  // ---- 4. rounds and receive layout -------------------------------------------------------------------
+  // ---- rounds and receive layout
   // Build side: source-major (sources in rank order = global input order, which HMJ_FIRST_WINS relies on).
   // Probe side: round-major and in several rounds, so that the local pass A can start on the rows that have
   // arrived while later rounds are still on the links.
@@ -536,15 +996,21 @@ int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_dev, uint64
   const u32 rounds_s = hmj_exchange_rounds(G, MS.data(), per_round);
   m->info.rounds_build = rounds_r;
   m->info.rounds_probe = rounds_s;
-  if ((rc = ensure_dev(c, m->recv_r, (size_t)nr * 16 + 16)) != HMJ_OK) return rc;
-  if ((rc = ensure_dev(c, m->recv_s, (size_t)ns * 16 + 16)) != HMJ_OK) return rc;
-  while (m->round_ev.size() < rounds_s) {
-    hipEvent_t e;
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    m->round_ev.push_back(e);
+  {
+    const bool grows = any_rank_grows(m, 2, need_r) || any_rank_grows(m, 3, need_s);
+    int mine = ensure_dev(c, m->recv_r, (size_t)nr * 16 + 16);
+    if (mine == HMJ_OK) mine = ensure_dev(c, m->recv_s, (size_t)ns * 16 + 16);
+    if (mine == HMJ_OK) mine = ensure_round_events(c, rounds_s);
+    if (grows) {
+      if ((rc = status_round(c, mine)) != HMJ_OK) return rc;
+      note_peaks(m, 2, need_r);
+      note_peaks(m, 3, need_s);
+    } else if (mine != HMJ_OK) {
+      return mine;
+    }
   }
 
-  // ---- 5. exchange: everything is queued on the communication stream behind the splits -----------------
+  // ---- exchange: everything is queued on the communication stream behind the splits
   HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_split, 0));
   HIP_TRY(hipEventRecord(m->ev_t0, m->stream));
   if ((rc = exchange_relation(c, parted_r, MR.data(), rounds_r, 0, m->recv_r.p, nullptr, nullptr)) != HMJ_OK) return rc;
@@ -555,54 +1021,128 @@ int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_dev, uint64
     return rc;
   HIP_TRY(hipEventRecord(m->ev_t2, m->stream));
 
-  // ---- 6. local join: build side as soon as it is complete, probe side as its rounds arrive ------------
+  // ---- local join: build side as soon as it is complete, probe side as its rounds arrive
   const auto t_local = std::chrono::steady_clock::now();
-  HIP_TRY(hipStreamWaitEvent(c->stream, m->ev_build, 0));
+  int lerr = HMJ_OK;
+  hipError_t e = hipStreamWaitEvent(c->stream, m->ev_build, 0);
+  if (e != hipSuccess) lerr = fail(c, HMJ_E_HIP, "hipStreamWaitEvent", e);
   spans_reset(c);
   c->sample_build_only = true;
-  if (flags == 0) {  // plain count join: the build side is partitioned while the probe rows are on the links
-    rc = prepare_build(c, m->recv_r.p, nr, ns);
-    if (rc != HMJ_OK) {
-      c->sample_build_only = false;
-      return rc;
-    }
+  // count modes (checksums and first-wins included): the build side is partitioned while the probe rows are on
+  // the links -- the plan of a join does not depend on those flags, only materialising joins may plan differently
+  if (lerr == HMJ_OK && !(flags & HMJ_MATERIALIZE)) lerr = prepare_build(c, m->recv_r.p, nr, ns);
+  if (lerr == HMJ_OK) {
+    c->arrive_rows.assign(round_end.begin(), round_end.end());
+    c->arrive_ev.assign(m->round_ev.begin(), m->round_ev.begin() + rounds_s);
+    lerr = join_device(c, m->recv_r.p, nr, m->recv_s.p, ns, flags, local_out, false);
+    if (lerr == HMJ_OK) m->info.n_subjoins = 1;
   }
-  c->arrive_rows.assign(round_end.begin(), round_end.end());
-  c->arrive_ev.assign(m->round_ev.begin(), m->round_ev.begin() + rounds_s);
-  rc = join_device(c, m->recv_r.p, nr, m->recv_s.p, ns, flags, local_out, false);
   c->sample_build_only = false;
   c->arrive_rows.clear();
   c->arrive_ev.clear();
   if (c->profiling) {
     (void)hipStreamSynchronize(c->stream);
     spans_collect(c);
+    m->info.ms_kernels = kernel_ms(c->timing);
   }
-  if (rc != HMJ_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (lerr != HMJ_OK) *err = lerr;
+  e = hipStreamSynchronize(m->stream);
+  if (e != hipSuccess && *err == HMJ_OK) *err = fail(c, HMJ_E_HIP, "communication stream", e);
   m->info.ms_local = ms_since(t_local);
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, m->ev_t0, m->ev_t1) == hipSuccess) m->info.ms_exchange_build = ms;
   if (hipEventElapsedTime(&ms, m->ev_t1, m->ev_t2) == hipSuccess) m->info.ms_exchange_probe = ms;
-
-  // ---- 7. the reduction over all ranks ------------------------------------------------------------------
-  if (global_out) {
-    std::memset(global_out, 0, sizeof(*global_out));
-    u64 mine[6] = {local_out->n_matches, local_out->sum_r, local_out->sum_s, local_out->xor_fold, local_out->mix_sum,
-                   local_out->sum_probe_all};
-    std::vector<u64> all(6 * (size_t)G);
-    if ((rc = transport_allgather(c, mine, all.data(), 6)) != HMJ_OK) return rc;
-    for (int g = 0; g < G; g++) {
-      const u64* p = &all[6 * (size_t)g];
-      global_out->n_matches += p[0];
-      global_out->sum_r += p[1];
-      global_out->sum_s += p[2];
-      global_out->xor_fold ^= p[3];
-      global_out->mix_sum += p[4];
-      global_out->sum_probe_all += p[5];
-    }
-  }
-  m->info.ms_total = ms_since(t_begin);
   return HMJ_OK;
 }
 
-}  // extern "C"
+}  // namespace
+
+extern "C" int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_dev, uint64_t n_build, const void* probe_shard_dev,
+                                            uint64_t n_probe, uint32_t flags, hmj_result* local_out, hmj_result* global_out) {
+  if (!c) return HMJ_E_ARG;
+  // (argument errors every rank makes alike -- the same program runs everywhere -- return at once)
+  if (!local_out) return fail(c, HMJ_E_ARG, "local_out is NULL");
+  if (!c->comm) return fail(c, HMJ_E_ARG, "no communicator: call hmj_comm_init_rank or hmj_comm_set_transport first");
+  HIP_TRY(hipSetDevice(c->device));
+  hmj_comm* m = c->comm;
+  const int G = m->n_ranks;
+  if (!m->has_cb && !m->nccl) return fail(c, HMJ_E_ARG, "communicator has no transport");
+  if (flags & HMJ_ORDERED) flags |= HMJ_MATERIALIZE;
+  std::memset(&m->info, 0, sizeof(m->info));
+  std::memset(local_out, 0, sizeof(*local_out));
+  m->info.n_ranks = G;
+  const auto t_begin = std::chrono::steady_clock::now();
+  // errors that depend on THIS rank's shard are carried to the next collective, where all ranks leave together
+  int err = HMJ_OK;
+  if (n_build > 0xFFFFFFFFull || n_probe > 0xFFFFFFFFull) err = fail(c, HMJ_E_ARG, "more than 2^32-1 rows in one shard");
+  else if ((n_build && !build_shard_dev) || (n_probe && !probe_shard_dev)) err = fail(c, HMJ_E_ARG, "shard pointer is NULL");
+
+  if (G == 1 && !m->self_exchange) {
+    // one rank owns every key: nothing to exchange, the step is the plain local join
+    if (err != HMJ_OK) return err;
+    spans_reset(c);
+    int rc = join_device(c, build_shard_dev, n_build, probe_shard_dev, n_probe, flags, local_out, false);
+    if (c->profiling) {
+      (void)hipStreamSynchronize(c->stream);
+      spans_collect(c);
+      m->info.ms_kernels = kernel_ms(c->timing);
+    }
+    if (rc != HMJ_OK) return rc;
+    m->info.recv_build = n_build;
+    m->info.recv_probe = n_probe;
+    m->info.n_subjoins = 1;
+    if (global_out) {
+      *global_out = *local_out;
+      global_out->key = global_out->rval = global_out->sval = nullptr;
+    }
+    m->info.ms_total = m->info.ms_local = ms_since(t_begin);
+    m->info.ms_exposed = c->profiling ? std::max(0.f, m->info.ms_total - m->info.ms_kernels) : 0.f;
+    return HMJ_OK;
+  }
+
+  // ---- 1. every rank's key sample and shard sizes (one all-gather; also the first point all ranks can fail at)
+  StepSample smp;
+  int rc = gather_samples(c, build_shard_dev, n_build, probe_shard_dev, n_probe, &err, &smp);
+  if (rc != HMJ_OK) return rc;
+
+  // ---- 2. the owner function
+  hmj::OwnerFn own;
+  std::memset(&own, 0, sizeof(own));
+  own.G = (u32)G;
+  if (flags & HMJ_ORDERED) {
+    // Ordered results: rank g owns the g-th key range between splitters all ranks agree on (their pooled key
+    // samples' quantiles), so per-rank ordered results concatenate in key order.
+    own.mode = 2;
+    std::vector<u64> keys = smp.keys;
+    std::sort(keys.begin(), keys.end());
+    for (int i = 0; i + 1 < G; i++)
+      own.spl[i] = keys.empty() ? ~0ull : keys[std::min(keys.size() - 1, keys.size() * (size_t)(i + 1) / (size_t)G)];
+    rc = exchange_owner_path(c, build_shard_dev, n_build, probe_shard_dev, n_probe, flags, own, local_out, &err);
+  } else {
+    // rounds: about target_round_bytes per message of the probe side (materialising joins: one round -- their
+    // result columns are those of ONE local join)
+    u64 pair_rows = 0;
+    for (int g = 0; g < G; g++) pair_rows = std::max<u64>(pair_rows, std::max(smp.np[g], smp.nb[g]) / (u64)G);
+    const u64 per_round = std::max<u64>(1, m->target_round_bytes / 16);
+    u64 nr64 = (flags & HMJ_MATERIALIZE) ? 1 : (pair_rows + per_round - 1) / per_round;
+    nr64 = std::min<u64>(std::max<u64>(nr64, 1), HMJ_MAX_ROUNDS);
+    hmj_digit_plan plan;
+    if (hmj_exchange_digit_plan(G, smp.keys.data(), smp.keys.size(), (u32)nr64, &plan) != HMJ_OK) return fail(c, HMJ_E_ARG, "digit plan");
+    if (plan.usable) {
+      rc = exchange_digit_path(c, build_shard_dev, n_build, probe_shard_dev, n_probe, flags, plan, local_out, &err);
+    } else {
+      // a few clusters of keys: no contiguous digit ranges balance the ranks -- the hash owner spreads ANY key set
+      own.mode = 1;
+      m->info.fallback = 1;
+      m->info.sample_max_share = plan.max_share;
+      rc = exchange_owner_path(c, build_shard_dev, n_build, probe_shard_dev, n_probe, flags, own, local_out, &err);
+    }
+  }
+  if (rc != HMJ_OK) return rc;
+
+  // ---- 3. the reduction over all ranks (and the last point a failed local join is reported at)
+  rc = final_reduction(c, err, local_out, global_out);
+  m->info.ms_total = ms_since(t_begin);
+  m->info.ms_exposed = c->profiling ? std::max(0.f, m->info.ms_total - m->info.ms_kernels) : 0.f;
+  return rc;
+}

@@ -122,6 +122,9 @@ void span_end(hmj_ctx* c, int id);
 // the whole local join (planning, retries) on device-resident relations
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
                 hmj_result* out, bool to_host);
+// one stable radix pass src -> dst (histogram, scan, write-combining scatter); offsets_out: 2^bits + 1 bucket starts
+int radix_pass(hmj_ctx* c, const void* src, void* dst, hmj::u32 n, int shift, int bits, int rel, hmj::u64* offsets_out,
+               int pass_index = 0);
 // partition the build side only (hmj_prepare_build_u64_device without the API prologue)
 int prepare_build(hmj_ctx* c, const void* R, uint64_t n_build, uint64_t n_probe_hint);
 void comm_destroy(hmj_ctx* c);  // exchange.hip: called by hmj_destroy

@@ -61,6 +61,40 @@ def exchange_plan(counts, rank, max_msg_rows, layout):
     return out
 
 
+def digit_plan(sample_keys, n_ranks, n_rounds=1):
+    """hmj_exchange_digit_plan: the digit window, the digit ranges the ranks own and the digit ranges of the rounds,
+    from a pooled key sample (pure host arithmetic inside the library).  Returns the ctypes struct."""
+    L = _lib.load_library()
+    k = np.ascontiguousarray(sample_keys, dtype=np.uint64)
+    plan = _lib.DigitPlan()
+    rc = L.hmj_exchange_digit_plan(n_ranks, k.ctypes.data_as(C.POINTER(C.c_uint64)), len(k), n_rounds, C.byref(plan))
+    if rc:
+        raise _lib.HmjError(rc, "hmj_exchange_digit_plan")
+    return plan
+
+
+def digit_of(keys, plan):
+    """The first radix pass's digit of every key under `plan` (radix.hip digit_of)."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    return ((keys >> np.uint64(plan.digit_low)) & np.uint64((1 << plan.digit_bits) - 1)).astype(np.int64)
+
+
+def digit_layout(plan, counts, rank):
+    """hmj_exchange_digit_layout.  counts: [G, 2^digit_bits] rows per (source rank, digit).  Returns a dict of
+    [n_rounds, G] uint64 arrays send_off / send_rows / recv_off / recv_rows and round_off [n_rounds + 1]."""
+    L = _lib.load_library()
+    m = np.ascontiguousarray(counts, dtype=np.uint64)
+    G, R = m.shape[0], plan.n_rounds
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))
+    out = {k: np.zeros((R, G), np.uint64) for k in ("send_off", "send_rows", "recv_off", "recv_rows")}
+    out["round_off"] = np.zeros(R + 1, np.uint64)
+    rc = L.hmj_exchange_digit_layout(G, rank, C.byref(plan), p(m), p(out["send_off"]), p(out["send_rows"]), p(out["recv_off"]),
+                                     p(out["recv_rows"]), p(out["round_off"]))
+    if rc:
+        raise _lib.HmjError(rc, "hmj_exchange_digit_layout")
+    return out
+
+
 def _hip():
     hip = C.CDLL(None)
     if not hasattr(hip, "hipMemcpy"):
@@ -167,9 +201,11 @@ def init_comm(ex, group=None, force_transport=None):
     return kind
 
 
-def init_comm_single(ex):
-    """One rank, RCCL transport: the whole exchange path with self send/recv (tests, HMJ_FORCE_DIST)."""
+def init_comm_single(ex, self_exchange=True):
+    """One rank, RCCL transport.  self_exchange=True: the whole exchange path with self send/recv (tests,
+    HMJ_FORCE_DIST); False: what a one-rank job does by default -- the plain local join, nothing crosses RCCL."""
     ex.comm_init_rccl(1, 0, new_unique_id())
+    ex.comm_set_self_exchange(self_exchange)
 
 
 def distributed_join(ex, r_shard, s_shard, flags=0):

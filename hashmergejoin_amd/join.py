@@ -163,6 +163,10 @@ class Executor:
         self._keep = transport
         self._check(self.L.hmj_comm_set_transport(self.h, C.byref(transport.struct)))
 
+    def comm_set_self_exchange(self, on=True):
+        """One-rank communicators: run the whole exchange path (tests / rehearsals) instead of the plain local join."""
+        self._check(self.L.hmj_comm_set_self_exchange(self.h, int(bool(on))))
+
     def comm_set_message_bytes(self, max_message_bytes=0, probe_round_bytes=0):
         self._check(self.L.hmj_comm_set_message_bytes(self.h, max_message_bytes, probe_round_bytes))
 

@@ -43,6 +43,7 @@ typedef struct hmj_ctx hmj_ctx;
                                /* single partition's result beyond 2^31-1 rows)                      */
 
 #define HMJ_E_RCCL (-6)        /* RCCL (or the host's transport callbacks) failed, or librccl is absent  */
+#define HMJ_E_PEER (-7)        /* a collective call failed on ANOTHER rank; every rank returns together   */
 
 /* flags for hmj_join_* */
 #define HMJ_MATERIALIZE 0x01u /* produce the (key, rval, sval) columns; else count/sums only --   */
@@ -254,36 +255,85 @@ int hmj_comm_destroy(hmj_ctx* ctx); /* also done by hmj_destroy */
 int hmj_comm_set_message_bytes(hmj_ctx* ctx, uint64_t max_message_bytes, uint64_t probe_round_bytes);
 
 /* The distributed join.  Replaces the HashMergeJoin ctor + iteration (hashjoin.h:56-68, :183-191) for
- * relations sharded by rows over the ranks.  Per call: owner split of both shards (stable histogram / scan /
- * scatter, as pass 1 of the reference's sort) -> counts all-gather -> grouped send/recv rounds on the
- * communicator's own stream -> local join; the build side is partitioned while the probe side is on the links,
- * and the probe side's first pass starts per arrived round.
- * Owner of a row: floor(mix64(key) * n_ranks / 2^64) -- even for any key set, dense integer keys included.
- * HMJ_ORDERED: the g-th key range between splitters all ranks agree on (quantiles of their pooled key
- * samples), so rank g's ordered rows precede rank g+1's: the concatenation in rank order is the reference's
- * iteration order.  HMJ_FIRST_WINS is global when rank r's build shard precedes rank r+1's in input order.
- * local_out: this rank's result (columns: device pointers owned by the ctx).  global_out (may be NULL):
- * counts and checksums over all ranks, columns NULL.  Collective: all ranks, same flags.                    */
+ * relations sharded by rows over the ranks.  The radix fan-out itself is the owner (round 3): every rank runs the
+ * FIRST radix pass of the join on its own shards -- stable histogram / scan / scatter on the top `digit_bits` key
+ * bits under the prefix all ranks' keys share (the window is agreed through one all-gather of key samples), exactly
+ * pass 1 of the reference's sort (radix_hash.h:313-345, top-bits routing radix_hash.h:369) -- and rank g owns a
+ * contiguous RANGE of those digits, chosen from the pooled sample so that the ranks balance.  The digit-major rows
+ * then travel in rounds of digit sub-ranges (grouped send/recv on the communicator's own stream; build side first);
+ * a round that has arrived is a complete key range of both relations and is joined at once by the remaining
+ * radix passes + build + probe, while later rounds are still on the links.  Nothing is partitioned twice.
+ * Fallbacks: a key sample whose digits cannot be balanced over the ranks (a few clusters of keys) selects the
+ * hash owner floor(mix64(key) * n_ranks / 2^64) with a separate owner split (round 2's path, even for any key
+ * set); HMJ_ORDERED uses key-range owners between splitters = quantiles of the pooled sample, so rank g's ordered
+ * rows precede rank g+1's and the concatenation in rank order is the reference's iteration order.
+ * HMJ_FIRST_WINS is global when rank r's build shard precedes rank r+1's in input order (rows are received
+ * source-major inside a round and every pass is stable).
+ * local_out: this rank's result (materialising flags: columns are device pointers owned by the ctx; count modes:
+ * the sums over the key ranges this rank owns).  global_out (may be NULL): counts and checksums over all ranks,
+ * columns NULL.  Collective: all ranks, same flags; an error on one rank (bad sizes, out of memory, a failed
+ * local join) makes EVERY rank return -- the failing one its own code, the others HMJ_E_PEER -- instead of
+ * leaving its peers blocked in the next collective.  One rank: the plain local join (nothing to exchange),
+ * unless hmj_comm_set_self_exchange asked for the whole path.                                                */
 int hmj_exchange_join_u64_device(hmj_ctx* ctx, const void* build_shard_dev, uint64_t n_build_shard,
                                  const void* probe_shard_dev, uint64_t n_probe_shard, uint32_t flags,
                                  hmj_result* local_out, hmj_result* global_out);
+/* One-rank communicators only (tests, rehearsals on a one-GPU box): on != 0 runs the whole exchange -- digit
+ * pre-pass, rounds through the transport (RCCL self send/recv), per-round joins -- where the default is the plain
+ * local join.                                                                                                */
+int hmj_comm_set_self_exchange(hmj_ctx* ctx, int on);
 /* The owner split on its own: rows grouped by owner rank, stably (owner-major; within an owner in input
  * order), offsets_dev[g] = first row of owner g (2^ceil(log2 n_ranks) + 1 uint64, device).  splitters: NULL =
  * hash owner; else n_ranks - 1 ascending keys (host memory) = key-range owner.  in/out must not overlap.   */
 int hmj_owner_split_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, int n_ranks,
                                const uint64_t* splitters, void* out_aos_dev, uint64_t* offsets_dev);
 typedef struct {
-  int n_ranks, owner_mode;            /* owner_mode: 1 = hash of the key, 2 = key ranges (splitters)          */
+  int n_ranks, owner_mode;            /* owner_mode: 1 = hash of the key, 2 = key ranges (splitters),          */
+                                      /* 3 = ranges of the first radix pass's digit, 0 = one rank, no exchange */
   uint32_t rounds_build, rounds_probe;
   uint64_t recv_build, recv_probe;    /* rows this rank owns                                                */
-  float ms_split;                     /* owner split of both shards + the read-back of the counts (host clock) */
+  float ms_split;                     /* digit pre-pass (or owner split) of both shards + the read-back of the */
+                                      /* counts (host clock)                                                 */
   float ms_exchange_build, ms_exchange_probe; /* on the communication stream                                */
-  float ms_local;                     /* from "build side complete" to the end of the local join (host clock) */
+  float ms_local;                     /* from "build side complete" to the end of the local join(s) (host clock) */
   float ms_total;
+  int32_t digit_bits, digit_low;      /* owner_mode 3: digit = (key >> digit_low) & (2^digit_bits - 1)         */
+  uint32_t n_subjoins;                /* local joins run (one per round of the digit path)                     */
+  uint32_t fallback;                  /* 1: the digit owner was rejected (sample not balanceable): hash owner  */
+  float sample_max_share;             /* owner_mode 3: largest sampled share of a rank x n_ranks (1 = even)    */
+  float ms_kernels;                   /* device time of this rank's own kernels in the step (pre-pass + local  */
+                                      /* joins; HIP events, needs hmj_set_profiling)                           */
+  float ms_exposed;                   /* ms_total - ms_kernels: what the exchange and its synchronisation added */
 } hmj_exchange_info;
 int hmj_last_exchange_info(hmj_ctx* ctx, hmj_exchange_info* out);
-/* The round plan, exported because it is pure host arithmetic (no GPU needed; every rank computes the same
- * from the same count matrix).  counts[src * n_ranks + dst] = rows rank src sends to rank dst.
+/* Digit-range owners and rounds, exported because they are pure host arithmetic (no GPU needed; every rank
+ * computes the same plan from the same pooled key sample).  sample_keys: the pooled sample (any order).
+ * digit = (key >> digit_low) & (2^digit_bits - 1): the top <= 8 bits under the prefix all sampled keys share.
+ * owner_first[g] .. owner_first[g+1]: the digits rank g owns (boundaries where the sample's cumulative count is
+ * closest to g / n_ranks); round_first[g][r] .. [r+1]: the digits of rank g that travel in round r.
+ * usable = 0: fewer than 2 digits per rank, or the fullest rank would get more than 1.3 x its share.          */
+#define HMJ_MAX_RANKS 16
+#define HMJ_MAX_ROUNDS 16
+typedef struct {
+  int32_t usable;
+  int32_t digit_bits, digit_low;
+  uint32_t n_rounds;
+  uint32_t owner_first[HMJ_MAX_RANKS + 1];
+  uint32_t round_first[HMJ_MAX_RANKS][HMJ_MAX_ROUNDS + 1];
+  float max_share;
+} hmj_digit_plan;
+int hmj_exchange_digit_plan(int n_ranks, const uint64_t* sample_keys, uint64_t n_sample, uint32_t n_rounds,
+                            hmj_digit_plan* out);
+/* One relation's messages under a digit plan.  counts[src * 2^digit_bits + d] = rows of digit d in rank src's
+ * shard.  For round r and peer g (index r * n_ranks + g): rows [send_off, +send_rows) of this rank's digit-major
+ * buffer go to g; rows [recv_off, +recv_rows) of its receive buffer are filled by g.  The receive buffer is
+ * round-major, inside a round source-major (sources in rank order = global input order): round r occupies rows
+ * [round_off[r], round_off[r+1]) and is a complete key range once every source's message has arrived.        */
+int hmj_exchange_digit_layout(int n_ranks, int rank, const hmj_digit_plan* plan, const uint64_t* counts,
+                              uint64_t* send_off, uint64_t* send_rows, uint64_t* recv_off, uint64_t* recv_rows,
+                              uint64_t* round_off);
+/* The round plan of the owner-split path (hash / key-range owners), exported because it is pure host arithmetic
+ * (no GPU needed; every rank computes the same from the same count matrix).  counts[src * n_ranks + dst] = rows rank src sends to rank dst.
  * hmj_exchange_rounds: rounds so that no message exceeds max_msg_rows.  hmj_exchange_layout: for round r and
  * peer g (index r * n_ranks + g) the rows [send_off, +send_rows) of this rank's owner-major split buffer that
  * go to g, and the rows [recv_off, +recv_rows) of its receive buffer that g's message fills.  layout 0 =

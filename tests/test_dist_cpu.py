@@ -5,7 +5,9 @@ What runs here is the part of the N>1 path that is host arithmetic and host plum
     libhmj_hip.so and used unchanged by hmj_exchange_join_u64_device (csrc/exchange.hip);
   * the callback transport (hashmergejoin_amd.dist.GroupTransport, the hmj_transport a host hands to
     hmj_comm_set_transport) moving real bytes between processes over gloo, round by round, on host pointers;
-  * the owner function's numpy mirror (dist.owner_of; the HIP owner_digit is checked against it on the GPU).
+  * the owner function's numpy mirror (dist.owner_of; the HIP owner_digit is checked against it on the GPU);
+  * the digit-range owner plan of round 3 -- hmj_exchange_digit_plan / hmj_exchange_digit_layout: the first radix
+    pass's digit is the owner, rounds are digit ranges, every arrived round is joined on its own.
 The HIP steps either side (owner split kernel, local join) cannot run without a GPU, so HERE the oracle stands
 in for them as the checker.  The same protocol with the real kernels: tests/test_dist_gpu.py."""
 import json
@@ -191,3 +193,200 @@ def test_owner_function_mirror():
             assert int(g) == (m * G) >> 64
     spl = np.array([10, 20, 20, 1 << 40], dtype=np.uint64)
     assert hdist.owner_of(np.array([0, 9, 10, 19, 20, 21, (1 << 40) - 1, 1 << 40], np.uint64), 5, spl).tolist() == [0, 0, 1, 1, 3, 3, 3, 4]
+
+
+DIGIT_WORKER = r"""
+import ctypes as C, json, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["HMJ_ROOT"])
+from hashmergejoin_amd import dist as hdist
+from oracle.pyoracle import Oracle
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+o = Oracle()
+nb, npb, miss = int(os.environ["NB"]), int(os.environ["NP"]), int(os.environ["MISS"])
+kind, n_rounds = os.environ["KIND"], int(os.environ["ROUNDS"])
+b0, b1 = rank * nb // world, (rank + 1) * nb // world
+p0, p1 = rank * npb // world, (rank + 1) * npb // world
+Bs = o.gen_build(b1 - b0, start=b0)
+Ps = o.gen_probe(p1 - p0, nb, start=p0, miss_mod=miss)
+if kind == "dense":      # dense integer keys: the window must sit under their shared prefix
+    Bs[:, 0] = np.arange(b0, b1, dtype=np.uint64)
+    Ps[:, 0] = (np.arange(p0, p1, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
+elif kind == "dup":      # duplicate build keys across shards: row i and row i + nb/2 share a key (first-wins order)
+    half = nb // 2
+    Bs[:, 0] = o.gen_build(nb)[(np.arange(b0, b1) % half), 0]
+    Ps = o.gen_probe(p1 - p0, half, start=p0, miss_mod=miss)
+tr = hdist.GroupTransport(None, device=False)
+U64P = C.POINTER(C.c_uint64)
+K = 256
+
+def sample(rel):  # numpy mirror of sample_keys_kernel: K evenly spaced keys
+    n = len(rel)
+    k = min(K, n)
+    return rel[(np.arange(k, dtype=np.uint64) * np.uint64(n) // np.uint64(max(k, 1))).astype(np.int64), 0] if k else np.zeros(0, np.uint64)
+
+mine = np.zeros(2 * K + 2, np.uint64)
+sb_, sp_ = sample(Bs), sample(Ps)
+mine[0], mine[1] = len(sb_), len(sp_)
+mine[2:2 + len(sb_)] = sb_
+mine[2 + K:2 + K + len(sp_)] = sp_
+allm = np.zeros((2 * K + 2) * world, np.uint64)
+assert tr.struct.allgather_u64(None, mine.ctypes.data_as(U64P), allm.ctypes.data_as(U64P), 2 * K + 2) == 0
+allm = allm.reshape(world, -1)
+pooled = np.concatenate([np.concatenate([allm[g, 2:2 + int(allm[g, 0])], allm[g, 2 + K:2 + K + int(allm[g, 1])]]) for g in range(world)])
+plan = hdist.digit_plan(pooled, world, n_rounds)
+info = {"usable": int(plan.usable), "bits": int(plan.digit_bits), "low": int(plan.digit_low), "max_share": float(plan.max_share)}
+if not plan.usable:
+    json.dump(info, open(os.path.join(os.environ["OUT"], "info%d.json" % rank), "w"))
+    dist.destroy_process_group()
+    sys.exit(0)
+D = 1 << plan.digit_bits
+
+def prepass(rel):  # stand-in for the HIP first radix pass: stable partition by digit
+    d = hdist.digit_of(rel[:, 0], plan)
+    order = np.argsort(d, kind="stable")
+    return np.ascontiguousarray(rel[order]), np.bincount(d, minlength=D).astype(np.uint64)
+
+def exchange(parted, cnt):
+    allc = np.zeros(D * world, np.uint64)
+    assert tr.struct.allgather_u64(None, cnt.ctypes.data_as(U64P), allc.ctypes.data_as(U64P), D) == 0
+    allc = allc.reshape(world, D)
+    lay = hdist.digit_layout(plan, allc, rank)
+    total = int(lay["round_off"][-1])
+    own = slice(plan.owner_first[rank], plan.owner_first[rank + 1])
+    assert total == int(allc[:, own].sum())
+    out = np.zeros((total, 2), np.uint64)
+    for r in range(plan.n_rounds):
+        sp = (C.c_void_p * world)(*[parted.ctypes.data + 16 * int(lay["send_off"][r, g]) for g in range(world)])
+        rp = (C.c_void_p * world)(*[out.ctypes.data + 16 * int(lay["recv_off"][r, g]) for g in range(world)])
+        sb = (C.c_uint64 * world)(*[16 * int(x) for x in lay["send_rows"][r]])
+        rb = (C.c_uint64 * world)(*[16 * int(x) for x in lay["recv_rows"][r]])
+        assert tr.struct.alltoallv(None, r, sp, sb, rp, rb, None) == 0
+    return out, lay
+
+pr, cr = prepass(Bs)
+ps, cs = prepass(Ps)
+recv_r, lay_r = exchange(pr, cr)
+recv_s, lay_s = exchange(ps, cs)
+acc = {"n_matches": 0, "sum_r": 0, "sum_s": 0, "xor_fold": 0, "mix_sum": 0}
+accf = dict(acc)
+M = (1 << 64) - 1
+rows_all = []
+for r in range(plan.n_rounds):  # every round is a complete range of digits of both relations: joined on its own
+    lo, hi = plan.round_first[rank][r], plan.round_first[rank][r + 1]
+    Rr = recv_r[int(lay_r["round_off"][r]):int(lay_r["round_off"][r + 1])]
+    Sr = recv_s[int(lay_s["round_off"][r]):int(lay_s["round_off"][r + 1])]
+    for rel in (Rr, Sr):
+        d = hdist.digit_of(rel[:, 0], plan)
+        assert bool(np.all((d >= lo) & (d < hi))), (r, lo, hi)
+    ck, rows = o.equijoin(Rr, Sr)                                  # stand-in for the local HIP (sub-)join
+    ckf, _ = o.equijoin(Rr, Sr, first_wins=True, cap=0)
+    for a, c in ((acc, ck), (accf, ckf)):
+        for k in ("n_matches", "sum_r", "sum_s", "mix_sum"):
+            a[k] = (a[k] + c[k]) & M
+        a["xor_fold"] ^= c["xor_fold"]
+    rows_all.append(rows)
+def reduce(a):
+    mine = np.array([a[k] for k in ("n_matches", "sum_r", "sum_s", "xor_fold", "mix_sum")], dtype=np.uint64)
+    allv = np.zeros(5 * world, np.uint64)
+    assert tr.struct.allgather_u64(None, mine.ctypes.data_as(U64P), allv.ctypes.data_as(U64P), 5) == 0
+    allv = allv.reshape(world, 5)
+    return {"n_matches": sum(int(x) for x in allv[:, 0]) & M, "sum_r": sum(int(x) for x in allv[:, 1]) & M,
+            "sum_s": sum(int(x) for x in allv[:, 2]) & M, "xor_fold": int(np.bitwise_xor.reduce(allv[:, 3])),
+            "mix_sum": sum(int(x) for x in allv[:, 4]) & M}
+info.update(glob=reduce(acc), glob_first=reduce(accf), recv=[len(recv_r), len(recv_s)])
+np.save(os.path.join(os.environ["OUT"], "rows%d.npy" % rank), np.concatenate(rows_all) if rows_all else np.zeros((0, 3), np.uint64))
+json.dump(info, open(os.path.join(os.environ["OUT"], "info%d.json" % rank), "w"))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,nb,npb,miss,kind,rounds", [
+    (2, 5000, 7000, 3, "uniform", 1), (4, 1 << 14, 1 << 14, 0, "uniform", 4), (3, 9000, 9001, 4, "uniform", 16),
+    (4, 20000, 15000, 0, "dense", 3), (2, 6000, 9000, 2, "dup", 5), (4, 1 << 13, 3000, 2, "dup", 2)])
+def test_digit_owner_exchange_over_gloo(oracle, tmp_path, world, nb, npb, miss, kind, rounds):
+    # Round 3's path: the first radix pass's digit is the owner (contiguous digit ranges chosen from the pooled key
+    # sample), rounds carry digit sub-ranges, and every arrived round is joined on its own.  Real bytes between real
+    # processes over gloo through the callback transport; the library's plan / layout arithmetic unchanged; the
+    # oracle stands in for the HIP pre-pass (stable partition by digit) and for the per-round joins.
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HMJ_ROOT=ROOT, NB=str(nb), NP=str(npb), MISS=str(miss), OUT=str(tmp_path), OMP_NUM_THREADS="1",
+                   KIND=kind, ROUNDS=str(rounds))
+        procs.append(subprocess.Popen([sys.executable, "-c", DIGIT_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    infos = [json.load(open(tmp_path / ("info%d.json" % r))) for r in range(world)]
+    assert all(i["usable"] == 1 for i in infos), infos
+    B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=miss)
+    if kind == "dense":
+        B[:, 0] = np.arange(nb, dtype=np.uint64)
+        P[:, 0] = (np.arange(npb, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
+        assert all(i["bits"] == 8 and i["low"] + 8 <= 16 for i in infos), infos  # the window sits under the shared zero bits
+    elif kind == "dup":
+        half = nb // 2
+        B[:, 0] = oracle.gen_build(nb)[np.arange(nb) % half, 0]
+        P = oracle.gen_probe(npb, half, miss_mod=miss)
+    ck, rows = oracle.equijoin(B, P)
+    ckf, _ = oracle.equijoin(B, P, first_wins=True, cap=0)
+    assert all(i["glob"] == ck for i in infos)
+    # first-wins is GLOBAL: inside a round the sources arrive in rank order and the pre-pass is stable
+    assert all(i["glob_first"] == ckf for i in infos)
+    assert sum(i["recv"][0] for i in infos) == nb and sum(i["recv"][1] for i in infos) == npb
+    for i in infos:  # digit ranges chosen from a 256-key sample per relation and rank still balance the ranks
+        assert 0.6 * nb / world <= i["recv"][0] <= 1.4 * nb / world, infos
+    # ranks own ascending digit ranges and rounds ascend inside a rank: the per-round results concatenate in key order
+    cat = np.concatenate([np.load(tmp_path / ("rows%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(cat, rows)
+
+
+def test_digit_plan_properties():
+    from hashmergejoin_amd import dist as hdist
+
+    rng = np.random.default_rng(11)
+    uni = rng.integers(0, 1 << 63, size=20000, dtype=np.uint64) * np.uint64(2)
+    for G in (1, 2, 3, 8, 16):
+        for R in (1, 4, 16):
+            p = hdist.digit_plan(uni, G, R)
+            assert p.usable == 1 and p.digit_bits == 8 and p.digit_low == 56 and p.n_rounds == R
+            of = [p.owner_first[g] for g in range(G + 1)]
+            assert of[0] == 0 and of[-1] == 256 and all(a < b for a, b in zip(of, of[1:]))
+            assert p.max_share <= 1.1
+            for g in range(G):
+                rf = [p.round_first[g][r] for r in range(R + 1)]
+                assert rf[0] == of[g] and rf[-1] == of[g + 1] and all(a <= b for a, b in zip(rf, rf[1:]))
+            # the layout of a random count matrix tiles both buffers and agrees between sender and receiver
+            cnt = rng.integers(0, 50, size=(G, 256)).astype(np.uint64)
+            lays = [hdist.digit_layout(p, cnt, r) for r in range(G)]
+            for r in range(G):
+                L = lays[r]
+                assert int(L["round_off"][-1]) == int(cnt[:, of[r]:of[r + 1]].sum())
+                assert int(L["send_rows"].sum()) == int(cnt[r].sum())
+                for g in range(G):
+                    assert np.array_equal(L["send_rows"][:, g], lays[g]["recv_rows"][:, r])
+                segs = sorted((int(o), int(n)) for o, n in zip(L["recv_off"].ravel(), L["recv_rows"].ravel()) if n)
+                pos = 0
+                for o, n in segs:
+                    assert o == pos
+                    pos += n
+                assert pos == int(L["round_off"][-1])
+    # dense integer keys: the digit window moves under the bits all keys share
+    p = hdist.digit_plan(np.arange(100000, dtype=np.uint64), 4, 2)
+    assert p.usable == 1 and p.digit_bits == 8 and p.digit_low == 17 - 8
+    # two far-apart clusters: no contiguous digit ranges can balance 4 ranks -> not usable (hash owner takes over)
+    two = np.concatenate([np.arange(5000, dtype=np.uint64), np.arange(5000, dtype=np.uint64) + np.uint64(1 << 62)])
+    p = hdist.digit_plan(two, 4, 1)
+    assert p.usable == 0 and p.max_share > 1.3
+    # too few distinct digits for the ranks
+    p = hdist.digit_plan(np.array([0, 1, 2, 3], dtype=np.uint64), 8, 1)
+    assert p.usable == 0
+    # all keys equal / no keys: a plan exists and covers all digits
+    for k in (np.zeros(100, np.uint64), np.zeros(0, np.uint64)):
+        p = hdist.digit_plan(k, 2, 2)
+        assert p.owner_first[0] == 0 and p.owner_first[2] == (1 << p.digit_bits)

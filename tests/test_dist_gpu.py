@@ -1,10 +1,11 @@
 """N>1 path with the real kernels, through the C ABI (hmj_exchange_join_u64_device, csrc/exchange.hip).
 
   * `world` processes share the one GPU of the box; the library's callback transport carries the exchange over
-    gloo (RCCL refuses two ranks on one device).  Owner split kernel, counts, round plan, receive layouts, prepared
-    build side, per-round pass A and the local join are the production code; only the byte transport differs.
+    gloo (RCCL refuses two ranks on one device).  The first radix pass as the owner (digit pre-pass, digit-range
+    plan, rounds of digit ranges, per-round joins), the hash / key-range owner split paths, counts, layouts and the
+    collective error handling are the production code; only the byte transport differs.
   * one rank with the RCCL transport (self send/recv inside ncclGroupStart/End), up to BASELINE configs[3]'s
-    per-rank shape: a 2^28-row shard in several rounds, slab path, prepared build side.
+    per-rank shape: a 2^28-row shard in 16 rounds.
   * two ranks over RCCL on two GPUs where the box has them (skipped on a one-GPU box).
 Checked against the CPU oracle, or at full size against the generator's closed forms."""
 import json
@@ -47,9 +48,13 @@ Bs = o.gen_build(b1 - b0, start=b0)
 if dup == 1:  # duplicate build keys across shards: global row i and i + nb/2 share a key
     Bs[:, 0] = o.gen_build(b1 - b0, start=b0 % (nb // 2))[:, 0] if b0 >= nb // 2 else Bs[:, 0]
 Ps = o.gen_probe(p1 - p0, nb // 2 if dup == 1 else nb, start=p0, miss_mod=miss)
-if dup == 2:  # dense integer keys: all top bits zero; the hash owner must spread them over the ranks
+if dup == 2:  # dense integer keys: all top bits zero; the digit window must sit under them
     Bs[:, 0] = np.arange(b0, b1, dtype=np.uint64)
     Ps[:, 0] = (np.arange(p0, p1, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
+if dup == 3:  # two far-apart clusters of keys (3/4 and 1/4 of the rows): no contiguous digit ranges balance the ranks -> hash owner
+    clus = lambda x: x | (((x & np.uint64(3)) == np.uint64(3)).astype(np.uint64) << np.uint64(62))
+    Bs[:, 0] = clus(np.arange(b0, b1, dtype=np.uint64))
+    Ps[:, 0] = clus((np.arange(p0, p1, dtype=np.uint64) * np.uint64(5)) % np.uint64(nb))
 to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy()).cuda()
 ex = H.Executor(dev)
 kind = hdist.init_comm(ex)
@@ -102,6 +107,10 @@ def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
     if dup == 2:
         B[:, 0] = np.arange(nb, dtype=np.uint64)
         P[:, 0] = (np.arange(npb, dtype=np.uint64) * np.uint64(7)) % np.uint64(nb + nb // 4)
+    if dup == 3:
+        clus = lambda x: x | (((x & np.uint64(3)) == np.uint64(3)).astype(np.uint64) << np.uint64(62))
+        B[:, 0] = clus(np.arange(nb, dtype=np.uint64))
+        P[:, 0] = clus((np.arange(npb, dtype=np.uint64) * np.uint64(5)) % np.uint64(nb))
     ck, rows = oracle.equijoin(B, P)
     ckf, _ = oracle.equijoin(B, P, first_wins=True, cap=0)
     for o in res:  # every rank reports the same global reduction
@@ -114,11 +123,20 @@ def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
     # ordered mode: rank g owns the g-th key range, so the per-rank ordered rows concatenate to the global order
     cat = np.concatenate([np.load(tmp_path / ("rows%d.npy" % r)) for r in range(world)])
     assert np.array_equal(cat, rows)
-    # ownership: every rank owns about 1/world of the rows -- for ANY keys, dense integers included
+    # ownership: every rank owns about 1/world of the rows -- for ANY keys, dense integers included.  Count modes:
+    # ranges of the first radix pass's digit (owner_mode 3), no separate owner split; keys in a few clusters fall
+    # back to the hash owner (1); ordered: key ranges between sample quantiles (2)
     for o in res:
         i = o["info"]["count"]
-        assert i["owner_mode"] == 1 and o["info"]["ordered"]["owner_mode"] == 2 and i["n_ranks"] == world
-        assert 0.8 * nb / world <= i["recv_build"] <= 1.2 * nb / world, i
+        assert o["info"]["ordered"]["owner_mode"] == 2 and i["n_ranks"] == world
+        if dup == 3:
+            assert i["owner_mode"] == 1 and i["fallback"] == 1 and i["sample_max_share"] > 1.3, i
+        else:
+            assert i["owner_mode"] == 3 and i["fallback"] == 0 and i["digit_bits"] == 8, i
+            assert i["n_subjoins"] >= 1 and i["rounds_build"] == i["rounds_probe"], i
+            for name in ("checksum", "first"):
+                assert o["info"][name]["owner_mode"] == 3
+        assert 0.75 * nb / world <= i["recv_build"] <= 1.25 * nb / world, i
         assert 0.7 * npb / world <= i["recv_probe"] <= 1.3 * npb / world, i
         if maxmsg:
             assert i["rounds_build"] > 1 and i["rounds_probe"] > 1, i
@@ -129,16 +147,72 @@ def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
 @pytest.mark.parametrize("world,nb,npb,miss,dup,maxmsg", [(2, 300000, 200000, 3, 0, 0), (4, 1 << 20, (1 << 20) + 777, 0, 0, 0),
                                                             (2, 1 << 21, 1 << 22, 5, 1, 1 << 20), (2, 9 << 20, (9 << 20) + 10, 0, 0, 1 << 24),
                                                             (2, 300000, 250000, 0, 2, 0), (3, 700000, 500000, 2, 0, 1 << 19),
-                                                            (2, 17 << 19, 36 << 20, 0, 0, 1 << 24)])
+                                                            (2, 300000, 270000, 0, 3, 0), (4, 1 << 20, 1 << 21, 3, 3, 1 << 20),
+                                                            (2, 34 << 19, 36 << 20, 0, 0, 0)])
 def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup, maxmsg):
     res = run_world(tmp_path, world, nb, npb, miss, dup, maxmsg)
     check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg)
-    if nb >= 17 << 19:  # each rank owns >= 4.4 M build rows: the slab path (threshold lowered to 2^22 for the tests): the build side was prepared during the probe exchange
+    if nb >= 34 << 19:  # two rounds; each round's join has >= 4.4 M build and 9.4 M probe rows: the slab path (threshold lowered to 2^22 for the tests)
         import hashmergejoin_amd as H
 
-        for o in res:  # (a probe-heavy shard of this size takes the probe-side plan of the full slab path)
-            pth = o["info"]["count"]["path"]
-            assert pth & (H.HMJ_PATH_SLAB | H.HMJ_PATH_SLAB_PROBE) and pth & H.HMJ_PATH_PREPARED, o["info"]["count"]
+        for o in res:
+            i = o["info"]["count"]
+            assert i["path"] & H.HMJ_PATH_SLAB and i["n_subjoins"] == i["rounds_probe"] == 2, i
+
+
+ERR_WORKER = r"""
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["HMJ_ROOT"])
+import hashmergejoin_amd as H
+from hashmergejoin_amd import dist as hdist
+from hashmergejoin_amd._lib import HmjError
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ex = H.Executor(0)
+hdist.init_comm(ex)
+n = 200000
+bd, pd = ex.gen_build(n, start=rank * n), ex.gen_probe(n, world * n, start=rank * n)
+codes = []
+for step in range(3):
+    bad = step == 1 and rank == 1
+    try:
+        if bad:  # this rank alone passes a shard beyond the 2^32-1 row limit: rejected before any memory is touched
+            import ctypes as C
+            loc, glob = H._lib.JoinResult(), H._lib.JoinResult()
+            rc = ex.L.hmj_exchange_join_u64_device(ex.h, C.c_void_p(bd.data_ptr()), (1 << 32) + 5, C.c_void_p(pd.data_ptr()), n, 0, C.byref(loc), C.byref(glob))
+            codes.append(rc)
+        else:
+            loc, glob = ex.exchange_join(bd, pd, 0)
+            assert int(glob.n_matches) == world * n
+            codes.append(0)
+    except HmjError as e:
+        codes.append(e.code)
+json.dump(codes, open(os.path.join(os.environ["OUT"], "codes%d.json" % rank), "w"))
+ex.close()
+dist.destroy_process_group()
+"""
+
+
+def test_an_error_on_one_rank_ends_the_collective_on_all_ranks(tmp_path):
+    # ADVICE r2: early returns decided by one rank alone left its peers blocked in the next collective.  Now a rank's
+    # error travels with its message of the next all-gather and every rank returns -- the failing one its own code,
+    # the others HMJ_E_PEER -- and the communicator stays usable (the step before and the step after succeed).
+    world, port = 3, free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HMJ_ROOT=ROOT,
+                   OUT=str(tmp_path), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", ERR_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    codes = [json.load(open(tmp_path / ("codes%d.json" % r))) for r in range(world)]
+    assert codes[1] == [0, -1, 0], codes           # HMJ_E_ARG on the rank that made the mistake
+    assert codes[0] == codes[2] == [0, -7, 0], codes  # HMJ_E_PEER on the others; nobody hangs
 
 
 def test_two_ranks_over_rccl(oracle, tmp_path):
@@ -178,8 +252,9 @@ def ex1():
 @pytest.mark.parametrize("log2n,maxmsg", [(22, 1 << 22), (26, 1 << 28), (28, 1 << 30)])
 def test_one_rank_rccl_exchange_at_shard_size(ex1, log2n, maxmsg):
     # BASELINE configs[3]'s per-rank shape (2^28-row shard at log2n = 28): the whole exchange path through RCCL
-    # -- multi-round build side, round-major probe side with pass A per arrived round, prepared build side, slab
-    # path -- checked by the generator's closed forms (every probe row matches one build row).
+    # (forced with hmj_comm_set_self_exchange: a one-rank job's default is the plain join) -- digit pre-pass, rounds
+    # of digit ranges as self send/recv, one join per arrived round -- checked by the generator's closed forms
+    # (every probe row matches one build row).
     import hashmergejoin_amd as H
 
     ex = ex1
@@ -194,9 +269,11 @@ def test_one_rank_rccl_exchange_at_shard_size(ex1, log2n, maxmsg):
         assert int(r.sum_r) == (n * (n - 1) // 2) & M64
         assert int(r.sum_s) == sum_xor_range(n, VAL_XOR)
     assert info["n_ranks"] == 1 and info["recv_build"] == n and info["recv_probe"] == n
+    assert info["owner_mode"] == 3 and info["digit_bits"] == 8 and info["digit_low"] == 56, info
     if log2n >= 26:
-        assert info["rounds_build"] >= 4 and info["rounds_probe"] >= 8, info
-        assert t["path"] & H.HMJ_PATH_SLAB and t["path"] & H.HMJ_PATH_PREPARED, t
+        assert info["rounds_build"] == info["rounds_probe"] == info["n_subjoins"] == 16, info
+        assert t["path"] & (H.HMJ_PATH_SLAB | H.HMJ_PATH_EXACT), t
+        assert info["ms_kernels"] > 0 and info["ms_exposed"] >= 0, info
     ck = ex.exchange_join(bd, pd, H.HMJ_CHECKSUM)[1].checks()
     plain = ex.join_device(bd, pd, H.HMJ_CHECKSUM).checks()
     assert ck == plain  # same multiset of result rows as the plain single-GPU join
