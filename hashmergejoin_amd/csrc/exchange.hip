@@ -108,6 +108,7 @@ struct hmj_comm {
   std::vector<u64> peak_rows;  // [n_ranks][4]
   u64 max_msg_bytes = 1ull << 30;       // RCCL 2.26 truncates a single message of 2 GiB or more
   u64 target_round_bytes = 128ull << 20;  // probe side: several rounds, so the local pass A starts on arrived rows
+  bool round_bytes_set = false;           // the host chose the round size itself (hmj_comm_set_message_bytes)
   hmj_exchange_info info;
 };
 
@@ -221,9 +222,17 @@ int transport_round(hmj_ctx* c, int round, const void* const* sp, const u64* sb,
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------
+// K keys of a relation: one from each of K equal strata, at a pseudo-random position inside the stratum (a regular
+// stride aliases with periodic key patterns: every 128th row of "every fourth key is in another cluster" never
+// sees that cluster)
 __global__ void sample_keys_kernel(const hmj::Tup* __restrict__ a, u64 n, u32 K, u64* __restrict__ out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < K) out[i] = a[(u64)i * n / K].key;
+  if (i < K) {
+    const u64 lo = (u64)i * n / K, hi = (u64)(i + 1) * n / K;
+    const u64 span = hi > lo ? hi - lo : 1;
+    u64 at = lo + hmj::mix64(0x9E3779B97F4A7C15ull * (i + 1)) % span;
+    out[i] = a[at < n ? at : n - 1].key;
+  }
 }
 
 // owner split of one relation: stable histogram / scan / scatter on owner_digit (radix.hip)
@@ -509,7 +518,10 @@ int hmj_comm_set_message_bytes(hmj_ctx* c, uint64_t max_message_bytes, uint64_t 
     if (max_message_bytes < 16 || max_message_bytes > (1ull << 30)) return fail(c, HMJ_E_ARG, "max_message_bytes must be in [16, 2^30]");
     c->comm->max_msg_bytes = max_message_bytes;
   }
-  if (probe_round_bytes) c->comm->target_round_bytes = probe_round_bytes < 16 ? 16 : probe_round_bytes;
+  if (probe_round_bytes) {
+    c->comm->target_round_bytes = probe_round_bytes < 16 ? 16 : probe_round_bytes;
+    c->comm->round_bytes_set = true;
+  }
   return HMJ_OK;
 }
 
@@ -1125,6 +1137,14 @@ extern "C" int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_
     for (int g = 0; g < G; g++) pair_rows = std::max<u64>(pair_rows, std::max(smp.np[g], smp.nb[g]) / (u64)G);
     const u64 per_round = std::max<u64>(1, m->target_round_bytes / 16);
     u64 nr64 = (flags & HMJ_MATERIALIZE) ? 1 : (pair_rows + per_round - 1) / per_round;
+    // a round's join should keep the efficient kernels busy: with the default round size, no more rounds than give
+    // every round about 2^25 probe rows per rank (the histogram-free slab passes start there; 2^24-row joins cost
+    // 60 % more per row)
+    if (!m->round_bytes_set) {
+      u64 total_np = 0;
+      for (int g = 0; g < G; g++) total_np += smp.np[g];
+      nr64 = std::min<u64>(nr64, std::max<u64>(1, (total_np / (u64)G) >> 25));
+    }
     nr64 = std::min<u64>(std::max<u64>(nr64, 1), HMJ_MAX_ROUNDS);
     hmj_digit_plan plan;
     if (hmj_exchange_digit_plan(G, smp.keys.data(), smp.keys.size(), (u32)nr64, &plan) != HMJ_OK) return fail(c, HMJ_E_ARG, "digit plan");
