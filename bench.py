@@ -125,7 +125,17 @@ def extra_runs(ex, H, torch):
         out["configs1_2p26_forced_10bit_plan"] = "%d passes, chunked LDS build (%d-row build partitions)" % (t["radix_passes"], n >> 10)
     finally:
         ex.set_radix_bits(None)
+    # what a caller of the reference ctor experiences (hashjoin_bench.cc:126-133): HOST-resident relations in, ordered
+    # rows back on the host (hmj_join_u64; pageable memory both ways).  PCIe-bound: 2 GiB up + 1.5 GiB down at 2^26.
+    Bh, Ph = R.cpu().numpy().view(np.uint64), S.cpu().numpy().view(np.uint64)
     del R, S
+    for name, fl in (("ordered", H.HMJ_ORDERED), ("count", 0)):
+        ms, r = timed(lambda: ex.join_host(Bh, Ph, fl), reps=3)
+        assert int(r.n_matches) == n
+        out["host_entry_2p26_%s_ms" % name] = ms
+    out["host_entry_pcie_floor_ms"] = "2 GiB up + 1.5 GiB down at the ~55 GB/s one hipMemcpy reaches here = 67 (ordered), 39 (count)"
+    ex.release_result()
+    del Bh, Ph
     n = 1 << 28
     R, S = ex.gen_build(n), ex.gen_probe(n, n)
     for name, fl in (("materialize", H.HMJ_MATERIALIZE), ("ordered", H.HMJ_ORDERED)):

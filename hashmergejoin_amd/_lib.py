@@ -16,6 +16,7 @@ HMJ_PATH_SLAB_PROBE = 0x400
 HMJ_PATH_SORTED_WRITE = 0x800
 HMJ_PATH_SORTED_FK = 0x1000
 HMJ_PATH_DENSE_BUILD = 0x2000
+HMJ_PATH_HOST_PIPELINE = 0x4000
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _U64P = C.POINTER(C.c_uint64)

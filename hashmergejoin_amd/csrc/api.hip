@@ -1346,6 +1346,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_UPLOAD")) c->staged_upload = std::strcmp(e, "staged") == 0;
+  if (const char* e = getenv("HMJ_HOST_PIPELINE")) c->host_pipeline = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SLAB_MIN_LOG2")) {
     const int l = atoi(e);
     if (l >= 16 && l <= 31) c->slab_min_rows = 1u << l;
@@ -1396,6 +1397,8 @@ void hmj_destroy(hmj_ctx* c) {
   for (auto& e : c->place_ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& st : c->up_streams) (void)hipStreamDestroy(st);
+  for (auto& e : c->copy_ev) (void)hipEventDestroy(e);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   for (auto& b : c->up_slots) free_host(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1595,6 +1598,15 @@ int hmj_join_u64_device(hmj_ctx* c, const void* build_aos_dev, uint64_t n_build,
   return rc;
 }
 
+// The host-resident entry point (what a caller of the reference ctor experiences, hashjoin_bench.cc:126-133) as a
+// pipeline:
+//   copy stream   :  H2D R | H2D S chunk 0 | chunk 1 | ...
+//   compute stream:        | partition R   | pass A of S per arrived chunk (slab path) ... | pass B, build + probe | D2H
+// The build side is partitioned while the probe side is still on the PCIe link (hmj_prepare_build; dropped if the
+// join plans differently), and the probe side's first pass follows its chunks -- the machinery the multi-GPU
+// exchange uses for rows arriving over xGMI.  The result columns go back in one copy per column: they exist only
+// once the last partition is probed, and the 2^26-row join's whole GPU part is 4 ms beside 38 ms up and 29 ms down,
+// so the PCIe link bounds the call.
 static int join_host_impl(hmj_ctx* c, const void* build_aos_host, uint64_t n_build,
                           const void* probe_aos_host, uint64_t n_probe, uint32_t flags,
                           hmj_result* out) {
@@ -1608,18 +1620,63 @@ static int join_host_impl(hmj_ctx* c, const void* build_aos_host, uint64_t n_bui
   if ((rc = ensure_dev(c, c->in_r, n_build * 16 + 16)) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->in_s, n_probe * 16 + 16)) != HMJ_OK) return rc;
   const auto t0 = std::chrono::steady_clock::now();
-  if ((rc = upload_host(c, c->in_r.p, build_aos_host, n_build * 16)) != HMJ_OK) return rc;
-  if ((rc = upload_host(c, c->in_s.p, probe_aos_host, n_probe * 16)) != HMJ_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  const float ms_h2d = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // small inputs, the staged multi-thread upload, or no pipeline wanted (HMJ_HOST_PIPELINE=0): the serial form
+  constexpr uint64_t kPipeMinRows = 1ull << 22;
+  const int kChunks = 8;
+  const bool pipeline = c->host_pipeline && !c->staged_upload && n_build >= kPipeMinRows && n_probe >= kPipeMinRows;
+  if (!pipeline) {
+    if ((rc = upload_host(c, c->in_r.p, build_aos_host, n_build * 16)) != HMJ_OK) return rc;
+    if ((rc = upload_host(c, c->in_s.p, probe_aos_host, n_probe * 16)) != HMJ_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const float ms_h2d = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    int st = span_begin(c, K_TOTAL, -1);
+    rc = join_device(c, c->in_r.p, n_build, c->in_s.p, n_probe, flags, out, true);
+    span_end(c, st);
+    if (c->profiling) {
+      (void)hipStreamSynchronize(c->stream);
+      spans_collect(c);
+      c->timing.ms_h2d = ms_h2d;  // wall clock: staging threads + PCIe
+      c->timing.ms_total += ms_h2d;
+    }
+    return rc;
+  }
+  if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  while ((int)c->copy_ev.size() < kChunks + 2) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->copy_ev.push_back(e);
+  }
+  // the staging buffers may still be read by earlier work on the compute stream
+  HIP_TRY(hipEventRecord(c->copy_ev[kChunks + 1], c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->copy_ev[kChunks + 1], 0));
+  HIP_TRY(hipMemcpyAsync(c->in_r.p, build_aos_host, n_build * 16, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(hipEventRecord(c->copy_ev[kChunks], c->copy_stream));
+  std::vector<u64> ends;
+  for (int i = 0; i < kChunks; i++) {
+    const u64 lo = n_probe * (u64)i / kChunks, hi = n_probe * (u64)(i + 1) / kChunks;
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(c->in_s.p) + lo * 16, static_cast<const char*>(probe_aos_host) + lo * 16,
+                           (hi - lo) * 16, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->copy_ev[i], c->copy_stream));
+    ends.push_back(hi);
+  }
   int st = span_begin(c, K_TOTAL, -1);
-  rc = join_device(c, c->in_r.p, n_build, c->in_s.p, n_probe, flags, out, true);
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_ev[kChunks], 0));  // R is on the device
+  c->sample_build_only = true;  // (the key sample must not read probe rows that are still on the link)
+  rc = prepare_build(c, c->in_r.p, n_build, n_probe);
+  if (rc == HMJ_OK) {
+    c->arrive_rows.assign(ends.begin(), ends.end());
+    c->arrive_ev.assign(c->copy_ev.begin(), c->copy_ev.begin() + kChunks);
+    rc = join_device(c, c->in_r.p, n_build, c->in_s.p, n_probe, flags, out, true);
+  }
+  c->sample_build_only = false;
+  c->arrive_rows.clear();
+  c->arrive_ev.clear();
   span_end(c, st);
+  if (rc != HMJ_OK) (void)hipStreamSynchronize(c->copy_stream);  // the caller's buffers are not read after return
   if (c->profiling) {
     (void)hipStreamSynchronize(c->stream);
     spans_collect(c);
-    c->timing.ms_h2d = ms_h2d;  // wall clock: staging threads + PCIe
-    c->timing.ms_total += ms_h2d;
+    c->timing.path |= HMJ_PATH_HOST_PIPELINE;
   }
   return rc;
 }

@@ -80,6 +80,9 @@ struct hmj_ctx {
   u64 probe_hint = 0;
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged
+  bool host_pipeline = true;   // HMJ_HOST_PIPELINE=0: host entry points upload, join and download one after the other
+  hipStream_t copy_stream = nullptr;  // host entry points: uploads run here, beside the partitioning on `stream`
+  std::vector<hipEvent_t> copy_ev;
   bool split_mode = true;      // HMJ_SPLIT=0: never split oversized probe partitions
   bool window_mode = true;     // HMJ_WINDOW=0: always partition right below the shared key prefix
   u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,

@@ -515,7 +515,12 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     else
       fp_load<THREADS>(t, ok ? S + sb_ : dummy, ok ? np_ : 1u, tid);
   };
+  const int tid_outer = tid;
   while (p < P) {
+    // write modes: keep the compiler from hoisting the per-row LDS / output addresses out of the partition loop
+    // (it then spills them and reloads each behind s_waitcnt vmcnt(0): see probe_write_sorted_kernel)
+    int tid = tid_outer;
+    if constexpr (OUT != 0) asm volatile("" : "+v"(tid));
     const u32 pn = __builtin_amdgcn_readfirstlane(p + gridDim.x);  // keep the offsets on the scalar path
     u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
     bool regular2 = false;
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int SW_LOGB = 12, SW_NB = 1 << SW_LOGB, SW_MAXBUCKET = 32;
 constexpr u64 LB_AGG = 1ull << 62, LB_PFX = 2ull << 62, LB_MASK = (1ull << 62) - 1;
-constexpr u32 LB_SPIN_LIMIT = 1u << 20;  // ~ a second of polling: a predecessor that never publishes is a bug
+constexpr u32 LB_SPIN_LIMIT = 1u << 22;  // ~ seconds of polling: a predecessor that never publishes is a bug
 
 template <int THREADS>
 struct SortedSmem {
@@ -797,22 +802,26 @@ struct SortedSmem {
   u64 red[8];
 };
 
-// FK = true: the probe keys may repeat (a foreign-key join: every build key is hit by f probe rows).  A build row
-// then counts its matches (the old count is the probe row's arrival number among the rows of its key), an exclusive
-// scan of the counts in sorted build order gives every key its run of output slots, the probe rows drop their
-// payloads there, rank themselves inside the run by payload (the result order is (key, rval, sval), and rval is
-// the same for the whole run) and move to their final slot; the copy-out walks the OUTPUT slots and finds key and
-// rval through the slot's build row.  Build rows: at most 4608 per partition (a foreign-key join has far fewer),
-// 2048 buckets -- that is what fits beside the per-slot arrays.
+// FK = true: the probe keys may repeat (a foreign-key join: every build key is hit by f probe rows).  The build rows
+// are then really sorted in LDS (bucket, then a rank among the handful of keys of a bucket: position = sorted rank),
+// a build row counts its matches (the old count is the probe row's arrival number among the rows of its key), an
+// exclusive scan of the counts in sorted order gives every key its run of output slots, and the probe rows drop
+// payload and sorted rank there.  The copy-out walks the OUTPUT slots -- consecutive lanes = consecutive slots, so
+// the lanes of a run sit side by side -- and every slot ranks its payload inside its run by reading the run once
+// (the result order is (key, rval, sval), and rval is the same for the whole run): lanes of one run read the SAME
+// LDS word in every step (a broadcast, no bank conflict), where round 2's row-order ranking made 64 lanes read 64
+// unrelated runs.  The row goes straight to its final place in global memory; a run's rows permute inside the
+// run's own 128-byte lines, so the stores coalesce as before.  Build rows: at most 4608 per partition (a foreign-key
+// join has far fewer), 2048 buckets -- that is what fits beside the per-slot arrays.
 constexpr int SWF_LOGB = 11, SWF_CAPB = 4608, SWF_MAXDUP = 1024;
 template <int THREADS>
 struct SortedFkSmem {
   static constexpr int CAP = THREADS * FP_ROWS, CAPB = SWF_CAPB, LOGB = SWF_LOGB;
-  u64 key[CAPB];   // build keys, grouped by bucket (buckets ascend; inside a bucket: order of arrival)
+  u64 key[CAPB];   // build keys in sorted order
   u64 val[CAPB];   // build payloads, same order
-  u64 sval[CAP];   // the probe payload of every OUTPUT slot
+  u64 sval[CAP];   // the probe payload of every OUTPUT slot (before that: the build keys in bucket / arrival order)
   u32 mcnt[CAPB];  // matches of the build row of sorted rank i, then the first output slot of its run
-  u16 owner[CAP];  // position in key[] / val[] of every output slot's build row
+  u16 srank[CAP];  // sorted rank of every output slot's build row
   u32 cnt[1 << SWF_LOGB];
   u16 bstart[(1 << SWF_LOGB) + 2];
   u32 scratch[THREADS / kWave + 1];
@@ -854,7 +863,12 @@ __device__ __forceinline__ u64 lookback_publish(u64* __restrict__ state, u32 p, 
   return excl;
 }
 
-template <int THREADS, bool SLAB, bool FK>
+// EXTRA: also accumulate the checksums and the sum of all probe payloads (HMJ_CHECKSUM / HMJ_SUM_PROBE); the
+// operator's own calls do not ask for them, and without them the kernel keeps six 64-bit accumulators and the
+// mixing arithmetic out of its registers (it ran at the 128-register limit of a 1024-thread workgroup with up to
+// 96 bytes of scratch per lane; the scratch reloads showed as 38 % more fetched bytes than the rows themselves,
+// profiles/r03a_ordered_unique_before_summary.txt).
+template <int THREADS, bool SLAB, bool FK, bool EXTRA>
 __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArgs a, u64* __restrict__ lookback, int key_low, bool chained) {
   typedef typename std::conditional<FK, SortedFkSmem<THREADS>, SortedSmem<THREADS>>::type Smem;
   constexpr u32 CAP = Smem::CAP, CAPB = Smem::CAPB, WORDS = CAP / 32, NB = 1u << Smem::LOGB, BPT = NB / THREADS;
@@ -876,7 +890,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
   bool pfx_bad = false, giveup = false, slab_bad = false, lb_timeout = false;
   u32 why = 0;  // why the kernel gave up (bits 7..11 of the error word, for HMJ_TRACE and the choice of the next form)
 
-  if (tid == 0) sm.tick[0] = (u32)atomicAdd(ticket, 1ull);
+  // Partitions are handed out by a ticket counter only when the output offsets are chained (a partition may wait
+  // only for smaller tickets, all running or done); otherwise a static stride does, and wave 0 does not have to wait
+  // at the top of every partition for a returning atomic that sits behind its own stores of the previous one.
+  if (tid == 0) sm.tick[0] = chained ? (u32)atomicAdd(ticket, 1ull) : blockIdx.x;
   if (tid < 8) sm.red[tid] = 0;
 #pragma unroll
   for (u32 q = 0; q < BPT; q++) sm.cnt[tid * BPT + q] = 0;
@@ -885,7 +902,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
   }
   if (tid == 0) sm.flag = 0;
   __syncthreads();
-  u32 p = sm.tick[0], par = 0;
+  // (wave-uniform, and known to be: everything indexed by p -- piece counts, item_base[p] -- then takes the scalar
+  //  path.  As a vector load, item_base[p] sat behind the prefetches of the next partition's rows in the vmcnt queue
+  //  and the copy-out waited for all of them.)
+  u32 p = (u32)__builtin_amdgcn_readfirstlane((int)sm.tick[0]), par = 0;
   u32 rb = 0, nb = 0, sb = 0, np = 0;
   u32 r1 = 0, r2 = 0, r3 = 0, s1 = 0, s2 = 0, s3 = 0, r1n = 0, r2n = 0, r3n = 0, s1n = 0, s2n = 0, s3n = 0;
   bool regular = false;
@@ -903,45 +923,60 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       sb = s_off[p]; np = s_end[p] - sb;
     }
     regular = nb && np && nb <= CAPB && np <= CAP;
-    if (SLAB)
+    // the first partition's rows, both sides (unconditional loads: see probe_count_fast_kernel)
+    if (SLAB) {
       fp_load_slab<THREADS>(br, regular ? R + (u64)p * SLAB_KB * a.r_cap : dummy, regular ? a.r_cap : 0u, regular ? r1 : 1u,
                             regular ? r2 : 1u, regular ? r3 : 1u, regular ? nb : 1u, tid);
-    else
-      fp_load<THREADS>(br, regular ? R + rb : dummy, regular ? nb : 1u, tid);
-  }
-  while (p < P) {
-    if (tid == 0) sm.tick[par ^ 1] = (u32)atomicAdd(ticket, 1ull);  // the partition after this one
-    // this partition's probe rows (unconditional loads: see probe_count_fast_kernel)
-    if (SLAB)
       fp_load_slab<THREADS>(pr, regular ? S + (u64)p * SLAB_KB * a.s_cap : dummy, regular ? a.s_cap : 0u, regular ? s1 : 1u,
                             regular ? s2 : 1u, regular ? s3 : 1u, regular ? np : 1u, tid);
-    else
+    } else {
+      fp_load<THREADS>(br, regular ? R + rb : dummy, regular ? nb : 1u, tid);
       fp_load<THREADS>(pr, regular ? S + sb : dummy, regular ? np : 1u, tid);
+    }
+  }
+  const int tid_outer = tid;
+  while (p < P) {
+    // The thread index as the loop body sees it is opaque to the compiler: otherwise it hoists every per-row LDS
+    // address (&sm.sval[k * THREADS + tid], &sm.perm[...], ...) out of the partition loop, runs out of registers,
+    // spills them, and reloads each one in the copy-out behind an s_waitcnt vmcnt(0) -- i.e. every output row waited
+    // for all stores and prefetches in flight (found in the ISA; profiles/r03a_ordered_unique_before_summary.txt:
+    // 71 % of the wave cycles parked, 38 % more bytes fetched than the rows themselves).
+    int tid = tid_outer;
+    asm volatile("" : "+v"(tid));
+    if (chained && tid == 0) sm.tick[par ^ 1] = (u32)atomicAdd(ticket, 1ull);  // the partition after this one
+    // this partition's first output slot, through the SCALAR cache (item_base was written by an earlier kernel).
+    // The compiler cannot prove it invariant and would use a vector load, and vector-memory operations complete in
+    // order: the copy-out's first use of it then waits (s_waitcnt vmcnt(0)) for the prefetches of the next
+    // partition's rows that were requested in between.
+    u64 ob = (u64)sb;
+    if (SLAB) {
+      const u64* ibp = a.item_base + p;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ob) : "s"(ibp) : "memory");
+    }
     // (no barrier here: the first LDS arrays this partition writes -- cnt, then bstart -- are not read by the
     //  previous partition's copy-out, and two barriers lie between here and the first write to sval / key / val)
-    u32 h[FP_ROWS], arr[FP_ROWS];
+    u32 ha[FP_ROWS];  // build row k: bucket | arrival number in the bucket << 12
     if (regular) {
       // count the build rows per bucket; the old count is the row's arrival number inside its bucket
 #pragma unroll
       for (int k = 0; k < FP_ROWS; k++) {
         const u32 i = k * THREADS + tid;
-        h[k] = 0;
-        arr[k] = 0;
+        ha[k] = 0;
         if (i < nb) {
           if (a.pfx_shift && (br[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-          h[k] = (u32)(br[k].key >> bsh) & (NB - 1);
-          arr[k] = atomicAdd(&sm.cnt[h[k]], 1u);
+          const u32 h = (u32)(br[k].key >> bsh) & (NB - 1);
+          ha[k] = h | (atomicAdd(&sm.cnt[h], 1u) << 12);
         }
       }
     }
     lds_barrier();  // bucket counts complete; the next ticket is visible
-    if constexpr (FK) {  // the match counts (the previous partition's copy-out does not read them)
+    if constexpr (FK) {  // the match counts (the previous partition's copy-out is over: one barrier since)
       for (u32 i = tid; i < CAPB; i += THREADS) sm.mcnt[i] = 0;
       if (tid == 0) sm.anydup = sm.hot = 0;
     } else {
       if ((u32)tid < WORDS) sm.mbits[par ^ 1][tid] = 0;  // the next partition's bitmap (the previous one's copy-out is over)
     }
-    const u32 pn = (u32)__builtin_amdgcn_readfirstlane((int)sm.tick[par ^ 1]);
+    const u32 pn = chained ? (u32)__builtin_amdgcn_readfirstlane((int)sm.tick[par ^ 1]) : p + gridDim.x;
     u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
     bool regular2 = false;
     if (pn < P) {
@@ -964,16 +999,23 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       else
         fp_load<THREADS>(br, regular2 ? R + rb2 : dummy, regular2 ? nb2 : 1u, tid);
     };
+    // The NEXT partition's probe rows are requested as soon as this partition's are consumed -- before the bitmap
+    // scan, the look-back and the copy-out, which do not touch them -- so they have the whole write phase and the
+    // next partition's count / scan / place phases to arrive (round 2 asked for them at the top of the iteration
+    // and waited for them three barriers later).
+    auto load_next_probe = [&]() {
+      if (SLAB)
+        fp_load_slab<THREADS>(pr, regular2 ? S + (u64)pn * SLAB_KB * a.s_cap : dummy, regular2 ? a.s_cap : 0u,
+                              regular2 ? s1n : 1u, regular2 ? s2n : 1u, regular2 ? s3n : 1u, regular2 ? np2 : 1u, tid);
+      else
+        fp_load<THREADS>(pr, regular2 ? S + sb2 : dummy, regular2 ? np2 : 1u, tid);
+    };
     u32 total = 0;       // result rows of this partition
     constexpr int WROUNDS = (int)((WORDS + kWave - 1) / kWave);
     u32 wpre[WROUNDS];   // bitmap form: matched rows before words lane, lane + 64, ...
 #pragma unroll
     for (int r = 0; r < WROUNDS; r++) wpre[r] = 0;
     bool sorted_ok = false;
-    // a probe row's match: sorted rank and position of the build row; FK: the probe row's arrival number in its key's run
-    u32 found[FP_ROWS], mpos[FP_ROWS], hits[FP_ROWS], slot[FP_ROWS];
-#pragma unroll
-    for (int k = 0; k < FP_ROWS; k++) found[k] = mpos[k] = hits[k] = slot[k] = 0;
     if (regular) {
       {  // exclusive scan of the bucket counts, BPT per thread (and the counts go back to zero for the next partition)
         u32 c[BPT], sum = 0, mx = 0;
@@ -995,84 +1037,169 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         if (tid == 0) sm.bstart[NB] = (u16)nb;
       }
       lds_barrier();
-      if (sm.flag == 0) {  // uniform
-        // key and payload go to their bucket, in order of arrival.  A row's sorted rank -- its bucket's start plus
-        // the number of smaller keys in the bucket -- is what the output order needs; the probe row that matches it
-        // scans the whole bucket anyway and counts them on the way, so the build rows are never moved again.
-#pragma unroll
-        for (int k = 0; k < FP_ROWS; k++) {
-          const u32 i = k * THREADS + tid;
-          if (i < nb) {
-            const u32 pos = (u32)sm.bstart[h[k]] + arr[k];
-            sm.key[pos] = br[k].key;
-            sm.val[pos] = br[k].val;
-          }
-        }
-      }
-      load_next_build();
-      lds_barrier();  // table complete
-      if (sm.flag == 0) {
-        // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap)
-        u32 cur[FP_ROWS], end[FP_ROWS], less[FP_ROWS];  // (cur: the bucket's start; less: smaller keys in the bucket)
-#pragma unroll
-        for (int k = 0; k < FP_ROWS; k++) {
-          const u32 j = k * THREADS + tid;
-          cur[k] = end[k] = less[k] = 0;
-          if (j < np) {
-            if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-            if (a.extra & 1u) acc_p += pr[k].val;
-            const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
-            cur[k] = sm.bstart[hh];
-            end[k] = sm.bstart[hh + 1];
-          }
-        }
-        for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
-          bool any = false;
-#pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) any |= cur[k] + step < end[k];
-          if (!__any(any)) break;
+      if constexpr (!FK) {
+        if (sm.flag == 0) {  // uniform
+          // key and payload go to their bucket, in order of arrival.  A row's sorted rank -- its bucket's start plus
+          // the number of smaller keys in the bucket -- is what the output order needs; the probe row that matches it
+          // scans the whole bucket anyway and counts them on the way, so the build rows are never moved again.
 #pragma unroll
           for (int k = 0; k < FP_ROWS; k++) {
-            if (cur[k] + step < end[k]) {
-              const u64 kk = sm.key[cur[k] + step];
-              less[k] += kk < pr[k].key ? 1u : 0u;
-              if (kk == pr[k].key) {
-                mpos[k] = cur[k] + step;
-                hits[k]++;
+            const u32 i = k * THREADS + tid;
+            if (i < nb) {
+              const u32 pos = (u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12);
+              sm.key[pos] = br[k].key;
+              sm.val[pos] = br[k].val;
+            }
+          }
+        }
+        load_next_build();
+        lds_barrier();  // table complete
+        if (sm.flag == 0) {
+          // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap).  Per row one packed
+          // word: smaller keys seen (bits 0-5), step of the match (6-11), matches (12-13)
+          u32 cur[FP_ROWS], len[FP_ROWS], st[FP_ROWS];
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            const u32 j = k * THREADS + tid;
+            cur[k] = len[k] = st[k] = 0;
+            if (j < np) {
+              if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+              if (EXTRA) acc_p += pr[k].val;
+              const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
+              cur[k] = sm.bstart[hh];
+              len[k] = (u32)sm.bstart[hh + 1] - cur[k];
+            }
+          }
+          for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; k++) any |= step < len[k];
+            if (!__any(any)) break;
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; k++) {
+              if (step < len[k]) {
+                const u64 kk = sm.key[cur[k] + step];
+                st[k] += kk < pr[k].key ? 1u : 0u;
+                if (kk == pr[k].key) st[k] = (st[k] & ~(63u << 6)) + (step << 6) + (1u << 12);
+              }
+            }
+          }
+          bool dup = false, dupb = false;
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            const u32 hits = st[k] >> 12;
+            if (hits) {
+              const u32 si = cur[k] + (st[k] & 63u), bit = 1u << (si & 31);  // the matched build row's sorted rank
+              const u32 mpos = cur[k] + ((st[k] >> 6) & 63u);
+              dupb |= hits > 1;                                            // two build rows with this key
+              dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
+              sm.sval[si] = pr[k].val;
+              sm.perm[si] = (u16)mpos;
+              acc_n++;
+              acc_s += pr[k].val;
+              if (EXTRA) {
+                const u64 m = tmix(pr[k].key, sm.val[mpos], pr[k].val);
+                acc_x ^= m;
+                acc_m += m;
+              }
+            }
+          }
+          if (dup) sm.flag = 2;
+          if (dupb) sm.flag = 3;
+        }
+        load_next_probe();
+        lds_barrier();
+        sorted_ok = sm.flag == 0;
+        if (!sorted_ok) giveup = true;
+        // matched rows before every bitmap word, and the partition's row count: every wave scans the 160 words for
+        // itself (lane l keeps the prefixes of words l, l + 64, l + 128), so nobody waits for anybody
+        u32 run = 0;
+#pragma unroll
+        for (int r = 0; r < WROUNDS; r++) {
+          const u32 w = (u32)r * kWave + lane;
+          const u32 c = (sorted_ok && w < WORDS) ? (u32)__popc(sm.mbits[par][w]) : 0u;
+          const u32 incl = wave_incl_scan_u32(c, lane);
+          wpre[r] = run + incl - c;
+          run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        total = run;
+      } else {
+        // ---- foreign-key form: the build rows are sorted for real (position = sorted rank)
+        u64* tmpkey = sm.sval;  // keys in bucket / arrival order (sval is free until the payloads are dropped)
+        if (sm.flag == 0) {     // uniform
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            const u32 i = k * THREADS + tid;
+            if (i < nb) tmpkey[(u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12)] = br[k].key;
+          }
+        }
+        lds_barrier();
+        if (sm.flag == 0) {
+          bool dupb = false;
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            const u32 i = k * THREADS + tid;
+            if (i < nb) {
+              const u32 h = ha[k] & (NB - 1), b0 = sm.bstart[h], b1 = sm.bstart[h + 1], mine = b0 + (ha[k] >> 12);
+              u32 less = 0;
+              for (u32 t = b0; t < b1; t++) {  // (a bucket holds a handful of keys: <= SW_MAXBUCKET, flagged above)
+                const u64 kk = tmpkey[t];
+                less += kk < br[k].key ? 1u : 0u;
+                dupb |= kk == br[k].key && t != mine;
+              }
+              sm.key[b0 + less] = br[k].key;
+              sm.val[b0 + less] = br[k].val;
+            }
+          }
+          if (dupb) sm.flag = 3;  // two build rows with one key: not this kernel's case
+        }
+        load_next_build();
+        lds_barrier();  // the sorted table is complete (and tmpkey is dead)
+        u32 found[FP_ROWS], slot[FP_ROWS];  // a probe row's match: sorted rank + 1 (0 = none); arrival number in its key's run
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) found[k] = slot[k] = 0;
+        if (sm.flag == 0) {
+          u32 cur[FP_ROWS], len[FP_ROWS];
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            const u32 j = k * THREADS + tid;
+            cur[k] = len[k] = 0;
+            if (j < np) {
+              if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+              if (EXTRA) acc_p += pr[k].val;
+              const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
+              cur[k] = sm.bstart[hh];
+              len[k] = (u32)sm.bstart[hh + 1] - cur[k];
+            }
+          }
+          for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; k++) any |= step < len[k];
+            if (!__any(any)) break;
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; k++) {
+              if (step < len[k] && sm.key[cur[k] + step] == pr[k].key) {
+                found[k] = cur[k] + step + 1;
+                len[k] = 0;  // (keys are unique in the table: done)
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < FP_ROWS; k++) {
+            if (found[k]) {
+              slot[k] = atomicAdd(&sm.mcnt[found[k] - 1], 1u);  // arrival number among the probe rows of the key
+              acc_n++;
+              acc_s += pr[k].val;
+              if (EXTRA) {
+                const u64 m = tmix(pr[k].key, sm.val[found[k] - 1], pr[k].val);
+                acc_x ^= m;
+                acc_m += m;
               }
             }
           }
         }
-        bool dup = false, dupb = false;
-#pragma unroll
-        for (int k = 0; k < FP_ROWS; k++) {
-          if (hits[k]) {
-            const u32 si = cur[k] + less[k], bit = 1u << (si & 31);    // the matched build row's sorted rank
-            found[k] = si;
-            dupb |= hits[k] > 1;                                      // two build rows with this key
-            if constexpr (FK) {
-              slot[k] = atomicAdd(&sm.mcnt[si], 1u);                  // arrival number among the probe rows of the key
-            } else {
-              dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
-              sm.sval[si] = pr[k].val;
-              sm.perm[si] = (u16)mpos[k];
-            }
-            const u64 vv = sm.val[mpos[k]];
-            acc_n++;
-            acc_r += vv;
-            acc_s += pr[k].val;
-            if (a.extra & 1u) {
-              const u64 m = tmix(pr[k].key, vv, pr[k].val);
-              acc_x ^= m;
-              acc_m += m;
-            }
-          }
-        }
-        if (dup) sm.flag = 2;
-        if (dupb) sm.flag = 3;
-      }
-      lds_barrier();
-      if constexpr (FK) {
+        lds_barrier();
         if (sm.flag == 0) {  // uniform
           // every build row's run of output slots: exclusive scan of the match counts in sorted build order
           u32 c[FP_ROWS], sum = 0, mx = 0;
@@ -1094,78 +1221,30 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           }
           lds_barrier();
         }
-        if (sm.flag == 0 && sm.hot == 0) {
-          // payloads to their key's run, in arrival order
+        sorted_ok = sm.flag == 0 && sm.hot == 0;
+        if (sorted_ok) {
+          // payload and sorted rank to the key's run, in arrival order
 #pragma unroll
           for (int k = 0; k < FP_ROWS; k++) {
-            if (hits[k]) {
-              const u32 o = sm.mcnt[found[k]] + slot[k];
+            if (found[k]) {
+              const u32 o = sm.mcnt[found[k] - 1] + slot[k];
               sm.sval[o] = pr[k].val;
-              sm.owner[o] = (u16)mpos[k];
+              sm.srank[o] = (u16)(found[k] - 1);
             }
           }
-          if (sm.anydup) {  // uniform: order every run by payload
-            lds_barrier();
-            // (row after row: walking the five runs of a thread in lockstep measured 15 % slower, eight reads of
-            //  a run in flight at once 4 % slower; the step is linear in the run length per row)
-            u32 rnk[FP_ROWS];
-#pragma unroll
-            for (int k = 0; k < FP_ROWS; k++) {
-              rnk[k] = 0xFFFFFFFFu;
-              if (hits[k]) {
-                const u32 si = found[k], base = sm.mcnt[si];
-                const u32 c = (si + 1 < CAPB ? sm.mcnt[si + 1] : total) - base;
-                if (c > 1) {
-                  u32 r = 0, e = 0;  // smaller payloads; equal ones (the row itself is one of them)
-                  for (u32 j = 0; j < c; j++) {
-                    const u64 ov = sm.sval[base + j];
-                    r += ov < pr[k].val ? 1u : 0u;
-                    e += ov == pr[k].val ? 1u : 0u;
-                  }
-                  if (e > 1) {  // equal payloads inside the run (rare): they line up by arrival
-                    e = 0;
-                    for (u32 j = 0; j < slot[k]; j++) e += sm.sval[base + j] == pr[k].val ? 1u : 0u;
-                    r += e;
-                  }
-                  rnk[k] = base + r;
-                }
-              }
-            }
-            lds_barrier();
-#pragma unroll
-            for (int k = 0; k < FP_ROWS; k++)
-              if (rnk[k] != 0xFFFFFFFFu) sm.sval[rnk[k]] = pr[k].val;
-          }
-        }
-        sorted_ok = sm.flag == 0 && sm.hot == 0;
-        if (!sorted_ok) {
+        } else {
           giveup = true;
           if (sm.flag == 0) why |= 2048u;
           total = 0;
         }
-      }
-      if constexpr (!FK) {
-        sorted_ok = sm.flag == 0;
-        if (!sorted_ok) giveup = true;
-        // matched rows before every bitmap word, and the partition's row count: every wave scans the 160 words for
-        // itself (lane l keeps the prefixes of words l, l + 64, l + 128), so nobody waits for anybody
-        u32 run = 0;
-#pragma unroll
-        for (int r = 0; r < WROUNDS; r++) {
-          const u32 w = (u32)r * kWave + lane;
-          const u32 c = (sorted_ok && w < WORDS) ? (u32)__popc(sm.mbits[par][w]) : 0u;
-          const u32 incl = wave_incl_scan_u32(c, lane);
-          wpre[r] = run + incl - c;
-          run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        total = run;
+        load_next_probe();
       }
     } else {
       if (nb && np) {  // does not fit the pipeline
         giveup = true;
         why |= 512u;
       }
-      if ((a.extra & 1u) && !nb) {  // probe rows without a build partition still count in sum_probe_all
+      if (EXTRA && !nb) {  // probe rows without a build partition still count in sum_probe_all
         if (SLAB) {
           const Tup* base = S + (u64)p * SLAB_KB * a.s_cap;
           for (u32 j = tid; j < np; j += THREADS) {
@@ -1178,12 +1257,12 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
       }
       load_next_build();
+      load_next_probe();
     }
     // every partition publishes its count (zero if it has no rows or gave up): its successors wait for it
     // chained: the rows of all partitions before this one (wave 0 finds out, the others wait); slots: the
     // partition's own probe-row slots (the result is then dense only if every probe row matched -- the caller
     // checks and closes the gaps otherwise)
-    u64 ob = SLAB ? a.item_base[p] : (u64)sb;
     if (tid == 0) a.part_count[p] = total;
     if (chained) {
       if (wv == 0) {
@@ -1193,38 +1272,95 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       lds_barrier();
       ob = sm.obase;
     } else if (FK) {
-      lds_barrier();  // the payloads and owners of all output slots are in place
+      lds_barrier();  // the payloads and ranks of all output slots are in place
     }
     if (FK && sorted_ok) {
       if constexpr (FK) {
+        // copy-out in SLOT order: lane <-> output slot, so the lanes of a run are neighbours and read the run's
+        // payloads as broadcasts.  rank = smaller payloads in the run + equal ones in earlier slots.
+        const bool rank_runs = sm.anydup != 0;  // uniform
+        // (all LDS work of the five slots first, then the stores back to back from registers of their own: see the
+        //  bitmap form below)
+        u32 rel[FP_ROWS];
+        u64 ok[FP_ROWS], orv[FP_ROWS], osv[FP_ROWS];
 #pragma unroll
         for (int k = 0; k < FP_ROWS; k++) {
           const u32 j = k * THREADS + tid;
-          if (j < total) {
-            const u32 si = sm.owner[j];
-            a.out_key[ob + j] = sm.key[si];
-            a.out_rval[ob + j] = sm.val[si];
-            a.out_sval[ob + j] = sm.sval[j];
+          const bool live = j < total;
+          u32 si = 0, base = 0, c = 0;
+          u64 v = 0;
+          if (live) {
+            si = sm.srank[j];
+            base = sm.mcnt[si];
+            c = (si + 1 < CAPB ? sm.mcnt[si + 1] : total) - base;
+            v = sm.sval[j];
+          }
+          u32 r = j - base;  // (runs of one row, or no repeating key in the partition: the slot is final)
+          if (rank_runs) {
+            r = 0;
+            const u32 last = c ? c - 1 : 0;
+            for (u32 t = 0; __any(t < c); t += 4) {  // four independent reads per step (clamped into the run)
+              u64 o[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) o[u] = sm.sval[base + (t + u < last ? t + u : last)];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const u32 at = t + u;
+                if (at < c) r += (o[u] < v || (o[u] == v && base + at < j)) ? 1u : 0u;
+              }
+            }
+          }
+          rel[k] = live ? base + r : 0xFFFFFFFFu;
+          ok[k] = live ? sm.key[si] : 0;
+          orv[k] = live ? sm.val[si] : 0;
+          osv[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; k++) {
+          if (rel[k] != 0xFFFFFFFFu) {
+            const u64 d = ob + rel[k];
+            a.out_key[d] = ok[k];
+            a.out_rval[d] = orv[k];
+            a.out_sval[d] = osv[k];
+            acc_r += orv[k];
           }
         }
       }
     } else if (sorted_ok) {
       if constexpr (!FK) {
       static_assert(THREADS == 1024, "word of slot k: 32 k + tid / 32");
+      // all LDS reads of the five rows first, then the fifteen stores back to back, every row in registers of its
+      // own: with the rows interleaved the compiler reused one row's store-data registers for the next row's LDS
+      // reads and put an s_waitcnt vmcnt(1) between them -- each row then waited for the previous row's stores
+      // AND for the prefetches of the next partition that are in flight (vector-memory operations retire in order)
+      u32 rel[FP_ROWS];  // output row relative to ob, or ~0
+      u64 ok[FP_ROWS], orv[FP_ROWS], osv[FP_ROWS];
 #pragma unroll
       for (int k = 0; k < FP_ROWS; k++) {
         const u32 si = k * THREADS + tid;
         // word si / 32 = 32 k + tid / 32: scan round k / 2, lane 32 (k & 1) + tid / 32 of this wave's registers
         const u32 before = (u32)__shfl((int)wpre[k >> 1], (int)((k & 1) * 32 + ((u32)tid >> 5) % 32u), kWave);
+        rel[k] = 0xFFFFFFFFu;
+        ok[k] = orv[k] = osv[k] = 0;
         if (si < nb) {
           const u32 w = sm.mbits[par][si >> 5], b = si & 31;
           if ((w >> b) & 1u) {
-            const u64 d = ob + before + (u32)__popc(w & ((1u << b) - 1u));
+            rel[k] = before + (u32)__popc(w & ((1u << b) - 1u));
             const u32 m = sm.perm[si];
-            a.out_key[d] = sm.key[m];
-            a.out_rval[d] = sm.val[m];
-            a.out_sval[d] = sm.sval[si];
+            ok[k] = sm.key[m];
+            orv[k] = sm.val[m];
+            osv[k] = sm.sval[si];
           }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < FP_ROWS; k++) {
+        if (rel[k] != 0xFFFFFFFFu) {
+          const u64 d = ob + rel[k];
+          a.out_key[d] = ok[k];
+          a.out_rval[d] = orv[k];
+          a.out_sval[d] = osv[k];
+          acc_r += orv[k];  // (summed here, where the payload is read anyway: one random LDS read less in the probe walk)
         }
       }
       }
@@ -1748,14 +1884,19 @@ hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, h
 }
 
 // ordered unique-key write in one pass (probe_write_sorted_kernel); lookback: P + 1 words, zeroed by the caller
-template <bool SLAB, bool FK>
+template <bool SLAB, bool FK, bool EXTRA>
 static hipError_t launch_sorted_t(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
   typedef typename std::conditional<FK, SortedFkSmem<1024>, SortedSmem<1024>>::type Smem;
   static_assert(sizeof(Smem) <= 160 * 1024, "one workgroup's LDS");
   static SmemAttrOnce attr_once;
-  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, SLAB, FK>), sizeof(Smem)); e != hipSuccess) return e;
-  hipLaunchKernelGGL((probe_write_sorted_kernel<1024, SLAB, FK>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, key_low, chained);
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, SLAB, FK, EXTRA>), sizeof(Smem)); e != hipSuccess) return e;
+  hipLaunchKernelGGL((probe_write_sorted_kernel<1024, SLAB, FK, EXTRA>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, key_low, chained);
   return hipGetLastError();
+}
+template <bool SLAB, bool FK>
+static hipError_t launch_sorted_x(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
+  return (a.extra & 1u) ? launch_sorted_t<SLAB, FK, true>(a, lookback, chained, key_low, grid, st)
+                        : launch_sorted_t<SLAB, FK, false>(a, lookback, chained, key_low, grid, st);
 }
 // fk: the probe keys may repeat (SortedFkSmem); key_low: the partition id's lowest key bit
 hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, u64* lookback, bool chained, int key_low,
@@ -1765,10 +1906,10 @@ hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, u64
   int grid = num_cus;  // one workgroup per CU fits (LDS); partitions are handed out by ticket
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
-  if (slab) return fk ? launch_sorted_t<true, true>(a, lookback, chained, key_low, grid, st)
-                      : launch_sorted_t<true, false>(a, lookback, chained, key_low, grid, st);
-  return fk ? launch_sorted_t<false, true>(a, lookback, chained, key_low, grid, st)
-            : launch_sorted_t<false, false>(a, lookback, chained, key_low, grid, st);
+  if (slab) return fk ? launch_sorted_x<true, true>(a, lookback, chained, key_low, grid, st)
+                      : launch_sorted_x<true, false>(a, lookback, chained, key_low, grid, st);
+  return fk ? launch_sorted_x<false, true>(a, lookback, chained, key_low, grid, st)
+            : launch_sorted_x<false, false>(a, lookback, chained, key_low, grid, st);
 }
 
 // np of every slab partition (sum of its 4 piece counts) as u64, for the exclusive scan that gives

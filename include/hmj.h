@@ -115,6 +115,7 @@ typedef struct {
 #define HMJ_PATH_SORTED_WRITE 0x800u   /* ordered join probed, sorted and written in one pass             */
 #define HMJ_PATH_SORTED_FK 0x1000u     /* ... in its foreign-key form (probe keys repeat)                 */
 #define HMJ_PATH_DENSE_BUILD 0x2000u   /* build keys cover part of the key range: plan sized by their density */
+#define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* Replaces: nothing in the reference (no device); one ctx per GPU. device_id < 0 = current.     */
@@ -181,8 +182,8 @@ int hmj_join_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_buil
                         hmj_result* out);
 /* Partition the build side ahead of the join (e.g. while the probe side is still arriving over
  * xGMI).  One-shot: the NEXT hmj_join_u64_device on this ctx whose build pointer, row count and plan
- * match, and whose flags are plain count mode (flags == 0), skips re-partitioning R; any other call
- * discards the prepared state.  The caller promises the build rows do not change in between.
+ * match (count modes and materialising joins of relations of similar size plan alike; a join that plans
+ * differently simply partitions R again) skips re-partitioning R; any other call discards the prepared state.  The caller promises the build rows do not change in between.
  * n_probe_hint: the probe size the join will have (it selects the partitioning path).
  * Corresponds to the first radix_non_inplace_par call of the reference ctor (hashjoin.h:65).       */
 int hmj_prepare_build_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_build,
