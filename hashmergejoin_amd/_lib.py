@@ -17,6 +17,8 @@ HMJ_PATH_SORTED_WRITE = 0x800
 HMJ_PATH_SORTED_FK = 0x1000
 HMJ_PATH_DENSE_BUILD = 0x2000
 HMJ_PATH_HOST_PIPELINE = 0x4000
+HMJ_PATH_SORTED_FK_HALF = 0x8000
+HMJ_PATH_LOOKBACK_TIMEOUT = 0x10000
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _U64P = C.POINTER(C.c_uint64)

@@ -571,13 +571,22 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   // match counts and a rank by payload inside every key's run).  The context remembers which one the last join
   // needed, and asks the cheaper one again every 64 ordered joins.
   if (ordered && c->sorted_fk && ++c->sorted_fk_age >= 64) c->sorted_fk = false;
+  // The foreign-key form has a small shape (512 threads, 3072 probe / 2048 build rows per partition, two workgroups
+  // per CU) for the partitions the planner makes for fan-out >= 6: about 2048 probe rows + 5 sigma, sigma =
+  // sqrt(fan-out x mean).  A partition beyond it makes the kernel give up ("does not fit"): the big shape then runs.
+  bool no_half = !c->sorted_half;
   for (int form = c->sorted_fk ? 1 : 0; form < 2 && ordered && c->sorted_mode && c->sorted_cooldown == 0 && low >= 12;
        form++) {
     const bool fk = form == 1;
+    bool half = false;
+    if (fk && !no_half && nb > 0 && P > 0) {
+      const double avg_np = (double)np / (double)P, avg_nb = (double)nb / (double)P, f = (double)np / (double)nb;
+      half = f >= 2.0 && avg_np + 5.0 * __builtin_sqrt(f * avg_np) <= 3072.0 && avg_nb + 6.0 * __builtin_sqrt(avg_nb) + 8.0 <= 2048.0;
+    }
     if ((rc = ensure_dev(c, c->lookback, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->lookback.p, 0, ((size_t)P + 1) * 8, c->stream));
     int sp = span_begin(c, K_PROBE_WRITE, -1);
-    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
+    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, half, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
     span_end(c, sp);
     HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -594,7 +603,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
       out->mix_sum = h[hmj::ACC_MIX];
       out->sum_probe_all = h[hmj::ACC_SUM_P];
       c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
-      c->timing.path |= HMJ_PATH_UNIQ_WRITE | HMJ_PATH_SORTED_WRITE | (fk ? HMJ_PATH_SORTED_FK : 0u);
+      c->timing.path |= HMJ_PATH_UNIQ_WRITE | HMJ_PATH_SORTED_WRITE | (fk ? HMJ_PATH_SORTED_FK : 0u) | (half ? HMJ_PATH_SORTED_FK_HALF : 0u);
       if (out->n_matches == 0) return HMJ_OK;
       const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
       // the next ordered join: chained output offsets if this one had unmatched probe rows (dense without an
@@ -615,18 +624,27 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     // clustered keys, a hot key, an oversized partition) -> the two-step form, and do not ask again for a while
     const u64 why = h[hmj::ACC_ERR];
     const bool try_fk = !fk && (why & 256) && !(why & (128 | 512 | 1024 | 2048));
+    const bool try_big = fk && half && (why & 512) && !(why & (128 | 1024 | 2048));
     if (try_fk) {
       c->sorted_fk = true;
       c->sorted_fk_age = 0;
+    } else if (try_big) {
+      no_half = true;  // same form again, one workgroup per CU with the full capacities
+      form--;
     } else {
       c->sorted_cooldown = 64;
       form = 2;
+    }
+    if (why & 1024) {  // never expected: say so whether or not tracing is on, and leave a mark the tests can see
+      c->timing.path |= HMJ_PATH_LOOKBACK_TIMEOUT;
+      std::fprintf(stderr, "[hmj] one-pass ordered write: a chained partition waited beyond the spin limit for its predecessor; "
+                           "the join falls back to the write + order epilogue (result unaffected)\n");
     }
     if (c->trace)
       std::fprintf(stderr, "[hmj]   one-pass ordered write%s gave up (%s%s%s%s%s) -> %s\n", fk ? " (foreign-key form)" : "",
                    (why & 128) ? "a bucket too long " : "", (why & 256) ? "repeating probe keys " : "",
                    (why & 512) ? "a partition does not fit " : "", (why & 1024) ? "look-back timeout " : "",
-                   (why & 2048) ? "duplicate build keys or a hot key" : "", try_fk ? "foreign-key form" : "write + order epilogue");
+                   (why & 2048) ? "duplicate build keys or a hot key" : "", try_fk ? "foreign-key form" : try_big ? "foreign-key form, big shape" : "write + order epilogue");
     std::vector<Span> keep;
     for (const Span& s2 : c->spans)
       if (s2.kind != K_PROBE_WRITE) keep.push_back(s2);
@@ -1343,6 +1361,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
     c->sorted_chained = atoi(e) == 2;
     c->sorted_chained_forced = atoi(e) == 2 || atoi(e) == 3;  // 3: never chained
   }
+  if (const char* e = getenv("HMJ_SORTED_HALF")) c->sorted_half = atoi(e) != 0;
   if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_UPLOAD")) c->staged_upload = std::strcmp(e, "staged") == 0;

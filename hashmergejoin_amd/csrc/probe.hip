@@ -363,12 +363,12 @@ __device__ __forceinline__ u32 fast_hash(u64 k) {
   return x >> (32 - LOG_NB);
 }
 
-template <int THREADS>
-__device__ __forceinline__ void fp_load(Tup (&t)[FP_ROWS], const Tup* __restrict__ base, u32 n,
+template <int THREADS, int ROWS = FP_ROWS>
+__device__ __forceinline__ void fp_load(Tup (&t)[ROWS], const Tup* __restrict__ base, u32 n,
                                         int tid) {
   // unpredicated loads (index clamped into the partition) so all five issue back to back
 #pragma unroll
-  for (int k = 0; k < FP_ROWS; k++) {
+  for (int k = 0; k < ROWS; k++) {
     u32 i = k * THREADS + tid;
     t[k] = base[i < n ? i : n - 1];
   }
@@ -379,11 +379,11 @@ __device__ __forceinline__ void fp_load(Tup (&t)[FP_ROWS], const Tup* __restrict
 // Slab layout loader: the partition is 4 pieces of up to `cap` rows; p1..p3 = prefix sums of the
 // first three piece counts (wave-uniform).
 static_assert(SLAB_KB == 4, "fp_load_slab / fp_load_pieces / slab_np_kernel unroll exactly four pieces per partition");
-template <int THREADS>
-__device__ __forceinline__ void fp_load_slab(Tup (&t)[FP_ROWS], const Tup* __restrict__ base, u32 cap,
+template <int THREADS, int ROWS = FP_ROWS>
+__device__ __forceinline__ void fp_load_slab(Tup (&t)[ROWS], const Tup* __restrict__ base, u32 cap,
                                              u32 p1, u32 p2, u32 p3, u32 n, int tid) {
 #pragma unroll
-  for (int k = 0; k < FP_ROWS; k++) {
+  for (int k = 0; k < ROWS; k++) {
     u32 i = k * THREADS + tid;
     i = i < n ? i : n - 1;
     const u32 j = (i >= p1) + (i >= p2) + (i >= p3);
@@ -814,16 +814,22 @@ struct SortedSmem {
 // run's own 128-byte lines, so the stores coalesce as before.  Build rows: at most 4608 per partition (a foreign-key
 // join has far fewer), 2048 buckets -- that is what fits beside the per-slot arrays.
 constexpr int SWF_LOGB = 11, SWF_CAPB = 4608, SWF_MAXDUP = 1024;
-template <int THREADS>
+// Two shapes: <1024 threads, 5 rows> -- 5120 probe rows, 4608 build rows, 2048 buckets, 152 KB: one workgroup per CU;
+// <512 threads, 6 rows> -- 3072 probe rows, 2048 build rows, 1024 buckets, 76 KB: TWO workgroups per CU, for the
+// partitions of a join with fan-out >= 6 (the planner sizes those for about 2048 probe rows: half of the big
+// shape's thread slots would idle, and one workgroup per CU leaves the memory pipeline empty during every one of
+// its barrier-separated phases -- with two, one computes while the other loads and stores).
+constexpr int SWF_HALF_THREADS = 512, SWF_HALF_ROWS = 6, SWF_HALF_CAPB = 2048, SWF_HALF_LOGB = 10;
+template <int THREADS, int ROWS = FP_ROWS, int CAPB_ = SWF_CAPB, int LOGB_ = SWF_LOGB>
 struct SortedFkSmem {
-  static constexpr int CAP = THREADS * FP_ROWS, CAPB = SWF_CAPB, LOGB = SWF_LOGB;
+  static constexpr int CAP = THREADS * ROWS, CAPB = CAPB_, LOGB = LOGB_;
   u64 key[CAPB];   // build keys in sorted order
   u64 val[CAPB];   // build payloads, same order
   u64 sval[CAP];   // the probe payload of every OUTPUT slot (before that: the build keys in bucket / arrival order)
   u32 mcnt[CAPB];  // matches of the build row of sorted rank i, then the first output slot of its run
   u16 srank[CAP];  // sorted rank of every output slot's build row
-  u32 cnt[1 << SWF_LOGB];
-  u16 bstart[(1 << SWF_LOGB) + 2];
+  u32 cnt[1 << LOGB_];
+  u16 bstart[(1 << LOGB_) + 2];
   u32 scratch[THREADS / kWave + 1];
   u32 tick[2];
   u32 flag;
@@ -832,6 +838,8 @@ struct SortedFkSmem {
   u64 obase;
   u64 red[8];
 };
+static_assert(sizeof(SortedFkSmem<SWF_HALF_THREADS, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>) <= 80 * 1024, "two workgroups per CU");
+static_assert(SWF_HALF_CAPB <= SWF_HALF_THREADS * SWF_HALF_ROWS, "tmpkey aliases sval");
 
 // Publish partition p's row count and return the number of result rows of partitions 0 .. p-1.  Called by one
 // whole wave: lane l inspects partition p-1-l, 64 predecessors per round, back to the nearest one that has
@@ -868,11 +876,16 @@ __device__ __forceinline__ u64 lookback_publish(u64* __restrict__ state, u32 p, 
 // mixing arithmetic out of its registers (it ran at the 128-register limit of a 1024-thread workgroup with up to
 // 96 bytes of scratch per lane; the scratch reloads showed as 38 % more fetched bytes than the rows themselves,
 // profiles/r03a_ordered_unique_before_summary.txt).
-template <int THREADS, bool SLAB, bool FK, bool EXTRA>
+template <int THREADS, bool SLAB, bool FK, bool EXTRA, int ROWS = FP_ROWS, int CAPB_ = SWF_CAPB, int LOGB_ = SWF_LOGB>
 __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArgs a, u64* __restrict__ lookback, int key_low, bool chained) {
-  typedef typename std::conditional<FK, SortedFkSmem<THREADS>, SortedSmem<THREADS>>::type Smem;
+  static_assert(FK || ROWS == ROWS, "the bitmap form has one shape");
+  typedef typename std::conditional<FK, SortedFkSmem<THREADS, ROWS, CAPB_, LOGB_>, SortedSmem<THREADS>>::type Smem;
   constexpr u32 CAP = Smem::CAP, CAPB = Smem::CAPB, WORDS = CAP / 32, NB = 1u << Smem::LOGB, BPT = NB / THREADS;
   static_assert(BPT * THREADS == NB && BPT >= 1, "whole buckets per thread in the scan");
+  // The big shapes (one workgroup per CU) request the next partition's probe rows as soon as this partition's are
+  // consumed; the small shape (two workgroups per CU: its sibling covers the latency) asks for a partition's probe
+  // rows at the top of its own iteration and keeps those 24 registers free during the copy-out.
+  constexpr bool EARLY_PROBE = ROWS == FP_ROWS;
   const int bsh = key_low - Smem::LOGB;  // bucket = the key bits right under the partition bits
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
@@ -909,7 +922,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
   u32 rb = 0, nb = 0, sb = 0, np = 0;
   u32 r1 = 0, r2 = 0, r3 = 0, s1 = 0, s2 = 0, s3 = 0, r1n = 0, r2n = 0, r3n = 0, s1n = 0, s2n = 0, s3n = 0;
   bool regular = false;
-  Tup br[FP_ROWS], pr[FP_ROWS];
+  Tup br[ROWS], pr[ROWS];
   const Tup* __restrict__ dummy = reinterpret_cast<const Tup*>(a.accum);
   if (p < P) {
     if (SLAB) {
@@ -925,13 +938,14 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     regular = nb && np && nb <= CAPB && np <= CAP;
     // the first partition's rows, both sides (unconditional loads: see probe_count_fast_kernel)
     if (SLAB) {
-      fp_load_slab<THREADS>(br, regular ? R + (u64)p * SLAB_KB * a.r_cap : dummy, regular ? a.r_cap : 0u, regular ? r1 : 1u,
+      fp_load_slab<THREADS, ROWS>(br, regular ? R + (u64)p * SLAB_KB * a.r_cap : dummy, regular ? a.r_cap : 0u, regular ? r1 : 1u,
                             regular ? r2 : 1u, regular ? r3 : 1u, regular ? nb : 1u, tid);
-      fp_load_slab<THREADS>(pr, regular ? S + (u64)p * SLAB_KB * a.s_cap : dummy, regular ? a.s_cap : 0u, regular ? s1 : 1u,
-                            regular ? s2 : 1u, regular ? s3 : 1u, regular ? np : 1u, tid);
+      if (EARLY_PROBE)
+        fp_load_slab<THREADS, ROWS>(pr, regular ? S + (u64)p * SLAB_KB * a.s_cap : dummy, regular ? a.s_cap : 0u, regular ? s1 : 1u,
+                              regular ? s2 : 1u, regular ? s3 : 1u, regular ? np : 1u, tid);
     } else {
-      fp_load<THREADS>(br, regular ? R + rb : dummy, regular ? nb : 1u, tid);
-      fp_load<THREADS>(pr, regular ? S + sb : dummy, regular ? np : 1u, tid);
+      fp_load<THREADS, ROWS>(br, regular ? R + rb : dummy, regular ? nb : 1u, tid);
+      if (EARLY_PROBE) fp_load<THREADS, ROWS>(pr, regular ? S + sb : dummy, regular ? np : 1u, tid);
     }
   }
   const int tid_outer = tid;
@@ -953,13 +967,20 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       const u64* ibp = a.item_base + p;
       asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ob) : "s"(ibp) : "memory");
     }
+    if (!EARLY_PROBE) {  // this partition's probe rows (unconditional loads: see probe_count_fast_kernel)
+      if (SLAB)
+        fp_load_slab<THREADS, ROWS>(pr, regular ? S + (u64)p * SLAB_KB * a.s_cap : dummy, regular ? a.s_cap : 0u, regular ? s1 : 1u,
+                              regular ? s2 : 1u, regular ? s3 : 1u, regular ? np : 1u, tid);
+      else
+        fp_load<THREADS, ROWS>(pr, regular ? S + sb : dummy, regular ? np : 1u, tid);
+    }
     // (no barrier here: the first LDS arrays this partition writes -- cnt, then bstart -- are not read by the
     //  previous partition's copy-out, and two barriers lie between here and the first write to sval / key / val)
-    u32 ha[FP_ROWS];  // build row k: bucket | arrival number in the bucket << 12
+    u32 ha[ROWS];  // build row k: bucket | arrival number in the bucket << 12
     if (regular) {
       // count the build rows per bucket; the old count is the row's arrival number inside its bucket
 #pragma unroll
-      for (int k = 0; k < FP_ROWS; k++) {
+      for (int k = 0; k < ROWS; k++) {
         const u32 i = k * THREADS + tid;
         ha[k] = 0;
         if (i < nb) {
@@ -994,21 +1015,22 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     }
     auto load_next_build = [&]() {
       if (SLAB)
-        fp_load_slab<THREADS>(br, regular2 ? R + (u64)pn * SLAB_KB * a.r_cap : dummy, regular2 ? a.r_cap : 0u,
+        fp_load_slab<THREADS, ROWS>(br, regular2 ? R + (u64)pn * SLAB_KB * a.r_cap : dummy, regular2 ? a.r_cap : 0u,
                               regular2 ? r1n : 1u, regular2 ? r2n : 1u, regular2 ? r3n : 1u, regular2 ? nb2 : 1u, tid);
       else
-        fp_load<THREADS>(br, regular2 ? R + rb2 : dummy, regular2 ? nb2 : 1u, tid);
+        fp_load<THREADS, ROWS>(br, regular2 ? R + rb2 : dummy, regular2 ? nb2 : 1u, tid);
     };
     // The NEXT partition's probe rows are requested as soon as this partition's are consumed -- before the bitmap
     // scan, the look-back and the copy-out, which do not touch them -- so they have the whole write phase and the
     // next partition's count / scan / place phases to arrive (round 2 asked for them at the top of the iteration
     // and waited for them three barriers later).
     auto load_next_probe = [&]() {
+      if (!EARLY_PROBE) return;
       if (SLAB)
-        fp_load_slab<THREADS>(pr, regular2 ? S + (u64)pn * SLAB_KB * a.s_cap : dummy, regular2 ? a.s_cap : 0u,
+        fp_load_slab<THREADS, ROWS>(pr, regular2 ? S + (u64)pn * SLAB_KB * a.s_cap : dummy, regular2 ? a.s_cap : 0u,
                               regular2 ? s1n : 1u, regular2 ? s2n : 1u, regular2 ? s3n : 1u, regular2 ? np2 : 1u, tid);
       else
-        fp_load<THREADS>(pr, regular2 ? S + sb2 : dummy, regular2 ? np2 : 1u, tid);
+        fp_load<THREADS, ROWS>(pr, regular2 ? S + sb2 : dummy, regular2 ? np2 : 1u, tid);
     };
     u32 total = 0;       // result rows of this partition
     constexpr int WROUNDS = (int)((WORDS + kWave - 1) / kWave);
@@ -1043,7 +1065,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           // the number of smaller keys in the bucket -- is what the output order needs; the probe row that matches it
           // scans the whole bucket anyway and counts them on the way, so the build rows are never moved again.
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             const u32 i = k * THREADS + tid;
             if (i < nb) {
               const u32 pos = (u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12);
@@ -1057,9 +1079,9 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         if (sm.flag == 0) {
           // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap).  Per row one packed
           // word: smaller keys seen (bits 0-5), step of the match (6-11), matches (12-13)
-          u32 cur[FP_ROWS], len[FP_ROWS], st[FP_ROWS];
+          u32 cur[ROWS], len[ROWS], st[ROWS];
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             const u32 j = k * THREADS + tid;
             cur[k] = len[k] = st[k] = 0;
             if (j < np) {
@@ -1073,10 +1095,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
             bool any = false;
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; k++) any |= step < len[k];
+            for (int k = 0; k < ROWS; k++) any |= step < len[k];
             if (!__any(any)) break;
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; k++) {
+            for (int k = 0; k < ROWS; k++) {
               if (step < len[k]) {
                 const u64 kk = sm.key[cur[k] + step];
                 st[k] += kk < pr[k].key ? 1u : 0u;
@@ -1086,7 +1108,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           }
           bool dup = false, dupb = false;
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             const u32 hits = st[k] >> 12;
             if (hits) {
               const u32 si = cur[k] + (st[k] & 63u), bit = 1u << (si & 31);  // the matched build row's sorted rank
@@ -1128,7 +1150,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         u64* tmpkey = sm.sval;  // keys in bucket / arrival order (sval is free until the payloads are dropped)
         if (sm.flag == 0) {     // uniform
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             const u32 i = k * THREADS + tid;
             if (i < nb) tmpkey[(u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12)] = br[k].key;
           }
@@ -1137,7 +1159,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         if (sm.flag == 0) {
           bool dupb = false;
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             const u32 i = k * THREADS + tid;
             if (i < nb) {
               const u32 h = ha[k] & (NB - 1), b0 = sm.bstart[h], b1 = sm.bstart[h + 1], mine = b0 + (ha[k] >> 12);
@@ -1155,13 +1177,13 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
         load_next_build();
         lds_barrier();  // the sorted table is complete (and tmpkey is dead)
-        u32 found[FP_ROWS], slot[FP_ROWS];  // a probe row's match: sorted rank + 1 (0 = none); arrival number in its key's run
+        u32 found[ROWS], slot[ROWS];  // a probe row's match: sorted rank + 1 (0 = none); arrival number in its key's run
 #pragma unroll
-        for (int k = 0; k < FP_ROWS; k++) found[k] = slot[k] = 0;
+        for (int k = 0; k < ROWS; k++) found[k] = slot[k] = 0;
         if (sm.flag == 0) {
-          u32 cur[FP_ROWS], len[FP_ROWS];
+          u32 cur[ROWS], len[ROWS];
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             const u32 j = k * THREADS + tid;
             cur[k] = len[k] = 0;
             if (j < np) {
@@ -1175,10 +1197,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
             bool any = false;
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; k++) any |= step < len[k];
+            for (int k = 0; k < ROWS; k++) any |= step < len[k];
             if (!__any(any)) break;
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; k++) {
+            for (int k = 0; k < ROWS; k++) {
               if (step < len[k] && sm.key[cur[k] + step] == pr[k].key) {
                 found[k] = cur[k] + step + 1;
                 len[k] = 0;  // (keys are unique in the table: done)
@@ -1186,7 +1208,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
             }
           }
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             if (found[k]) {
               slot[k] = atomicAdd(&sm.mcnt[found[k] - 1], 1u);  // arrival number among the probe rows of the key
               acc_n++;
@@ -1202,10 +1224,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         lds_barrier();
         if (sm.flag == 0) {  // uniform
           // every build row's run of output slots: exclusive scan of the match counts in sorted build order
-          u32 c[FP_ROWS], sum = 0, mx = 0;
+          u32 c[ROWS], sum = 0, mx = 0;
 #pragma unroll
-          for (int q = 0; q < FP_ROWS; q++) {
-            const u32 i = (u32)tid * FP_ROWS + q;
+          for (int q = 0; q < ROWS; q++) {
+            const u32 i = (u32)tid * ROWS + q;
             c[q] = i < CAPB ? sm.mcnt[i] : 0u;
             sum += c[q];
             mx = c[q] > mx ? c[q] : mx;
@@ -1214,8 +1236,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           if (mx > 1) sm.anydup = 1;
           u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &total);  // (a barrier follows below)
 #pragma unroll
-          for (int q = 0; q < FP_ROWS; q++) {
-            const u32 i = (u32)tid * FP_ROWS + q;
+          for (int q = 0; q < ROWS; q++) {
+            const u32 i = (u32)tid * ROWS + q;
             if (i < CAPB) sm.mcnt[i] = ex;
             ex += c[q];
           }
@@ -1225,7 +1247,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         if (sorted_ok) {
           // payload and sorted rank to the key's run, in arrival order
 #pragma unroll
-          for (int k = 0; k < FP_ROWS; k++) {
+          for (int k = 0; k < ROWS; k++) {
             if (found[k]) {
               const u32 o = sm.mcnt[found[k] - 1] + slot[k];
               sm.sval[o] = pr[k].val;
@@ -1281,10 +1303,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         const bool rank_runs = sm.anydup != 0;  // uniform
         // (all LDS work of the five slots first, then the stores back to back from registers of their own: see the
         //  bitmap form below)
-        u32 rel[FP_ROWS];
-        u64 ok[FP_ROWS], orv[FP_ROWS], osv[FP_ROWS];
+        u32 rel[ROWS];
+        u64 ok[ROWS], orv[ROWS], osv[ROWS];
 #pragma unroll
-        for (int k = 0; k < FP_ROWS; k++) {
+        for (int k = 0; k < ROWS; k++) {
           const u32 j = k * THREADS + tid;
           const bool live = j < total;
           u32 si = 0, base = 0, c = 0;
@@ -1316,7 +1338,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           osv[k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < FP_ROWS; k++) {
+        for (int k = 0; k < ROWS; k++) {
           if (rel[k] != 0xFFFFFFFFu) {
             const u64 d = ob + rel[k];
             a.out_key[d] = ok[k];
@@ -1333,10 +1355,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       // own: with the rows interleaved the compiler reused one row's store-data registers for the next row's LDS
       // reads and put an s_waitcnt vmcnt(1) between them -- each row then waited for the previous row's stores
       // AND for the prefetches of the next partition that are in flight (vector-memory operations retire in order)
-      u32 rel[FP_ROWS];  // output row relative to ob, or ~0
-      u64 ok[FP_ROWS], orv[FP_ROWS], osv[FP_ROWS];
+      u32 rel[ROWS];  // output row relative to ob, or ~0
+      u64 ok[ROWS], orv[ROWS], osv[ROWS];
 #pragma unroll
-      for (int k = 0; k < FP_ROWS; k++) {
+      for (int k = 0; k < ROWS; k++) {
         const u32 si = k * THREADS + tid;
         // word si / 32 = 32 k + tid / 32: scan round k / 2, lane 32 (k & 1) + tid / 32 of this wave's registers
         const u32 before = (u32)__shfl((int)wpre[k >> 1], (int)((k & 1) * 32 + ((u32)tid >> 5) % 32u), kWave);
@@ -1354,7 +1376,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
       }
 #pragma unroll
-      for (int k = 0; k < FP_ROWS; k++) {
+      for (int k = 0; k < ROWS; k++) {
         if (rel[k] != 0xFFFFFFFFu) {
           const u64 d = ob + rel[k];
           a.out_key[d] = ok[k];
@@ -1893,16 +1915,39 @@ static hipError_t launch_sorted_t(const ProbeArgs& a, u64* lookback, bool chaine
   hipLaunchKernelGGL((probe_write_sorted_kernel<1024, SLAB, FK, EXTRA>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, key_low, chained);
   return hipGetLastError();
 }
+// the foreign-key form's small shape: 512 threads x 6 rows, two workgroups per CU
+template <bool SLAB, bool EXTRA>
+static hipError_t launch_sorted_half_t(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
+  typedef SortedFkSmem<SWF_HALF_THREADS, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB> Smem;
+  static SmemAttrOnce attr_once;
+  const void* fn = reinterpret_cast<const void*>(
+      probe_write_sorted_kernel<SWF_HALF_THREADS, SLAB, true, EXTRA, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>);
+  if (hipError_t e = ensure_max_smem(attr_once, fn, sizeof(Smem)); e != hipSuccess) return e;
+  hipLaunchKernelGGL((probe_write_sorted_kernel<SWF_HALF_THREADS, SLAB, true, EXTRA, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>),
+                     dim3(grid), dim3(SWF_HALF_THREADS), sizeof(Smem), st, a, lookback, key_low, chained);
+  return hipGetLastError();
+}
 template <bool SLAB, bool FK>
 static hipError_t launch_sorted_x(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
   return (a.extra & 1u) ? launch_sorted_t<SLAB, FK, true>(a, lookback, chained, key_low, grid, st)
                         : launch_sorted_t<SLAB, FK, false>(a, lookback, chained, key_low, grid, st);
 }
-// fk: the probe keys may repeat (SortedFkSmem); key_low: the partition id's lowest key bit
-hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, u64* lookback, bool chained, int key_low,
+// fk: the probe keys may repeat (SortedFkSmem); half: its small shape (partitions of up to 3072 probe and 2048 build
+// rows; anything larger makes the kernel give up with "a partition does not fit"); key_low: the partition id's
+// lowest key bit
+hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, bool half, u64* lookback, bool chained, int key_low,
                                      int num_cus, hipStream_t st) {
   if (key_low < SW_LOGB) return hipErrorInvalidValue;
   if (slab && !slab_operands_ok(a)) return hipErrorInvalidValue;
+  if (fk && half) {
+    int grid = 2 * num_cus;
+    if ((u32)grid > a.P) grid = (int)a.P;
+    if (grid < 1) grid = 1;
+    if (slab) return (a.extra & 1u) ? launch_sorted_half_t<true, true>(a, lookback, chained, key_low, grid, st)
+                                    : launch_sorted_half_t<true, false>(a, lookback, chained, key_low, grid, st);
+    return (a.extra & 1u) ? launch_sorted_half_t<false, true>(a, lookback, chained, key_low, grid, st)
+                          : launch_sorted_half_t<false, false>(a, lookback, chained, key_low, grid, st);
+  }
   int grid = num_cus;  // one workgroup per CU fits (LDS); partitions are handed out by ticket
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;

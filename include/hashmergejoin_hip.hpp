@@ -327,8 +327,9 @@ class HashMergeJoin<RIter, SIter, false> {
 
 // ---------------------------------------------------------------------------------------------------
 // HashMergeJoin2 (hashjoin.h:201-363): the relations arrive PRE-HASHED as std::tuple<size_t hash, Key,
-// Value> rows.  The reference sorts both buffers in place on (hash, key) (radix_inplace_par,
-// radix_hash.h:589-654) and merges them; here the GPU joins the {hash, row index} rows, the host keeps
+// Value> rows.  The reference sorts both buffers in place by the hash (radix_inplace_par,
+// radix_hash.h:589-654; keys only break ties inside its insertion sort of tiny buckets) and merges them on
+// (hash, key); here both buffers are sorted by hash (stable), the GPU joins the {hash, row index} rows, the host keeps
 // the pairs whose keys are equal, and iteration runs in the same ascending (hash, key) order.
 // operator* points into the caller's buffers, as the reference's does -- and, as in the reference
 // (hashjoin.h:234-235), the ctor leaves BOTH caller buffers sorted by hash: tuples of 8-byte trivially copyable
@@ -359,7 +360,8 @@ class HashMergeJoin2 {
     for (std::size_t i = 0; i < n; i++) out[i] = std::make_pair((std::uint64_t)std::get<0>(begin[i]), (std::uint64_t)i);
   }
 
-  // radix_inplace_par's visible effect (radix_hash.h:589-654): the caller's buffer ends up sorted by hash
+  // radix_inplace_par's visible effect (radix_hash.h:589-654): the caller's buffer ends up sorted by hash (stable: equal
+  // hashes keep their input order; the reference's swap chains do not promise any)
   template <typename Iter>
   static void sort_in_place(Iter begin, std::size_t n) {
     typedef typename std::iterator_traits<Iter>::value_type T;
@@ -369,11 +371,17 @@ class HashMergeJoin2 {
     if (n < 2) return;
     hmj_ctx* c = hmj_detail::thread_ctx();
     const bool contiguous = std::is_pointer<Iter>::value || std::is_same<Iter, typename std::vector<T>::iterator>::value;
+    // Rows may go through the device as raw bytes only when that is what copying a T means: every element
+    // trivially copyable, and the tuple nothing but its elements -- no padding, no over-alignment (std::tuple itself
+    // is never std::is_trivially_copyable in libstdc++: its assignment operators are user-provided; a tuple from
+    // another standard library with a different layout still passes or fails this test on its own merits, and the
+    // hash element's offset is taken from the object, not assumed).  Anything else: argsort + moves on the host.
     const bool plain = std::is_trivially_copyable<H>::value && std::is_trivially_copyable<K>::value &&
-                       std::is_trivially_copyable<V>::value && sizeof(H) == 8 && sizeof(T) % 8 == 0 && sizeof(T) <= 64;
-    T* first = std::addressof(*begin);
-    const std::size_t hash_off = (std::size_t)(reinterpret_cast<const char*>(&std::get<0>(*first)) - reinterpret_cast<const char*>(first));
-    if (contiguous && plain) {
+                       std::is_trivially_copyable<V>::value && sizeof(H) == 8 && sizeof(T) % 8 == 0 && sizeof(T) <= 64 &&
+                       sizeof(T) == sizeof(H) + sizeof(K) + sizeof(V) && alignof(T) <= 8;
+    if (contiguous && plain) {  // (only a contiguous range has ONE address to hand over)
+      T* first = std::addressof(*begin);
+      const std::size_t hash_off = (std::size_t)(reinterpret_cast<const char*>(&std::get<0>(*first)) - reinterpret_cast<const char*>(first));
       hmj_detail::check(c, hmj_sort_rows_by_u64_host(c, first, (uint64_t)n, (uint32_t)sizeof(T), (uint32_t)hash_off), "hmj_sort_rows_by_u64_host");
       return;
     }
