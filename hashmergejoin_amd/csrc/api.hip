@@ -514,7 +514,7 @@ int order_rows(hmj_ctx* c, const u32* vstart, const u32* in_base32, const u64* i
 // and the ordered epilogue moves every partition to its place while sorting it.  Returns
 // kRetryNoFastWrite when the kernel met duplicate build keys or an oversized partition.
 int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, int low, bool extra,
-                         int verify_prefix, u64 pfx_ref, bool ordered, bool to_host, hmj_result* out) {
+                         int verify_prefix, u64 pfx_ref, bool ordered, bool to_host, bool fk_wide_plan, hmj_result* out) {
   int rc;
   const u32 P = wa.P;
   const size_t cap_bytes = ((size_t)np + 8) * 8;  // at most one row per probe row
@@ -575,18 +575,24 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   // per CU) for the partitions the planner makes for fan-out >= 6: about 2048 probe rows + 5 sigma, sigma =
   // sqrt(fan-out x mean).  A partition beyond it makes the kernel give up ("does not fit"): the big shape then runs.
   bool no_half = !c->sorted_half;
-  for (int form = c->sorted_fk ? 1 : 0; form < 2 && ordered && c->sorted_mode && c->sorted_cooldown == 0 && low >= 12;
-       form++) {
+  // a probe side of more than twice the build side cannot have unique keys if its rows match: start with the
+  // foreign-key form (the bitmap form would only find out: 1.9 ms at 2^24 x 2^28)
+  const bool must_repeat = nb > 0 && (double)np >= 2.0 * (double)nb;
+  for (int form = (c->sorted_fk || must_repeat || fk_wide_plan) ? 1 : 0;
+       form < 2 && ordered && c->sorted_mode && c->sorted_cooldown == 0 && low >= 12; form++) {
     const bool fk = form == 1;
     bool half = false;
-    if (fk && !no_half && nb > 0 && P > 0) {
+    int shape = 0;
+    if (fk && nb > 0 && P > 0) {
       const double avg_np = (double)np / (double)P, avg_nb = (double)nb / (double)P, f = (double)np / (double)nb;
-      half = f >= 2.0 && avg_np + 5.0 * __builtin_sqrt(f * avg_np) <= 3072.0 && avg_nb + 6.0 * __builtin_sqrt(avg_nb) + 8.0 <= 2048.0;
+      const double hi_np = avg_np + 5.0 * __builtin_sqrt(f * avg_np), hi_nb = avg_nb + 6.0 * __builtin_sqrt(avg_nb) + 8.0;
+      half = !no_half && f >= 2.0 && hi_np <= 3072.0 && hi_nb <= 2048.0;
+      shape = half ? 1 : (fk_wide_plan && hi_nb <= 2560.0) ? 2 : 0;
     }
     if ((rc = ensure_dev(c, c->lookback, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->lookback.p, 0, ((size_t)P + 1) * 8, c->stream));
     int sp = span_begin(c, K_PROBE_WRITE, -1);
-    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, half, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
+    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, shape, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
     span_end(c, sp);
     HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -603,7 +609,8 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
       out->mix_sum = h[hmj::ACC_MIX];
       out->sum_probe_all = h[hmj::ACC_SUM_P];
       c->timing.bytes_probe_write = 16ull * ((u64)nb + np) + 24ull * out->n_matches;
-      c->timing.path |= HMJ_PATH_UNIQ_WRITE | HMJ_PATH_SORTED_WRITE | (fk ? HMJ_PATH_SORTED_FK : 0u) | (half ? HMJ_PATH_SORTED_FK_HALF : 0u);
+      c->timing.path |= HMJ_PATH_UNIQ_WRITE | HMJ_PATH_SORTED_WRITE | (fk ? HMJ_PATH_SORTED_FK : 0u) | (half ? HMJ_PATH_SORTED_FK_HALF : 0u) |
+                        (shape == 2 ? HMJ_PATH_SORTED_FK_WIDE : 0u);
       if (out->n_matches == 0) return HMJ_OK;
       const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
       // the next ordered join: chained output offsets if this one had unmatched probe rows (dense without an
@@ -635,6 +642,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
       c->sorted_cooldown = 64;
       form = 2;
     }
+    if (fk_wide_plan && !try_big) c->sorted_wide = false;  // the 16-bit plan did not pay off here: plan for 5120 rows from now on
     if (why & 1024) {  // never expected: say so whether or not tracing is on, and leave a mark the tests can see
       c->timing.path |= HMJ_PATH_LOOKBACK_TIMEOUT;
       std::fprintf(stderr, "[hmj] one-pass ordered write: a chained partition waited beyond the spin limit for its predecessor; "
@@ -712,6 +720,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;  // before the plan: one decision per join
 
   int B, passes, pass_bits[4];
+  bool fk_wide_plan = false;  // the plan relies on the wide shape of the one-pass ordered write (foreign-key form)
   plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
   // ---- key sample (one small kernel): the top bits all keys share, a hot-key hint, and the range of the build keys
   u64 smp[8] = {0, 0, 0, 0, ~0ull, 0, 0, 0};
@@ -759,11 +768,26 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     int Bp, passes_p, pb_p[4];
     plan_bits(np_plan, -1, &Bp, &passes_p, pb_p);
     const double f = (double)np_plan / (double)nb;
+    // ordered joins with fan-out >= 2.5 (their probe keys MUST repeat): the foreign-key form of the one-pass ordered
+    // write has a 6144-row shape, so 16 bits still hold mean + 5 sigma of a 2^28-row probe side at fan-out 16 -- and
+    // 16 bits partition on the slab path (32 instead of 48 B per row and pass)
+    const bool wide_ok = materialize && (flags & HMJ_ORDERED) && allow_fast_write && !c->prepare_only && c->sorted_mode &&
+                         c->sorted_wide && c->sorted_cooldown <= 1 && f >= 2.5;
+    const int B_narrow = [&] {
+      int b = Bp;
+      while (b < 18) {
+        const double avg = (double)np_plan / (double)(1ull << b);
+        if (avg + 5.0 * __builtin_sqrt(f * avg) <= 5056.0) break;
+        b++;
+      }
+      return b;
+    }();
     while (Bp < 18) {
       const double avg = (double)np_plan / (double)(1ull << Bp);
-      if (avg + 5.0 * __builtin_sqrt(f * avg) <= 5056.0) break;
+      if (avg + 5.0 * __builtin_sqrt(f * avg) <= (wide_ok ? 6016.0 : 5056.0)) break;
       Bp++;
     }
+    fk_wide_plan = wide_ok && Bp < B_narrow;
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 16 && slab_ok)))
       plan_bits(0, Bp, &B, &passes, pass_bits);  // the pass split of Bp bits
@@ -853,14 +877,15 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // no count pass); it works on either partition layout
   if (c->uniq_cooldown > 0 && allow_fast_write && materialize) c->uniq_cooldown--;
   // the pipelined probe kernels hold one partition's probe rows in registers (5120 at most)
-  const bool probe_fits = ((u64)np_plan >> B) <= 4608;
+  const bool probe_fits = ((u64)np_plan >> B) <= 4608;  // (the wide foreign-key plan keeps the mean at <= 4608 too)
   const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !first && !win_ordered &&
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
   if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
       probe_fits &&
       passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && slab_sizes_ok(c, nb, np_plan) &&
       hmj::slab_geometry(nb, pass_bits[0], pass_bits[1], &gr) &&
-      hmj::slab_geometry(np_plan, pass_bits[0], pass_bits[1], &gs)) {
+      hmj::slab_geometry(np_plan, pass_bits[0], pass_bits[1], &gs, 0,
+                         fk_wide_plan ? (double)np_plan / (double)(nb ? nb : 1) : 1.0)) {  // (a foreign-key probe side: slabs sized for its spread)
     const bool reuse = c->prep.valid && c->prep.slab && c->prep.ptr == R && c->prep.n == nb &&
                        c->prep.low == low && c->prep.B == B;
     c->prep.valid = false;  // one-shot; slab_br is about to be (re)written unless reused
@@ -939,7 +964,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       wa.Q = 1;
       wa.accum = acc;
       return unique_key_write(c, wa, true, nb, np, low, extra, verify_pfx ? prefix : 0, pfx_ref,
-                                  (flags & HMJ_ORDERED) != 0, to_host, out);
+                                  (flags & HMJ_ORDERED) != 0, to_host, fk_wide_plan, out);
     }
     hmj::ProbeArgs sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -1162,7 +1187,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     wa.Q = 1;
     wa.accum = (u64*)c->accum.p;
     rc = unique_key_write(c, wa, false, nb, np, low, extra, verify_pfx ? prefix : 0, pfx_ref,
-                                  (flags & HMJ_ORDERED) != 0, to_host, out);
+                                  (flags & HMJ_ORDERED) != 0, to_host, fk_wide_plan, out);
     if (rc != kRetryNoFastWrite) return rc;
     // duplicate build keys: the partitions stay valid, carry on with the count / scan / write passes
     HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
@@ -1362,6 +1387,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
     c->sorted_chained_forced = atoi(e) == 2 || atoi(e) == 3;  // 3: never chained
   }
   if (const char* e = getenv("HMJ_SORTED_HALF")) c->sorted_half = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_SORTED_WIDE")) c->sorted_wide = atoi(e) != 0;
   if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_UPLOAD")) c->staged_upload = std::strcmp(e, "staged") == 0;

@@ -75,6 +75,7 @@ struct hmj_ctx {
   bool sorted_chained = false;  // dense output offsets by a chained scan over the partitions (adaptive: on after an
                                 // ordered join with unmatched probe rows; HMJ_SORTED_WRITE=2 always, 3 never)
   bool sorted_chained_forced = false;
+  bool sorted_wide = true;   // HMJ_SORTED_WIDE=0: ordered foreign-key joins are never planned for the 6144-row shape
   bool sorted_half = true;   // HMJ_SORTED_HALF=0: the foreign-key form never takes its two-workgroups-per-CU shape
   bool sorted_fk = false;  // the last ordered join's probe keys repeated: start with the foreign-key form of the kernel
   int sorted_fk_age = 0;

@@ -180,9 +180,12 @@ __device__ __forceinline__ void block_accumulate(u64* red, u64* accum, const u64
 // Block-wide exclusive scan of one u32 per thread.  scratch: >= THREADS/64 + 1 words of LDS.
 // Returns the exclusive prefix; *total receives the block sum.  Contains two barriers.
 // TRAILING_BARRIER = false: the caller guarantees a workgroup barrier before `scratch` is written again.
+// tid_: the caller's thread index (default: threadIdx.x) -- a kernel that keeps its thread index opaque inside a loop
+// passes it, so that &scratch[wave] is not hoisted out of that loop as one more live register.
 template <int THREADS, bool TRAILING_BARRIER = true>
-__device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* scratch, u32* total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+__device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32* scratch, u32* total, int tid_ = -1) {
+  const int t_ = tid_ < 0 ? (int)threadIdx.x : tid_;
+  const int lane = t_ & 63, w = t_ >> 6;
   constexpr int NW = THREADS / kWave;
   u32 incl = wave_incl_scan_u32(v, lane);
   if (lane == 63) scratch[w] = incl;

@@ -105,7 +105,7 @@ int probe_default_grid(int num_cus);
 hipError_t launch_probe_count_ext(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool slab,
                                   int num_cus, hipStream_t st);
 hipError_t launch_probe_count_slab(const ProbeArgs& a, int num_cus, hipStream_t st);
-hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, bool half, u64* lookback, bool chained, int key_low,
+hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, int shape, u64* lookback, bool chained, int key_low,
                                      int num_cus, hipStream_t st);
 hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, hipStream_t st);
 hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st);

@@ -820,26 +820,33 @@ constexpr int SWF_LOGB = 11, SWF_CAPB = 4608, SWF_MAXDUP = 1024;
 // shape's thread slots would idle, and one workgroup per CU leaves the memory pipeline empty during every one of
 // its barrier-separated phases -- with two, one computes while the other loads and stores).
 constexpr int SWF_HALF_THREADS = 512, SWF_HALF_ROWS = 6, SWF_HALF_CAPB = 2048, SWF_HALF_LOGB = 10;
+// <1024 threads, 6 rows>, 2560 build rows -- 6144 probe rows, 125 KB: the partitions of a 16-bit plan for fan-out 2.5 ... 30
+// (4096 probe rows + 5 sigma, sigma = sqrt(fan-out x 4096) <= 390), which lets those joins partition on the slab path
+// (two 8-bit passes, 32 B per row and pass) instead of 17 bits on the exact path (48 B).
+constexpr int SWF_WIDE_ROWS = 6, SWF_WIDE_CAPB = 2560;
 template <int THREADS, int ROWS = FP_ROWS, int CAPB_ = SWF_CAPB, int LOGB_ = SWF_LOGB>
 struct SortedFkSmem {
   static constexpr int CAP = THREADS * ROWS, CAPB = CAPB_, LOGB = LOGB_;
   u64 key[CAPB];   // build keys in sorted order
   u64 val[CAPB];   // build payloads, same order
   u64 sval[CAP];   // the probe payload of every OUTPUT slot (before that: the build keys in bucket / arrival order)
-  u32 mcnt[CAPB];  // matches of the build row of sorted rank i, then the first output slot of its run
+  // matches of the build row of sorted rank i, then the first output slot of its run; [CAPB] = "some key has more than
+  // one probe row", [CAPB + 1] = "some key has more than SWF_MAXDUP probe rows" (two words of the same array, so that one
+  // loop over thread-relative addresses zeroes them all: as words of their own their constant addresses each took a
+  // register, got spilled, and came back behind an s_waitcnt vmcnt(0) in wave 0)
+  u32 mcnt[CAPB + 2];
   u16 srank[CAP];  // sorted rank of every output slot's build row
   u32 cnt[1 << LOGB_];
   u16 bstart[(1 << LOGB_) + 2];
   u32 scratch[THREADS / kWave + 1];
   u32 tick[2];
   u32 flag;
-  u32 anydup;  // some key has more than one probe row
-  u32 hot;     // some key has more than SWF_MAXDUP probe rows
   u64 obase;
   u64 red[8];
 };
 static_assert(sizeof(SortedFkSmem<SWF_HALF_THREADS, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>) <= 80 * 1024, "two workgroups per CU");
 static_assert(SWF_HALF_CAPB <= SWF_HALF_THREADS * SWF_HALF_ROWS, "tmpkey aliases sval");
+static_assert(sizeof(SortedFkSmem<1024, SWF_WIDE_ROWS, SWF_WIDE_CAPB, SWF_LOGB>) <= 160 * 1024, "one workgroup per CU");
 
 // Publish partition p's row count and return the number of result rows of partitions 0 .. p-1.  Called by one
 // whole wave: lane l inspects partition p-1-l, 64 predecessors per round, back to the nearest one that has
@@ -957,6 +964,11 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     // 71 % of the wave cycles parked, 38 % more bytes fetched than the rows themselves).
     int tid = tid_outer;
     asm volatile("" : "+v"(tid));
+    // (the same for the few words single lanes write at constant addresses -- the flag, this partition's row count:
+    //  indexed by an opaque zero their addresses are computed where they are used, not kept, spilled and reloaded
+    //  behind s_waitcnt vmcnt(0))
+    u32 zero = 0;
+    asm volatile("" : "+v"(zero));
     if (chained && tid == 0) sm.tick[par ^ 1] = (u32)atomicAdd(ticket, 1ull);  // the partition after this one
     // this partition's first output slot, through the SCALAR cache (item_base was written by an earlier kernel).
     // The compiler cannot prove it invariant and would use a vector load, and vector-memory operations complete in
@@ -992,8 +1004,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     }
     lds_barrier();  // bucket counts complete; the next ticket is visible
     if constexpr (FK) {  // the match counts (the previous partition's copy-out is over: one barrier since)
-      for (u32 i = tid; i < CAPB; i += THREADS) sm.mcnt[i] = 0;
-      if (tid == 0) sm.anydup = sm.hot = 0;
+      for (u32 i = tid; i < CAPB + 2; i += THREADS) sm.mcnt[i] = 0;  // (+ anydup, hot: the two words behind the array)
     } else {
       if ((u32)tid < WORDS) sm.mbits[par ^ 1][tid] = 0;  // the next partition's bitmap (the previous one's copy-out is over)
     }
@@ -1048,15 +1059,15 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           sum += c[q];
           mx = c[q] > mx ? c[q] : mx;
         }
-        if (mx > (u32)SW_MAXBUCKET) sm.flag = 1;
+        if (mx > (u32)SW_MAXBUCKET) (&sm.flag)[zero] = 1;
         u32 tot;
-        u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &tot);  // (a barrier follows below)
+        u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &tot, tid);  // (a barrier follows below)
 #pragma unroll
         for (u32 q = 0; q < BPT; q++) {
           sm.bstart[tid * BPT + q] = (u16)ex;
           ex += c[q];
         }
-        if (tid == 0) sm.bstart[NB] = (u16)nb;
+        if (tid == THREADS - 1) sm.bstart[tid * BPT + BPT] = (u16)ex;  // = bstart[NB] = nb: the end of the last bucket
       }
       lds_barrier();
       if constexpr (!FK) {
@@ -1126,8 +1137,8 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
               }
             }
           }
-          if (dup) sm.flag = 2;
-          if (dupb) sm.flag = 3;
+          if (dup) (&sm.flag)[zero] = 2;
+          if (dupb) (&sm.flag)[zero] = 3;
         }
         load_next_probe();
         lds_barrier();
@@ -1173,7 +1184,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
               sm.val[b0 + less] = br[k].val;
             }
           }
-          if (dupb) sm.flag = 3;  // two build rows with one key: not this kernel's case
+          if (dupb) (&sm.flag)[zero] = 3;  // two build rows with one key: not this kernel's case
         }
         load_next_build();
         lds_barrier();  // the sorted table is complete (and tmpkey is dead)
@@ -1232,9 +1243,9 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
             sum += c[q];
             mx = c[q] > mx ? c[q] : mx;
           }
-          if (mx > (u32)SWF_MAXDUP) sm.hot = 1;  // (its own word: sm.flag is being read by slower threads right now)
-          if (mx > 1) sm.anydup = 1;
-          u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &total);  // (a barrier follows below)
+          if (mx > (u32)SWF_MAXDUP) sm.mcnt[CAPB + 1] = 1;  // (its own word: sm.flag is being read by slower threads right now)
+          if (mx > 1) sm.mcnt[CAPB] = 1;
+          u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &total, tid);  // (a barrier follows below)
 #pragma unroll
           for (int q = 0; q < ROWS; q++) {
             const u32 i = (u32)tid * ROWS + q;
@@ -1243,7 +1254,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           }
           lds_barrier();
         }
-        sorted_ok = sm.flag == 0 && sm.hot == 0;
+        sorted_ok = sm.flag == 0 && sm.mcnt[CAPB + 1] == 0;
         if (sorted_ok) {
           // payload and sorted rank to the key's run, in arrival order
 #pragma unroll
@@ -1285,7 +1296,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     // chained: the rows of all partitions before this one (wave 0 finds out, the others wait); slots: the
     // partition's own probe-row slots (the result is then dense only if every probe row matched -- the caller
     // checks and closes the gaps otherwise)
-    if (tid == 0) a.part_count[p] = total;
+    if (tid == 0) a.part_count[p + zero] = total;
     if (chained) {
       if (wv == 0) {
         const u64 excl = lookback_publish(state, p, (u64)total, lane, &lb_timeout);
@@ -1300,7 +1311,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
       if constexpr (FK) {
         // copy-out in SLOT order: lane <-> output slot, so the lanes of a run are neighbours and read the run's
         // payloads as broadcasts.  rank = smaller payloads in the run + equal ones in earlier slots.
-        const bool rank_runs = sm.anydup != 0;  // uniform
+        const bool rank_runs = sm.mcnt[CAPB] != 0;  // uniform
         // (all LDS work of the five slots first, then the stores back to back from registers of their own: see the
         //  bitmap form below)
         u32 rel[ROWS];
@@ -1915,42 +1926,43 @@ static hipError_t launch_sorted_t(const ProbeArgs& a, u64* lookback, bool chaine
   hipLaunchKernelGGL((probe_write_sorted_kernel<1024, SLAB, FK, EXTRA>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, key_low, chained);
   return hipGetLastError();
 }
-// the foreign-key form's small shape: 512 threads x 6 rows, two workgroups per CU
-template <bool SLAB, bool EXTRA>
-static hipError_t launch_sorted_half_t(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
-  typedef SortedFkSmem<SWF_HALF_THREADS, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB> Smem;
+// the foreign-key form's other shapes: 512 threads x 6 rows (two workgroups per CU), 1024 threads x 6 rows
+template <int THREADS, int ROWS, int CAPB_, int LOGB_, bool SLAB, bool EXTRA>
+static hipError_t launch_sorted_shape_t(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
+  typedef SortedFkSmem<THREADS, ROWS, CAPB_, LOGB_> Smem;
   static SmemAttrOnce attr_once;
-  const void* fn = reinterpret_cast<const void*>(
-      probe_write_sorted_kernel<SWF_HALF_THREADS, SLAB, true, EXTRA, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>);
+  const void* fn = reinterpret_cast<const void*>(probe_write_sorted_kernel<THREADS, SLAB, true, EXTRA, ROWS, CAPB_, LOGB_>);
   if (hipError_t e = ensure_max_smem(attr_once, fn, sizeof(Smem)); e != hipSuccess) return e;
-  hipLaunchKernelGGL((probe_write_sorted_kernel<SWF_HALF_THREADS, SLAB, true, EXTRA, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>),
-                     dim3(grid), dim3(SWF_HALF_THREADS), sizeof(Smem), st, a, lookback, key_low, chained);
+  hipLaunchKernelGGL((probe_write_sorted_kernel<THREADS, SLAB, true, EXTRA, ROWS, CAPB_, LOGB_>), dim3(grid), dim3(THREADS),
+                     sizeof(Smem), st, a, lookback, key_low, chained);
   return hipGetLastError();
+}
+template <int THREADS, int ROWS, int CAPB_, int LOGB_>
+static hipError_t launch_sorted_shape(const ProbeArgs& a, bool slab, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
+  if (slab) return (a.extra & 1u) ? launch_sorted_shape_t<THREADS, ROWS, CAPB_, LOGB_, true, true>(a, lookback, chained, key_low, grid, st)
+                                  : launch_sorted_shape_t<THREADS, ROWS, CAPB_, LOGB_, true, false>(a, lookback, chained, key_low, grid, st);
+  return (a.extra & 1u) ? launch_sorted_shape_t<THREADS, ROWS, CAPB_, LOGB_, false, true>(a, lookback, chained, key_low, grid, st)
+                        : launch_sorted_shape_t<THREADS, ROWS, CAPB_, LOGB_, false, false>(a, lookback, chained, key_low, grid, st);
 }
 template <bool SLAB, bool FK>
 static hipError_t launch_sorted_x(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
   return (a.extra & 1u) ? launch_sorted_t<SLAB, FK, true>(a, lookback, chained, key_low, grid, st)
                         : launch_sorted_t<SLAB, FK, false>(a, lookback, chained, key_low, grid, st);
 }
-// fk: the probe keys may repeat (SortedFkSmem); half: its small shape (partitions of up to 3072 probe and 2048 build
-// rows; anything larger makes the kernel give up with "a partition does not fit"); key_low: the partition id's
-// lowest key bit
-hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, bool half, u64* lookback, bool chained, int key_low,
+// fk: the probe keys may repeat (SortedFkSmem); shape (fk only): 0 = 5120 probe / 4608 build rows per partition,
+// 1 = the small shape (3072 / 2048, two workgroups per CU), 2 = the wide shape (6144 / 2560) -- a partition beyond the
+// shape's capacities makes the kernel give up with "a partition does not fit"; key_low: the partition id's lowest key bit
+hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, int shape, u64* lookback, bool chained, int key_low,
                                      int num_cus, hipStream_t st) {
   if (key_low < SW_LOGB) return hipErrorInvalidValue;
   if (slab && !slab_operands_ok(a)) return hipErrorInvalidValue;
-  if (fk && half) {
-    int grid = 2 * num_cus;
-    if ((u32)grid > a.P) grid = (int)a.P;
-    if (grid < 1) grid = 1;
-    if (slab) return (a.extra & 1u) ? launch_sorted_half_t<true, true>(a, lookback, chained, key_low, grid, st)
-                                    : launch_sorted_half_t<true, false>(a, lookback, chained, key_low, grid, st);
-    return (a.extra & 1u) ? launch_sorted_half_t<false, true>(a, lookback, chained, key_low, grid, st)
-                          : launch_sorted_half_t<false, false>(a, lookback, chained, key_low, grid, st);
-  }
-  int grid = num_cus;  // one workgroup per CU fits (LDS); partitions are handed out by ticket
+  int grid = (fk && shape == 1) ? 2 * num_cus : num_cus;  // workgroups that fit a CU (LDS); partitions by stride or ticket
   if ((u32)grid > a.P) grid = (int)a.P;
   if (grid < 1) grid = 1;
+  if (fk && shape == 1)
+    return launch_sorted_shape<SWF_HALF_THREADS, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>(a, slab, lookback, chained, key_low, grid, st);
+  if (fk && shape == 2)
+    return launch_sorted_shape<1024, SWF_WIDE_ROWS, SWF_WIDE_CAPB, SWF_LOGB>(a, slab, lookback, chained, key_low, grid, st);
   if (slab) return fk ? launch_sorted_x<true, true>(a, lookback, chained, key_low, grid, st)
                       : launch_sorted_x<true, false>(a, lookback, chained, key_low, grid, st);
   return fk ? launch_sorted_x<false, true>(a, lookback, chained, key_low, grid, st)

@@ -116,6 +116,7 @@ typedef struct {
 #define HMJ_PATH_SORTED_FK 0x1000u     /* ... in its foreign-key form (probe keys repeat)                 */
 #define HMJ_PATH_DENSE_BUILD 0x2000u   /* build keys cover part of the key range: plan sized by their density */
 #define HMJ_PATH_SORTED_FK_HALF 0x8000u /* ... in its small shape: 512-thread workgroups, two per CU                */
+#define HMJ_PATH_SORTED_FK_WIDE 0x20000u /* ... in its wide shape: 6144 probe rows per partition (16-bit plan, slab path)    */
 #define HMJ_PATH_LOOKBACK_TIMEOUT 0x10000u /* a chained partition gave up waiting for its predecessor (a bug if seen) */
 #define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
 
