@@ -249,12 +249,13 @@ def ex1():
     e.close()
 
 
-@pytest.mark.parametrize("log2n,maxmsg", [(22, 1 << 22), (26, 1 << 28), (28, 1 << 30)])
+@pytest.mark.parametrize("log2n,maxmsg", [(22, 1 << 22), (24, 1 << 20), (26, 1 << 28), (28, 1 << 30)])
 def test_one_rank_rccl_exchange_at_shard_size(ex1, log2n, maxmsg):
     # BASELINE configs[3]'s per-rank shape (2^28-row shard at log2n = 28): the whole exchange path through RCCL
     # (forced with hmj_comm_set_self_exchange: a one-rank job's default is the plain join) -- digit pre-pass, rounds
     # of digit ranges as self send/recv, one join per arrived round -- checked by the generator's closed forms
-    # (every probe row matches one build row).
+    # (every probe row matches one build row).  [24-2^20]: 16 MiB messages under a 1 MiB limit: every message goes as
+    # sixteen consecutive ncclSend / ncclRecv pieces (what keeps a message under RCCL's 2 GiB truncation).
     import hashmergejoin_amd as H
 
     ex = ex1

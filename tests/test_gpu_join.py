@@ -139,6 +139,59 @@ def test_join_matches_oracle(ex, H, oracle, nb, npb, miss):
     assert np.array_equal(ex.columns_to_numpy(r, host=True), rows)
 
 
+@pytest.mark.parametrize("nb,npb,miss", [((1 << 22) + 4321, (1 << 22) + 99, 3), (1 << 22, 3 * (1 << 22) + 5, 0)])
+def test_host_entry_pipeline_matches_oracle(ex, H, oracle, nb, npb, miss):
+    # the host-resident entry point as a pipeline (from 2^22 rows per relation on): uploads on a copy
+    # stream, the build side partitioned while the probe side is still on the PCIe link, the probe side's first pass
+    # per uploaded chunk -- same rows, same order, same checksums as the oracle; and the serial form agrees.
+    B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=miss)
+    ck, rows = oracle.equijoin(B, P)
+    ex.set_profiling(True)
+    try:
+        r = ex.join_host(B, P, H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+        assert ex.last_timing()["path"] & H.HMJ_PATH_HOST_PIPELINE
+        assert r.checks() == ck
+        assert np.array_equal(ex.columns_to_numpy(r, host=True), rows)
+        r = ex.join_host(B, P, H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE)  # count mode: nothing comes back but the sums
+        assert r.checks() == ck and int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+        ckf, _ = oracle.equijoin(B, P, first_wins=True, cap=0)
+        r = ex.join_host(B, P, H.HMJ_FIRST_WINS)
+        assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ckf["n_matches"], ckf["sum_r"], ckf["sum_s"])
+    finally:
+        ex.set_profiling(False)
+        ex.release_result()
+
+
+def test_placement_info_reports_the_probed_buffers(H):
+    # hmj_placement_info: what the bench line's `placement` object is made of.  Default: every big partition buffer of
+    # the slab path is listed with the fill rate of the allocation that was kept; HMJ_PLACE=0: nothing is probed.
+    import torch
+
+    assert torch.cuda.is_available()
+    for env, expect in (("4", True), ("0", False)):
+        os.environ["HMJ_PLACE"] = env
+        try:
+            e = H.Executor(0)
+        finally:
+            del os.environ["HMJ_PLACE"]
+        try:
+            n = 1 << 26  # slab buffers of 1.4-1.5 GB: above the 512 MiB from which an allocation is probed
+            R, S = e.gen_build(n), e.gen_probe(n, n)
+            r = e.join_device(R, S, 0)
+            assert int(r.n_matches) == n and e.last_timing()["path"] & H.HMJ_PATH_SLAB
+            info = e.placement_info()
+            if expect:
+                names = {b["name"] for b in info}
+                assert {"slab_a", "slab_b_build", "slab_b_probe"} <= names, info
+                for b in info:
+                    assert b["bytes"] >= 512 << 20 and 1.0 < b["fill_TBps"] < 8.0 and 1 <= b["candidates"] <= 4, b
+            else:
+                assert info == []
+            del R, S
+        finally:
+            e.close()
+
+
 def test_golden_joins_from_compiled_reference(ex, H, oracle, G, golden_dir):
     # inputs regenerated ON DEVICE; expected values come from the compiled reference's
     # HashMergeJoin (tests/golden/make_golden.py)
