@@ -75,12 +75,14 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
   // and while one fills slower than a good one does, another candidate is allocated (the previous one still held, so
   // it is other memory) and the best is kept.  At most c->place_tries candidates (HMJ_PLACE=n; 0 = take what comes).
   // Exchange buffers, result columns and upload targets are never probed (their (re)growth must not stall
-  // in-flight rounds with extra device-synchronising hipMalloc / hipFree calls).
+  // in-flight rounds with extra device-synchronising hipMalloc / hipFree calls), and nothing below 2 GiB is
+  // (HMJ_PLACE_MIN_MB): a fresh candidate costs ~30 ms per 1.5 GB (the driver clears new memory), so a 2^26-row
+  // join's one-shot host call took 374-407 ms with the search against 170 ms without it, for 0.1 ms per join.
   const char* pname = !c ? nullptr
                       : &b == &c->slab_a ? "slab_a" : &b == &c->slab_br ? "slab_b_build" : &b == &c->slab_bs ? "slab_b_probe"
                       : &b == &c->rbuf[0] ? "rbuf0" : &b == &c->rbuf[1] ? "rbuf1" : &b == &c->sbuf[0] ? "sbuf0"
                       : &b == &c->sbuf[1] ? "sbuf1" : nullptr;
-  if (c && c->place_tune && pname && want >= (512ull << 20)) {
+  if (c && c->place_tune && pname && want >= c->place_min_bytes) {
     if (!c->place_ev[0]) {
       if (hipEventCreate(&c->place_ev[0]) != hipSuccess || hipEventCreate(&c->place_ev[1]) != hipSuccess) {
         (void)hipGetLastError();
@@ -1379,6 +1381,10 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_PLACE")) {  // 0: off; n: at most n candidates per big allocation
     c->place_tune = atoi(e) != 0;
     if (atoi(e) > 0) c->place_tries = atoi(e);
+  }
+  if (const char* e = getenv("HMJ_PLACE_MIN_MB")) {
+    const long long mb = atoll(e);
+    if (mb >= 1) c->place_min_bytes = (size_t)mb << 20;
   }
   if (const char* e = getenv("HMJ_DENSE_PLAN")) c->dense_plan = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SORTED_WRITE")) {

@@ -68,6 +68,7 @@ struct hmj_ctx {
   hipEvent_t place_ev[2] = {nullptr, nullptr};
   double place_best = 0.0;  // best fill rate (bytes per ms) any probed allocation of this context reached
   bool place_tune = true;  // HMJ_PLACE=0: take the buffers as the driver hands them out
+  size_t place_min_bytes = 2048ull << 20;  // only allocations of this size and more are probed (HMJ_PLACE_MIN_MB)
   std::vector<hmj_place_info> place_log;  // one entry per probed buffer (hmj_placement_info)
   bool dense_plan = true;    // HMJ_DENSE_PLAN=0: never size the plan by the build keys' share of the key range
   int sorted_cooldown = 0;   // ordered joins left before the one-pass ordered write is tried again

@@ -175,7 +175,7 @@ def test_placement_info_reports_the_probed_buffers(H):
         finally:
             del os.environ["HMJ_PLACE"]
         try:
-            n = 1 << 26  # slab buffers of 1.4-1.5 GB: above the 512 MiB from which an allocation is probed
+            n = 1 << 27  # slab buffers of 2.8-3.0 GB: above the 2 GiB from which an allocation is probed
             R, S = e.gen_build(n), e.gen_probe(n, n)
             r = e.join_device(R, S, 0)
             assert int(r.n_matches) == n and e.last_timing()["path"] & H.HMJ_PATH_SLAB
@@ -184,7 +184,7 @@ def test_placement_info_reports_the_probed_buffers(H):
                 names = {b["name"] for b in info}
                 assert {"slab_a", "slab_b_build", "slab_b_probe"} <= names, info
                 for b in info:
-                    assert b["bytes"] >= 512 << 20 and 1.0 < b["fill_TBps"] < 8.0 and 1 <= b["candidates"] <= 4, b
+                    assert b["bytes"] >= 2048 << 20 and 1.0 < b["fill_TBps"] < 8.0 and 1 <= b["candidates"] <= 4, b
             else:
                 assert info == []
             del R, S
