@@ -521,6 +521,14 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
     // (it then spills them and reloads each behind s_waitcnt vmcnt(0): see probe_write_sorted_kernel)
     int tid = tid_outer;
     if constexpr (OUT != 0) asm volatile("" : "+v"(tid));
+    // write mode, slab layout: this partition's first output slot through the SCALAR cache (item_base was written by an
+    // earlier kernel).  As a vector load at its point of use it sat behind the prefetch of the next partition's build
+    // rows in the vmcnt queue and the copy-out waited for them (s_waitcnt vmcnt(0); see probe_write_sorted_kernel).
+    u64 out_base = (u64)sb;
+    if constexpr (OUT == 1 && SLAB) {
+      const u64* ibp = a.item_base + p;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(out_base) : "s"(ibp) : "memory");
+    }
     const u32 pn = __builtin_amdgcn_readfirstlane(p + gridDim.x);  // keep the offsets on the scalar path
     u32 rb2 = 0, nb2 = 0, sb2 = 0, np2 = 0;
     bool regular2 = false;
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_count_fast_kernel(
           if (dup) {
             giveup = true;  // duplicate build keys here: not the unique-key case
           } else {
-            u64 o = SLAB ? a.item_base[p] : (u64)sb;
+            u64 o = out_base;
             u32 total = 0;
 #pragma unroll
             for (int k = 0; k < FP_ROWS; k++) {
@@ -1049,211 +1057,200 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
 #pragma unroll
     for (int r = 0; r < WROUNDS; r++) wpre[r] = 0;
     bool sorted_ok = false;
-    if (regular) {
-      {  // exclusive scan of the bucket counts, BPT per thread (and the counts go back to zero for the next partition)
-        u32 c[BPT], sum = 0, mx = 0;
+    // The phases below are guarded one by one instead of nested in one `if (regular) ... else ...`: the prefetches of
+    // the next partition's rows then have ONE call site each.  With a call site per branch the loaded rows of the
+    // branches met in a phi, the register allocator gave them registers other than the loop header's, and the copies
+    // at the loop's back edge waited for every load and store in flight (s_waitcnt vmcnt(0)) once per partition.
+    if (regular) {  // exclusive scan of the bucket counts, BPT per thread (and the counts go back to zero for the next partition)
+      u32 c[BPT], sum = 0, mx = 0;
 #pragma unroll
-        for (u32 q = 0; q < BPT; q++) {
-          c[q] = sm.cnt[tid * BPT + q];
-          sm.cnt[tid * BPT + q] = 0;
+      for (u32 q = 0; q < BPT; q++) {
+        c[q] = sm.cnt[tid * BPT + q];
+        sm.cnt[tid * BPT + q] = 0;
+        sum += c[q];
+        mx = c[q] > mx ? c[q] : mx;
+      }
+      if (mx > (u32)SW_MAXBUCKET) (&sm.flag)[zero] = 1;
+      u32 tot;
+      u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &tot, tid);  // (a barrier follows below)
+#pragma unroll
+      for (u32 q = 0; q < BPT; q++) {
+        sm.bstart[tid * BPT + q] = (u16)ex;
+        ex += c[q];
+      }
+      if (tid == THREADS - 1) sm.bstart[tid * BPT + BPT] = (u16)ex;  // = bstart[NB] = nb: the end of the last bucket
+      lds_barrier();
+    }
+    if constexpr (!FK) {
+      if (regular && sm.flag == 0) {  // uniform
+        // key and payload go to their bucket, in order of arrival.  A row's sorted rank -- its bucket's start plus
+        // the number of smaller keys in the bucket -- is what the output order needs; the probe row that matches it
+        // scans the whole bucket anyway and counts them on the way, so the build rows are never moved again.
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+          const u32 i = k * THREADS + tid;
+          if (i < nb) {
+            const u32 pos = (u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12);
+            sm.key[pos] = br[k].key;
+            sm.val[pos] = br[k].val;
+          }
+        }
+      }
+    } else {
+      // ---- foreign-key form: the build rows are sorted for real (position = sorted rank)
+      u64* tmpkey = sm.sval;  // keys in bucket / arrival order (sval is free until the payloads are dropped)
+      if (regular && sm.flag == 0) {  // uniform
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+          const u32 i = k * THREADS + tid;
+          if (i < nb) tmpkey[(u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12)] = br[k].key;
+        }
+      }
+      if (regular) lds_barrier();
+      if (regular && sm.flag == 0) {
+        bool dupb = false;
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+          const u32 i = k * THREADS + tid;
+          if (i < nb) {
+            const u32 h = ha[k] & (NB - 1), b0 = sm.bstart[h], b1 = sm.bstart[h + 1], mine = b0 + (ha[k] >> 12);
+            u32 less = 0;
+            for (u32 t = b0; t < b1; t++) {  // (a bucket holds a handful of keys: <= SW_MAXBUCKET, flagged above)
+              const u64 kk = tmpkey[t];
+              less += kk < br[k].key ? 1u : 0u;
+              dupb |= kk == br[k].key && t != mine;
+            }
+            sm.key[b0 + less] = br[k].key;
+            sm.val[b0 + less] = br[k].val;
+          }
+        }
+        if (dupb) (&sm.flag)[zero] = 3;  // two build rows with one key: not this kernel's case
+      }
+    }
+    load_next_build();              // (the only call site)
+    if (regular) lds_barrier();     // table complete (foreign-key form: and tmpkey is dead)
+    u32 found[FK ? ROWS : 1], slot[FK ? ROWS : 1];  // foreign-key form: a probe row's match, sorted rank + 1 (0 = none); its arrival number in the key's run
+#pragma unroll
+    for (int k = 0; k < (FK ? ROWS : 1); k++) found[k] = slot[k] = 0;
+    if constexpr (!FK) {
+      if (regular && sm.flag == 0) {
+        // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap).  Per row one packed
+        // word: smaller keys seen (bits 0-5), step of the match (6-11), matches (12-13)
+        u32 cur[ROWS], len[ROWS], st[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+          const u32 j = k * THREADS + tid;
+          cur[k] = len[k] = st[k] = 0;
+          if (j < np) {
+            if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+            if (EXTRA) acc_p += pr[k].val;
+            const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
+            cur[k] = sm.bstart[hh];
+            len[k] = (u32)sm.bstart[hh + 1] - cur[k];
+          }
+        }
+        for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
+          bool any = false;
+#pragma unroll
+          for (int k = 0; k < ROWS; k++) any |= step < len[k];
+          if (!__any(any)) break;
+#pragma unroll
+          for (int k = 0; k < ROWS; k++) {
+            if (step < len[k]) {
+              const u64 kk = sm.key[cur[k] + step];
+              st[k] += kk < pr[k].key ? 1u : 0u;
+              if (kk == pr[k].key) st[k] = (st[k] & ~(63u << 6)) + (step << 6) + (1u << 12);
+            }
+          }
+        }
+        bool dup = false, dupb = false;
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+          const u32 hits = st[k] >> 12;
+          if (hits) {
+            const u32 si = cur[k] + (st[k] & 63u), bit = 1u << (si & 31);  // the matched build row's sorted rank
+            const u32 mpos = cur[k] + ((st[k] >> 6) & 63u);
+            dupb |= hits > 1;                                            // two build rows with this key
+            dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
+            sm.sval[si] = pr[k].val;
+            sm.perm[si] = (u16)mpos;
+            acc_n++;
+            acc_s += pr[k].val;
+            if (EXTRA) {
+              const u64 m = tmix(pr[k].key, sm.val[mpos], pr[k].val);
+              acc_x ^= m;
+              acc_m += m;
+            }
+          }
+        }
+        if (dup) (&sm.flag)[zero] = 2;
+        if (dupb) (&sm.flag)[zero] = 3;
+      }
+    } else {
+      if (regular && sm.flag == 0) {
+        u32 cur[ROWS], len[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+          const u32 j = k * THREADS + tid;
+          cur[k] = len[k] = 0;
+          if (j < np) {
+            if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+            if (EXTRA) acc_p += pr[k].val;
+            const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
+            cur[k] = sm.bstart[hh];
+            len[k] = (u32)sm.bstart[hh + 1] - cur[k];
+          }
+        }
+        for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
+          bool any = false;
+#pragma unroll
+          for (int k = 0; k < ROWS; k++) any |= step < len[k];
+          if (!__any(any)) break;
+#pragma unroll
+          for (int k = 0; k < ROWS; k++) {
+            if (step < len[k] && sm.key[cur[k] + step] == pr[k].key) {
+              found[k] = cur[k] + step + 1;
+              len[k] = 0;  // (keys are unique in the table: done)
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+          if (found[k]) {
+            slot[k] = atomicAdd(&sm.mcnt[found[k] - 1], 1u);  // arrival number among the probe rows of the key
+            acc_n++;
+            acc_s += pr[k].val;
+            if (EXTRA) {
+              const u64 m = tmix(pr[k].key, sm.val[found[k] - 1], pr[k].val);
+              acc_x ^= m;
+              acc_m += m;
+            }
+          }
+        }
+      }
+      if (regular) lds_barrier();
+      if (regular && sm.flag == 0) {  // uniform
+        // every build row's run of output slots: exclusive scan of the match counts in sorted build order
+        u32 c[ROWS], sum = 0, mx = 0;
+#pragma unroll
+        for (int q = 0; q < ROWS; q++) {
+          const u32 i = (u32)tid * ROWS + q;
+          c[q] = i < CAPB ? sm.mcnt[i] : 0u;
           sum += c[q];
           mx = c[q] > mx ? c[q] : mx;
         }
-        if (mx > (u32)SW_MAXBUCKET) (&sm.flag)[zero] = 1;
-        u32 tot;
-        u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &tot, tid);  // (a barrier follows below)
+        if (mx > (u32)SWF_MAXDUP) sm.mcnt[CAPB + 1] = 1;  // (its own word: sm.flag is being read by slower threads right now)
+        if (mx > 1) sm.mcnt[CAPB] = 1;
+        u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &total, tid);  // (a barrier follows below)
 #pragma unroll
-        for (u32 q = 0; q < BPT; q++) {
-          sm.bstart[tid * BPT + q] = (u16)ex;
+        for (int q = 0; q < ROWS; q++) {
+          const u32 i = (u32)tid * ROWS + q;
+          if (i < CAPB) sm.mcnt[i] = ex;
           ex += c[q];
         }
-        if (tid == THREADS - 1) sm.bstart[tid * BPT + BPT] = (u16)ex;  // = bstart[NB] = nb: the end of the last bucket
+        lds_barrier();
       }
-      lds_barrier();
-      if constexpr (!FK) {
-        if (sm.flag == 0) {  // uniform
-          // key and payload go to their bucket, in order of arrival.  A row's sorted rank -- its bucket's start plus
-          // the number of smaller keys in the bucket -- is what the output order needs; the probe row that matches it
-          // scans the whole bucket anyway and counts them on the way, so the build rows are never moved again.
-#pragma unroll
-          for (int k = 0; k < ROWS; k++) {
-            const u32 i = k * THREADS + tid;
-            if (i < nb) {
-              const u32 pos = (u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12);
-              sm.key[pos] = br[k].key;
-              sm.val[pos] = br[k].val;
-            }
-          }
-        }
-        load_next_build();
-        lds_barrier();  // table complete
-        if (sm.flag == 0) {
-          // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap).  Per row one packed
-          // word: smaller keys seen (bits 0-5), step of the match (6-11), matches (12-13)
-          u32 cur[ROWS], len[ROWS], st[ROWS];
-#pragma unroll
-          for (int k = 0; k < ROWS; k++) {
-            const u32 j = k * THREADS + tid;
-            cur[k] = len[k] = st[k] = 0;
-            if (j < np) {
-              if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-              if (EXTRA) acc_p += pr[k].val;
-              const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
-              cur[k] = sm.bstart[hh];
-              len[k] = (u32)sm.bstart[hh + 1] - cur[k];
-            }
-          }
-          for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < ROWS; k++) any |= step < len[k];
-            if (!__any(any)) break;
-#pragma unroll
-            for (int k = 0; k < ROWS; k++) {
-              if (step < len[k]) {
-                const u64 kk = sm.key[cur[k] + step];
-                st[k] += kk < pr[k].key ? 1u : 0u;
-                if (kk == pr[k].key) st[k] = (st[k] & ~(63u << 6)) + (step << 6) + (1u << 12);
-              }
-            }
-          }
-          bool dup = false, dupb = false;
-#pragma unroll
-          for (int k = 0; k < ROWS; k++) {
-            const u32 hits = st[k] >> 12;
-            if (hits) {
-              const u32 si = cur[k] + (st[k] & 63u), bit = 1u << (si & 31);  // the matched build row's sorted rank
-              const u32 mpos = cur[k] + ((st[k] >> 6) & 63u);
-              dupb |= hits > 1;                                            // two build rows with this key
-              dup |= (atomicOr(&sm.mbits[par][si >> 5], bit) & bit) != 0;  // two probe rows with this key
-              sm.sval[si] = pr[k].val;
-              sm.perm[si] = (u16)mpos;
-              acc_n++;
-              acc_s += pr[k].val;
-              if (EXTRA) {
-                const u64 m = tmix(pr[k].key, sm.val[mpos], pr[k].val);
-                acc_x ^= m;
-                acc_m += m;
-              }
-            }
-          }
-          if (dup) (&sm.flag)[zero] = 2;
-          if (dupb) (&sm.flag)[zero] = 3;
-        }
-        load_next_probe();
-        lds_barrier();
-        sorted_ok = sm.flag == 0;
-        if (!sorted_ok) giveup = true;
-        // matched rows before every bitmap word, and the partition's row count: every wave scans the 160 words for
-        // itself (lane l keeps the prefixes of words l, l + 64, l + 128), so nobody waits for anybody
-        u32 run = 0;
-#pragma unroll
-        for (int r = 0; r < WROUNDS; r++) {
-          const u32 w = (u32)r * kWave + lane;
-          const u32 c = (sorted_ok && w < WORDS) ? (u32)__popc(sm.mbits[par][w]) : 0u;
-          const u32 incl = wave_incl_scan_u32(c, lane);
-          wpre[r] = run + incl - c;
-          run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        total = run;
-      } else {
-        // ---- foreign-key form: the build rows are sorted for real (position = sorted rank)
-        u64* tmpkey = sm.sval;  // keys in bucket / arrival order (sval is free until the payloads are dropped)
-        if (sm.flag == 0) {     // uniform
-#pragma unroll
-          for (int k = 0; k < ROWS; k++) {
-            const u32 i = k * THREADS + tid;
-            if (i < nb) tmpkey[(u32)sm.bstart[ha[k] & (NB - 1)] + (ha[k] >> 12)] = br[k].key;
-          }
-        }
-        lds_barrier();
-        if (sm.flag == 0) {
-          bool dupb = false;
-#pragma unroll
-          for (int k = 0; k < ROWS; k++) {
-            const u32 i = k * THREADS + tid;
-            if (i < nb) {
-              const u32 h = ha[k] & (NB - 1), b0 = sm.bstart[h], b1 = sm.bstart[h + 1], mine = b0 + (ha[k] >> 12);
-              u32 less = 0;
-              for (u32 t = b0; t < b1; t++) {  // (a bucket holds a handful of keys: <= SW_MAXBUCKET, flagged above)
-                const u64 kk = tmpkey[t];
-                less += kk < br[k].key ? 1u : 0u;
-                dupb |= kk == br[k].key && t != mine;
-              }
-              sm.key[b0 + less] = br[k].key;
-              sm.val[b0 + less] = br[k].val;
-            }
-          }
-          if (dupb) (&sm.flag)[zero] = 3;  // two build rows with one key: not this kernel's case
-        }
-        load_next_build();
-        lds_barrier();  // the sorted table is complete (and tmpkey is dead)
-        u32 found[ROWS], slot[ROWS];  // a probe row's match: sorted rank + 1 (0 = none); arrival number in its key's run
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) found[k] = slot[k] = 0;
-        if (sm.flag == 0) {
-          u32 cur[ROWS], len[ROWS];
-#pragma unroll
-          for (int k = 0; k < ROWS; k++) {
-            const u32 j = k * THREADS + tid;
-            cur[k] = len[k] = 0;
-            if (j < np) {
-              if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-              if (EXTRA) acc_p += pr[k].val;
-              const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
-              cur[k] = sm.bstart[hh];
-              len[k] = (u32)sm.bstart[hh + 1] - cur[k];
-            }
-          }
-          for (u32 step = 0; step < (u32)SW_MAXBUCKET; step++) {
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < ROWS; k++) any |= step < len[k];
-            if (!__any(any)) break;
-#pragma unroll
-            for (int k = 0; k < ROWS; k++) {
-              if (step < len[k] && sm.key[cur[k] + step] == pr[k].key) {
-                found[k] = cur[k] + step + 1;
-                len[k] = 0;  // (keys are unique in the table: done)
-              }
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < ROWS; k++) {
-            if (found[k]) {
-              slot[k] = atomicAdd(&sm.mcnt[found[k] - 1], 1u);  // arrival number among the probe rows of the key
-              acc_n++;
-              acc_s += pr[k].val;
-              if (EXTRA) {
-                const u64 m = tmix(pr[k].key, sm.val[found[k] - 1], pr[k].val);
-                acc_x ^= m;
-                acc_m += m;
-              }
-            }
-          }
-        }
-        lds_barrier();
-        if (sm.flag == 0) {  // uniform
-          // every build row's run of output slots: exclusive scan of the match counts in sorted build order
-          u32 c[ROWS], sum = 0, mx = 0;
-#pragma unroll
-          for (int q = 0; q < ROWS; q++) {
-            const u32 i = (u32)tid * ROWS + q;
-            c[q] = i < CAPB ? sm.mcnt[i] : 0u;
-            sum += c[q];
-            mx = c[q] > mx ? c[q] : mx;
-          }
-          if (mx > (u32)SWF_MAXDUP) sm.mcnt[CAPB + 1] = 1;  // (its own word: sm.flag is being read by slower threads right now)
-          if (mx > 1) sm.mcnt[CAPB] = 1;
-          u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &total, tid);  // (a barrier follows below)
-#pragma unroll
-          for (int q = 0; q < ROWS; q++) {
-            const u32 i = (u32)tid * ROWS + q;
-            if (i < CAPB) sm.mcnt[i] = ex;
-            ex += c[q];
-          }
-          lds_barrier();
-        }
+      if (regular) {
         sorted_ok = sm.flag == 0 && sm.mcnt[CAPB + 1] == 0;
         if (sorted_ok) {
           // payload and sorted rank to the key's run, in arrival order
@@ -1270,9 +1267,29 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           if (sm.flag == 0) why |= 2048u;
           total = 0;
         }
-        load_next_probe();
       }
-    } else {
+    }
+    load_next_probe();              // (the only call site; a no-op in the shapes that ask at the top of the iteration)
+    if constexpr (!FK) {
+      if (regular) {
+        lds_barrier();
+        sorted_ok = sm.flag == 0;
+        if (!sorted_ok) giveup = true;
+        // matched rows before every bitmap word, and the partition's row count: every wave scans the 160 words for
+        // itself (lane l keeps the prefixes of words l, l + 64, l + 128), so nobody waits for anybody
+        u32 run = 0;
+#pragma unroll
+        for (int r = 0; r < WROUNDS; r++) {
+          const u32 w = (u32)r * kWave + lane;
+          const u32 c = (sorted_ok && w < WORDS) ? (u32)__popc(sm.mbits[par][w]) : 0u;
+          const u32 incl = wave_incl_scan_u32(c, lane);
+          wpre[r] = run + incl - c;
+          run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        total = run;
+      }
+    }
+    if (!regular) {
       if (nb && np) {  // does not fit the pipeline
         giveup = true;
         why |= 512u;
@@ -1289,8 +1306,6 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           for (u32 j = tid; j < np; j += THREADS) acc_p += S[sb + j].val;
         }
       }
-      load_next_build();
-      load_next_probe();
     }
     // every partition publishes its count (zero if it has no rows or gave up): its successors wait for it
     // chained: the rows of all partitions before this one (wave 0 finds out, the others wait); slots: the

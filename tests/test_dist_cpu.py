@@ -307,7 +307,8 @@ dist.destroy_process_group()
 
 @pytest.mark.parametrize("world,nb,npb,miss,kind,rounds", [
     (2, 5000, 7000, 3, "uniform", 1), (4, 1 << 14, 1 << 14, 0, "uniform", 4), (3, 9000, 9001, 4, "uniform", 16),
-    (4, 20000, 15000, 0, "dense", 3), (2, 6000, 9000, 2, "dup", 5), (4, 1 << 13, 3000, 2, "dup", 2)])
+    (4, 20000, 15000, 0, "dense", 3), (2, 6000, 9000, 2, "dup", 5), (4, 1 << 13, 3000, 2, "dup", 2),
+    (8, 1 << 15, 40000, 3, "uniform", 4)])
 def test_digit_owner_exchange_over_gloo(oracle, tmp_path, world, nb, npb, miss, kind, rounds):
     # Round 3's path: the first radix pass's digit is the owner (contiguous digit ranges chosen from the pooled key
     # sample), rounds carry digit sub-ranges, and every arrived round is joined on its own.  Real bytes between real

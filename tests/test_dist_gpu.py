@@ -148,6 +148,7 @@ def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
                                                             (2, 1 << 21, 1 << 22, 5, 1, 1 << 20), (2, 9 << 20, (9 << 20) + 10, 0, 0, 1 << 24),
                                                             (2, 300000, 250000, 0, 2, 0), (3, 700000, 500000, 2, 0, 1 << 19),
                                                             (2, 300000, 270000, 0, 3, 0), (4, 1 << 20, 1 << 21, 3, 3, 1 << 20),
+                                                            (5, 900000, 700001, 4, 0, 1 << 19),  # (five ranks + this process: the box allows six on its GPU)
                                                             (2, 34 << 19, 36 << 20, 0, 0, 0)])
 def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup, maxmsg):
     res = run_world(tmp_path, world, nb, npb, miss, dup, maxmsg)
