@@ -1713,7 +1713,10 @@ static int join_host_impl(hmj_ctx* c, const void* build_aos_host, uint64_t n_bui
   int st = span_begin(c, K_TOTAL, -1);
   HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_ev[kChunks], 0));  // R is on the device
   c->sample_build_only = true;  // (the key sample must not read probe rows that are still on the link)
-  rc = prepare_build(c, c->in_r.p, n_build, n_probe);
+  // (a materialising join with the larger probe side plans by the probe rows: a build side prepared for the count
+  //  plan would only be partitioned a second time)
+  const bool prep_pays = !((flags & (HMJ_MATERIALIZE | HMJ_ORDERED)) && n_probe > n_build);
+  rc = prep_pays ? prepare_build(c, c->in_r.p, n_build, n_probe) : HMJ_OK;
   if (rc == HMJ_OK) {
     c->arrive_rows.assign(ends.begin(), ends.end());
     c->arrive_ev.assign(c->copy_ev.begin(), c->copy_ev.begin() + kChunks);
