@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -308,6 +309,24 @@ void spans_collect(hmj_ctx* c) {  // call after the stream is synchronized
 // Partition count: enough most-significant key bits that an average build partition holds
 // <= PB_TARGET_AVG rows and so fits the LDS table of probe.hip (the reference's optimal_partition,
 // radix_hash.h:38-57, sizes for CPU caches instead).  Passes: LSD order, <= RP_MAX_BITS each.
+// The most probe rows ANY of P partitions is expected to hold in a foreign-key join: a partition gets N ~ Poisson(lam)
+// build keys (lam = avg_np / f) and about f probe rows for each.  N's upper quantile at 0.05 / P is found by summing
+// the Poisson tail (the normal approximation "mean + 5 sigma" is 15 % short at lam = 8: fan-out 256 was planned into
+// partitions that did not fit, and the whole join fell back to the two-step ordered form); the rows-per-key noise is
+// added in quadrature.
+double fk_probe_rows_hi(double avg_np, double f, double P) {
+  if (avg_np <= 0.0 || f <= 0.0) return 0.0;
+  const double lam = avg_np / f, p_tail = 0.05 / (P > 1.0 ? P : 1.0);
+  const double step = lam > 256.0 ? std::floor(std::sqrt(lam) / 8.0) : 1.0;
+  double k = std::floor(lam);
+  for (const double k_end = lam + 40.0 * std::sqrt(lam) + 100.0; k < k_end; k += step) {
+    const double lp = -lam + (k + 1.0) * std::log(lam) - std::lgamma(k + 2.0);  // log P(N = k + 1)
+    if (std::exp(lp) / (1.0 - lam / (k + 2.0)) <= p_tail) break;                // (geometric bound on P(N > k))
+  }
+  const double z = (k - lam) / std::sqrt(lam), from_keys = (k - lam) * f, from_rows = z * std::sqrt(avg_np);
+  return avg_np + std::sqrt(from_keys * from_keys + from_rows * from_rows);
+}
+
 void plan_bits(u64 n_build, int force, int* total, int* passes, int pass_bits[4]) {
   int B = 0;
   if (force >= 0) {
@@ -587,7 +606,7 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     int shape = 0;
     if (fk && nb > 0 && P > 0) {
       const double avg_np = (double)np / (double)P, avg_nb = (double)nb / (double)P, f = (double)np / (double)nb;
-      const double hi_np = avg_np + 5.0 * __builtin_sqrt(f * avg_np), hi_nb = avg_nb + 6.0 * __builtin_sqrt(avg_nb) + 8.0;
+      const double hi_np = fk_probe_rows_hi(avg_np, f, (double)P), hi_nb = avg_nb + 6.0 * __builtin_sqrt(avg_nb) + 8.0;
       half = !no_half && f >= 2.0 && hi_np <= 3072.0 && hi_nb <= 2048.0;
       shape = half ? 1 : (fk_wide_plan && hi_nb <= 2560.0) ? 2 : 0;
     }
@@ -777,18 +796,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
                          c->sorted_wide && c->sorted_cooldown <= 1 && f >= 2.5;
     const int B_narrow = [&] {
       int b = Bp;
-      while (b < 18) {
-        const double avg = (double)np_plan / (double)(1ull << b);
-        if (avg + 5.0 * __builtin_sqrt(f * avg) <= 5056.0) break;
-        b++;
-      }
+      while (b < 18 && fk_probe_rows_hi((double)np_plan / (double)(1ull << b), f, (double)(1ull << b)) > 5120.0) b++;
       return b;
     }();
-    while (Bp < 18) {
-      const double avg = (double)np_plan / (double)(1ull << Bp);
-      if (avg + 5.0 * __builtin_sqrt(f * avg) <= (wide_ok ? 6016.0 : 5056.0)) break;
-      Bp++;
-    }
+    while (Bp < 18 && fk_probe_rows_hi((double)np_plan / (double)(1ull << Bp), f, (double)(1ull << Bp)) > (wide_ok ? 6144.0 : 5120.0)) Bp++;
     fk_wide_plan = wide_ok && Bp < B_narrow;
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 16 && slab_ok)))
@@ -1122,7 +1133,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // one partition holds most of the rows -- and only partitions of more than four slices are cut.
     u32 slice = probe_fits ? 4096u : np / 2048u;
     if (!probe_fits && slice < 16384u) slice = 16384u;
-    const u32 thr = probe_fits ? 5120u : 4u * slice;
+    const u32 thr = probe_fits ? (fk_wide_plan ? 6144u : 5120u) : 4u * slice;  // (the one-pass ordered write's partition capacity)
     // modes that enumerate every pair (materialise, checksums) and are not first-wins also cut partitions with
     // thousands of copies of a key on the build side: the cross product of a hot key is then written by many
     // workgroups (each build slice meets every probe slice of the partition)

@@ -855,6 +855,7 @@ struct SortedFkSmem {
 static_assert(sizeof(SortedFkSmem<SWF_HALF_THREADS, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>) <= 80 * 1024, "two workgroups per CU");
 static_assert(SWF_HALF_CAPB <= SWF_HALF_THREADS * SWF_HALF_ROWS, "tmpkey aliases sval");
 static_assert(sizeof(SortedFkSmem<1024, SWF_WIDE_ROWS, SWF_WIDE_CAPB, SWF_LOGB>) <= 160 * 1024, "one workgroup per CU");
+static_assert((SWF_HALF_CAPB + 2) * 4 + SWF_HALF_THREADS * SWF_HALF_ROWS * 2 >= (SWF_MAXDUP + 8) * 8, "the run ranking reads up to a run past sval[]");
 
 // Publish partition p's row count and return the number of result rows of partitions 0 .. p-1.  Called by one
 // whole wave: lane l inspects partition p-1-l, 64 predecessors per round, back to the nearest one that has
@@ -1345,16 +1346,21 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           }
           u32 r = j - base;  // (runs of one row, or no repeating key in the partition: the slot is final)
           if (rank_runs) {
+            // rank = payloads of the run below mine + equal ones in earlier slots.  Eight reads per step at constant
+            // offsets from one address (unclamped: a read past the run's end is ignored, one past sval[] lands in the
+            // arrays behind it -- a run is at most SWF_MAXDUP rows); round 2's form clamped every index and spent 18
+            // instructions per pair, which made fan-outs from 64 on compute-bound (profiles/r03c_side_ordered_kernels.txt)
+            const u32 rel = j - base;
+            const u64* rp = &sm.sval[base];
             r = 0;
-            const u32 last = c ? c - 1 : 0;
-            for (u32 t = 0; __any(t < c); t += 4) {  // four independent reads per step (clamped into the run)
-              u64 o[4];
+            for (u32 t = 0; __any(t < c); t += 8) {
+              u64 o[8];
 #pragma unroll
-              for (int u = 0; u < 4; u++) o[u] = sm.sval[base + (t + u < last ? t + u : last)];
+              for (int u = 0; u < 8; u++) o[u] = rp[t + u];
 #pragma unroll
-              for (int u = 0; u < 4; u++) {
+              for (int u = 0; u < 8; u++) {
                 const u32 at = t + u;
-                if (at < c) r += (o[u] < v || (o[u] == v && base + at < j)) ? 1u : 0u;
+                r += ((at < c) & ((o[u] < v) | ((o[u] == v) & (at < rel)))) ? 1u : 0u;
               }
             }
           }

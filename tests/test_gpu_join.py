@@ -1019,6 +1019,14 @@ def test_one_pass_ordered_write(ex_fresh, H, oracle):
         for _ in range(2):
             t = run(Bf, Pf)
             assert t["path"] & H.HMJ_PATH_SORTED_FK and t["ms_order"] == 0.0, hex(t["path"])
+    # long runs (fan-out 64 and 256), and payloads that tie heavily inside every run (seven distinct values)
+    for npf, dom, ties in [(1 << 22, 1 << 16, False), (1 << 22, 1 << 16, True), (3000000, 1 << 14, False), (1 << 21, 1 << 13, True)]:
+        Bf = oracle.gen_build(dom)
+        Pf = oracle.gen_uniform_domain(npf, dom)
+        if ties:
+            Pf[:, 1] %= np.uint64(7)
+        t = run(Bf, Pf)
+        assert t["path"] & H.HMJ_PATH_SORTED_FK and t["ms_order"] == 0.0, hex(t["path"])
     # ... with unmatched probe rows (keys outside the build side's domain)
     Pm = oracle.gen_uniform_domain(900000, 300000)
     t = run(oracle.gen_build(200000), Pm)
