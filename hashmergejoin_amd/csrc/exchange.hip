@@ -167,7 +167,9 @@ int comm_ensure(hmj_ctx* c) {
 // all ranks learn every rank's `count` values: recv[r * count + i] = rank r's send[i].  Host memory, blocking.
 int transport_allgather(hmj_ctx* c, const u64* send, u64* recv, int count) {
   hmj_comm* m = c->comm;
-  if (m->n_ranks == 1) {
+  // (one rank: nothing to gather -- except in the forced self-exchange of the tests, which then also drives
+  //  ncclAllGather, its device staging and its stream order on the one GPU a test box has)
+  if (m->n_ranks == 1 && !(m->self_exchange && !m->has_cb && m->nccl)) {
     std::memcpy(recv, send, (size_t)count * 8);
     return HMJ_OK;
   }
