@@ -151,6 +151,14 @@ def extra_runs(ex, H, torch):
     assert int(r.n_matches) == 1 << 28
     out["fk_2p24_x_2p28_ordered_ms"] = ms
     ex.release_result()
+    # ... and with runs of 64 probe rows per key (the run ranking is linear in the run length: DESIGN section 6)
+    del Rf, Sf
+    Rf = ex.gen_build(1 << 22)
+    Sf = ex.gen_uniform_domain(1 << 28, 1 << 22)
+    ms, r = timed(lambda: ex.join_device(Rf, Sf, H.HMJ_ORDERED), reps=2)
+    assert int(r.n_matches) == 1 << 28
+    out["fk_2p22_x_2p28_ordered_ms"] = ms
+    ex.release_result()
     del R, Rf, Sf
     torch.cuda.empty_cache()
     # configs[4]: Zipf(0.9) build side of 2^24 rows over 2^24 distinct values, probe 2^30 uniform over the domain
