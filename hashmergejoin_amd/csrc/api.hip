@@ -345,9 +345,8 @@ void plan_bits(u64 n_build, int force, int* total, int* passes, int pass_bits[4]
   *passes = np;
 }
 
-// Sizes for which the histogram-free slab partitioning pays: the larger relation has at least slab_min_rows
-// rows (2^25) and the smaller one at least a quarter-million tiles' worth (2^22; its share of the time is
-// small either way).  Below that the exact path is faster.
+// Sizes for which the histogram-free slab partitioning pays: both relations have at least slab_min_rows rows
+// (2^21: every size that plans two passes; hmj_ctx.h has the measurements).
 static inline bool slab_sizes_ok(const hmj_ctx* c, u64 nb, u64 np) {
   const u64 big = nb > np ? nb : np, small = nb > np ? np : nb;
   const u64 small_min = c->slab_min_rows < (1u << 22) ? c->slab_min_rows : (1u << 22);

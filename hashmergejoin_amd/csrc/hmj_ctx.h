@@ -88,8 +88,11 @@ struct hmj_ctx {
   std::vector<hipEvent_t> copy_ev;
   bool split_mode = true;      // HMJ_SPLIT=0: never split oversized probe partitions
   bool window_mode = true;     // HMJ_WINDOW=0: always partition right below the shared key prefix
-  u32 slab_min_rows = 1u << 25;  // per relation; below, the exact path is faster (measured: 2^22 0.33 vs 0.45 ms,
-                                 // 2^24 0.80 vs 0.84 ms, 2^26 3.03 vs 2.35 ms).  HMJ_SLAB_MIN_LOG2 overrides (tests).
+  u32 slab_min_rows = 1u << 21;  // per relation: every size that plans two passes.  (Round 1 measured the exact path
+                                 // faster below 2^25 -- 2^22 0.33 vs 0.45 ms -- and the threshold stayed there while the slab
+                                 // kernels got faster; round 3's size sweep, tools/exp_cliffs.py, count mode, exact vs slab:
+                                 // 2.7 M rows 0.295 vs 0.251 ms, 2^22 0.359 vs 0.304, 2^24 0.827 vs 0.651, 28.5 M 1.345 vs
+                                 // 0.970; ordered and materialising joins alike.)  HMJ_SLAB_MIN_LOG2 overrides (tests).
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
   u32 slab_probe_kb = 0;  // HMJ_SLAB_PROBE_KB: pieces per partition of the probe-side slabs (0 = 512 >> bits of pass A)
   int slab_probe_cooldown = 0;  // the same for the probe-side-only slab partitioning of probe-heavy count joins
