@@ -94,6 +94,8 @@ struct hmj_ctx {
                                  // 2.7 M rows 0.295 vs 0.251 ms, 2^22 0.359 vs 0.304, 2^24 0.827 vs 0.651, 28.5 M 1.345 vs
                                  // 0.970; ordered and materialising joins alike.)  HMJ_SLAB_MIN_LOG2 overrides (tests).
   int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
+  int exact_prefix_joins = 0;  // ordered joins that still take the shared key prefix from a pass over ALL keys: the
+                               // sample of an earlier join missed a few keys above an otherwise dense range
   u32 slab_probe_kb = 0;  // HMJ_SLAB_PROBE_KB: pieces per partition of the probe-side slabs (0 = 512 >> bits of pass A)
   int slab_probe_cooldown = 0;  // the same for the probe-side-only slab partitioning of probe-heavy count joins
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)

@@ -55,7 +55,8 @@ struct SlabGeom {
 };
 // kb: pieces per final partition (0 = 4, what the pipelined probe kernel reads)
 // fan: expected rows per distinct key (>= 1): widens the slabs by sqrt(fan) standard deviations
-bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb = 0, double fan = 1.0);
+// density: the populated partitions hold this many times the mean (keys that fill only part of the key range)
+bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb = 0, double fan = 1.0, double density = 1.0);
 // slab_*_rows / cnt_*_n: what the caller ALLOCATED (rows of 16 bytes, u32 entries).  The launchers compare them with
 // what the kernel and its grid will touch for this geometry and refuse (hipErrorInvalidValue) instead of launching
 // a kernel that would write past a buffer.
@@ -64,6 +65,7 @@ hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabG
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
                          const SlabGeom& g, void* slab_b, u64 slab_b_rows, u32* cnt_b, u64 cnt_b_n, u64* accum, hipStream_t st);
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st);
+hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st);
 hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st);
 
 // probe.hip

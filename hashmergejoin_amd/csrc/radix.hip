@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
   __shared__ unsigned long long rng[2];  // smallest / largest sampled build key
   __shared__ u32 bins[64];               // sampled build keys per 64th of that range
   __shared__ u32 same[2];
+  __shared__ u32 order[4];  // ascending / descending neighbouring sample pairs of R, of S
   const int tid = threadIdx.x, lane = tid & 63;
   const u64* rk = reinterpret_cast<const u64*>(R);
   const u64* sk = reinterpret_cast<const u64*>(S);
@@ -1133,12 +1134,13 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
     rng[1] = 0;
   }
   if (tid < 2) same[tid] = 0;
+  if (tid < 4) order[tid] = 0;
   if (tid < 64) bins[tid] = 0;
   __syncthreads();
   u64 x = 0, mn = ~0ull, mx = 0;
   u64 mykey[2] = {0, 0};
   bool myvalid[2] = {false, false};
-  u32 eq_r = 0, eq_s = 0;
+  u32 eq_r = 0, eq_s = 0, up_r = 0, dn_r = 0, up_s = 0, dn_s = 0;
   const u32 sr = nb / 2048 + 1, ss = np / 2048 + 1;  // ~2048 samples per relation
 #pragma unroll
   for (int k = 0; k < 2; k++) {
@@ -1157,6 +1159,10 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
     const bool vr_next = __shfl_down((int)vr, 1, kWave) != 0, vs_next = __shfl_down((int)vs, 1, kWave) != 0;
     if (lane < 63 && vr && vr_next && kr == kr_next) eq_r++;
     if (lane < 63 && vs && vs_next && ks == ks_next) eq_s++;
+    // neighbouring samples in ascending / descending key order: a relation that arrives sorted hands every worker
+    // of the histogram-free slab pass rows of ONE digit (its slab for that digit overflows)
+    if (lane < 63 && vr && vr_next) (kr < kr_next ? up_r : dn_r)++;
+    if (lane < 63 && vs && vs_next) (ks < ks_next ? up_s : dn_s)++;
   }
   if (nb) {
     const u64 kl = rk[2 * (u64)(nb - 1)];
@@ -1180,6 +1186,10 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
   }
   if (eq_r) atomicAdd(&same[0], eq_r);
   if (eq_s) atomicAdd(&same[1], eq_s);
+  if (up_r) atomicAdd(&order[0], up_r);
+  if (dn_r) atomicAdd(&order[1], dn_r);
+  if (up_s) atomicAdd(&order[2], up_s);
+  if (dn_s) atomicAdd(&order[3], dn_s);
   __syncthreads();
   {  // how evenly the sampled build keys fill their range: 64 equal bins
     const u64 lo = rng[0], span = rng[1] - rng[0];
@@ -1191,8 +1201,9 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
   if (tid == 0) {
     out[0] = acc;
     out[1] = ref;
-    out[2] = same[0];
-    out[3] = same[1];
+    // (bits 0-15: neighbouring samples with equal keys; 16-31 / 32-47: pairs in ascending / descending order)
+    out[2] = (u64)same[0] | ((u64)order[0] << 16) | ((u64)order[1] << 32);
+    out[3] = (u64)same[1] | ((u64)order[2] << 16) | ((u64)order[3] << 32);
     out[4] = rng[0];  // (~0, 0 without build rows)
     out[5] = rng[1];
     u32 nonempty = 0, big = 0;
@@ -1252,7 +1263,7 @@ static u32 slab_cap(double mean, double fan) {
   double c = mean + 8.0 * __builtin_sqrt(fan * mean) + 24.0;
   return ((u32)c + 8) & ~7u;
 }
-bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fan) {
+bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fan, double density) {
   const u32 tile = 2048;
   u64 tiles = ((u64)n + tile - 1) / tile;
   u64 max_workers = 2048;
@@ -1267,8 +1278,9 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fa
   g->KB = kb;
   if (g->WA < kb || (g->WA + kb - 1) / kb > (u32)SLAB_MAXSEG) return false;
   if (fan < 1.0) fan = 1.0;
-  g->CA = slab_cap((double)g->rpw / (double)(1u << bits_a), fan);
-  g->CB = slab_cap((double)n / (double)(1u << bits_a) / (double)kb / (double)(1u << bits_b), fan);
+  if (density < 1.0) density = 1.0;  // keys that fill 1 / density of the partitions: those hold density x the mean
+  g->CA = slab_cap(density * (double)g->rpw / (double)(1u << bits_a), fan);
+  g->CB = slab_cap(density * (double)n / (double)(1u << bits_a) / (double)kb / (double)(1u << bits_b), fan);
   const u64 rows_a = (u64)(1u << bits_a) * g->WA * g->CA;
   const u64 rows_b = (u64)(1u << (bits_a + bits_b)) * kb * g->CB;
   g->rows_a = rows_a;
@@ -1298,6 +1310,43 @@ hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int s
                                              cnt_b, accum, st, g.KB)
                      : launch_slab_b_t<false>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
                                               cnt_b, accum, st, g.KB);
+}
+
+// Every key of both relations against the sample's reference key: the bits in which ANY key differs (atomicOr into
+// *out, which the caller zeroes), and the smallest / largest build key (out[1], out[2]; caller: ~0, 0).  The retry of an
+// ordered join whose sampled prefix some row did not share (a handful of keys above an otherwise dense range) plans
+// with these exact values instead.
+__global__ __launch_bounds__(256) void key_exact_kernel(const Tup* __restrict__ R, u32 nb, const Tup* __restrict__ S, u32 np,
+                                                        u64 ref, u64* __restrict__ out) {
+  u64 x = 0, mn = ~0ull, mx = 0;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) {
+    const u64 k = R[i].key;
+    x |= k ^ ref;
+    mn = k < mn ? k : mn;
+    mx = k > mx ? k : mx;
+  }
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += stride) x |= S[i].key ^ ref;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    x |= __shfl_xor(x, o, kWave);
+    const u64 a2 = __shfl_xor(mn, o, kWave), b2 = __shfl_xor(mx, o, kWave);
+    mn = a2 < mn ? a2 : mn;
+    mx = b2 > mx ? b2 : mx;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (x) atomicOr(reinterpret_cast<unsigned long long*>(out), (unsigned long long)x);
+    if (nb) {
+      atomicMin(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)mn);
+      atomicMax(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)mx);
+    }
+  }
+}
+
+hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st) {
+  hipLaunchKernelGGL(key_exact_kernel, dim3(num_cus * 8), dim3(256), 0, st, static_cast<const Tup*>(R), nb,
+                     static_cast<const Tup*>(S), np, ref, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st) {

@@ -840,8 +840,10 @@ def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
     r = ex.join_device(to_dev(B2), to_dev(P2), H.HMJ_CHECKSUM)
     assert r.checks() == ck2
     # the common way to get such outliers: dense keys 0..N-1 with N slightly above a power of two (the sample
-    # misses the few keys >= 2^k).  The plan is kept and the ordered result finished by a sort on the key; once
-    # this dropped the prefix instead and joined ONE partition of millions of rows (minutes at 2^25 rows).
+    # misses the few keys >= 2^k).  The retry takes the shared prefix from a pass over ALL keys, sees that the keys
+    # fill half of that range (the dense-build plan: one more bit) and stays on the one-pass ordered path -- and the
+    # context goes straight to the exact prefix for its next ordered joins.  (Round 2 kept the sampled prefix and sorted
+    # all result rows by key: 5 x slower; round 1 dropped the prefix and joined ONE partition of millions of rows.)
     n3 = (1 << 21) + 900
     k3 = rng.permutation(n3).astype(np.uint64)
     B3 = np.stack([k3, np.arange(n3, dtype=np.uint64)], 1)
@@ -852,9 +854,24 @@ def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
     t = ex.last_timing()
     ex.set_profiling(False)
     assert r.checks() == ck3 and np.array_equal(ex.columns_to_numpy(r, host=False), rows3)
-    # the dense prefix is kept either way: 42 bits when the sample happened to see a key >= 2^21, else 43 bits plus
-    # the final stable sort by key
-    assert t["key_prefix_bits"] == 42 or (t["key_prefix_bits"] == 43 and t["path"] & H.HMJ_PATH_ORDER_BY_KEY), t
+    assert t["key_prefix_bits"] == 42 and not (t["path"] & H.HMJ_PATH_ORDER_BY_KEY) and (t["path"] & H.HMJ_PATH_SORTED_WRITE), t
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(B3), to_dev(P3), H.HMJ_ORDERED | H.HMJ_CHECKSUM)  # (no failed first attempt this time)
+    t = ex.last_timing()
+    ex.set_profiling(False)
+    assert r.checks() == ck3 and np.array_equal(ex.columns_to_numpy(r, host=False), rows3)
+    assert t["key_prefix_bits"] == 42 and (t["path"] & H.HMJ_PATH_SORTED_WRITE), t
+    # sorted input (both relations ascending by key): the slab pass is not even tried (every worker would see one digit)
+    ks = np.arange(n3, dtype=np.uint64)
+    Bs = np.stack([ks, ks + np.uint64(1)], 1)
+    Ps = np.stack([ks, ks + np.uint64(2)], 1)
+    cks, rowss = oracle.equijoin(Bs, Ps)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(Bs), to_dev(Ps), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    ex.set_profiling(False)
+    assert r.checks() == cks and np.array_equal(ex.columns_to_numpy(r, host=False), rowss)
+    assert not (t["path"] & H.HMJ_PATH_SLAB) and t["path"] & H.HMJ_PATH_SORTED_WRITE, hex(t["path"])
     # reference known-answer shape: radix_hash_test.cc:82-93 keys 12345..1 (descending ints)
     k = np.arange(12345, 0, -1, dtype=np.uint64)
     D = np.stack([k, k], 1)
