@@ -936,12 +936,15 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // a join keeps Q = 1 while that mode is on offer -- one pass on half the chip beats count + write + order on all of
   // it (ordered, 2^20 + 3000 rows: 0.34 -> 0.22 ms, 2^21 + 3000: 0.45 -> 0.27 ms).  After a failed attempt (duplicate
   // build keys: uniq_cooldown) the slices are back.
-  if (Q > 1 && allow_fast_write && c->uniq_cooldown == 0 && materialize && !first && !win_ordered && P >= 2 && probe_fits &&
+  if (Q > 1 && allow_fast_write && c->uniq_cooldown == 0 && materialize && !win_ordered && P >= 2 && probe_fits &&
       !c->prepare_only) {
     Q = 1;
     items = P;
   }
-  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !first && !win_ordered &&
+  // (HMJ_FIRST_WINS included: with unique build keys "the first row of a key" is the only one, and the unique-key
+  //  kernels give up the moment a probe row meets a key twice -- the general first-wins passes then run as before.
+  //  Until round 3 first-wins joins never tried: first + ordered 3.2 ms against 1.4 ms at 2^25 unique keys.)
+  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !win_ordered &&
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
   if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
       probe_fits &&
