@@ -65,7 +65,8 @@ hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabG
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
                          const SlabGeom& g, void* slab_b, u64 slab_b_rows, u32* cnt_b, u64 cnt_b_n, u64* accum, hipStream_t st);
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st);
-hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st);
+hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st,
+                            bool ref_is_first_key = false);
 hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st);
 
 // probe.hip

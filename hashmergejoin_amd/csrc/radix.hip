@@ -1317,7 +1317,8 @@ hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int s
 // ordered join whose sampled prefix some row did not share (a handful of keys above an otherwise dense range) plans
 // with these exact values instead.
 __global__ __launch_bounds__(256) void key_exact_kernel(const Tup* __restrict__ R, u32 nb, const Tup* __restrict__ S, u32 np,
-                                                        u64 ref, u64* __restrict__ out) {
+                                                        u64 ref, bool ref_is_first_key, u64* __restrict__ out) {
+  if (ref_is_first_key) ref = nb ? R[0].key : (np ? S[0].key : 0);  // (callers that have not seen a key yet)
   u64 x = 0, mn = ~0ull, mx = 0;
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) {
@@ -1343,9 +1344,10 @@ __global__ __launch_bounds__(256) void key_exact_kernel(const Tup* __restrict__ 
   }
 }
 
-hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st) {
+hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st,
+                            bool ref_is_first_key) {
   hipLaunchKernelGGL(key_exact_kernel, dim3(num_cus * 8), dim3(256), 0, st, static_cast<const Tup*>(R), nb,
-                     static_cast<const Tup*>(S), np, ref, out);
+                     static_cast<const Tup*>(S), np, ref, ref_is_first_key, out);
   return hipGetLastError();
 }
 

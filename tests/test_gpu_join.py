@@ -768,6 +768,33 @@ def test_full_radix_sort_matches_reference_sort(ex, oracle, n):
     assert np.array_equal(got2[:, 0], ref2[:, 0])  # key column equals the reference's
 
 
+@pytest.mark.parametrize("shape", ["dense", "digits_0_2_5", "digits_1_6", "one_key", "sample_misses_a_digit"])
+def test_sort_skips_the_digits_no_key_differs_in(ex, shape):
+    # from 2^22 rows on hmj_sort_u64_device runs a pass only for the 8-bit digits in which some key differs (a sample
+    # says whether that can be the case, one pass over all keys makes it exact).  Odd and even numbers of passes, out
+    # of place and in place (an odd number in place ends in the scratch buffer and is copied back), one distinct key
+    # (no pass at all), and a digit that only a single unsampled key varies in: always the stable order by key.
+    n = (1 << 22) + 77
+    rng = np.random.default_rng(12)
+    if shape == "dense":
+        keys = rng.permutation(n).astype(np.uint64)                      # digits 0, 1, 2 vary: three passes
+    elif shape == "digits_0_2_5":
+        keys = (rng.integers(0, 256, n).astype(np.uint64) | (rng.integers(0, 256, n).astype(np.uint64) << np.uint64(16))
+                | (rng.integers(0, 256, n).astype(np.uint64) << np.uint64(40)) | (np.uint64(0xAB) << np.uint64(56)))
+    elif shape == "digits_1_6":
+        keys = (rng.integers(0, 256, n).astype(np.uint64) << np.uint64(8)) | (rng.integers(0, 200, n).astype(np.uint64) << np.uint64(48))
+    elif shape == "one_key":
+        keys = np.full(n, 0x1234567890ABCDEF, np.uint64)
+    else:
+        keys = rng.integers(0, 1 << 16, n).astype(np.uint64)
+        keys[n // 2 + 12345] |= np.uint64(1) << np.uint64(61)             # digit 7 differs in ONE row the sample does not see
+    a = np.stack([keys, np.arange(n, dtype=np.uint64)], 1)
+    want = a[np.argsort(keys, kind="stable")]
+    assert np.array_equal(to_np(ex.sort_device(to_dev(a))), want)
+    d = to_dev(a)
+    assert np.array_equal(to_np(ex.sort_device(d, inplace=True)), want)
+
+
 def test_sort_in_place_replaces_radix_int_inplace(ex, oracle):
     # hmj_sort_u64_device with out == in vs the restated radix_int_inplace (radix_sort.h:333-398; the call
     # radix_bench_par.cc:96 times).  The reference's in-place sort is unstable: same rows, same key column.
