@@ -540,7 +540,8 @@ int order_rows(hmj_ctx* c, const u32* vstart, const u32* in_base32, const u64* i
 // and the ordered epilogue moves every partition to its place while sorting it.  Returns
 // kRetryNoFastWrite when the kernel met duplicate build keys or an oversized partition.
 int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, int low, bool extra,
-                         int verify_prefix, u64 pfx_ref, bool ordered, bool to_host, bool fk_wide_plan, hmj_result* out) {
+                         int verify_prefix, u64 pfx_ref, bool ordered, bool to_host, bool fk_wide_plan, double density,
+                         hmj_result* out) {
   int rc;
   const u32 P = wa.P;
   const size_t cap_bytes = ((size_t)np + 8) * 8;  // at most one row per probe row
@@ -605,12 +606,13 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   // foreign-key form (the bitmap form would only find out: 1.9 ms at 2^24 x 2^28)
   const bool must_repeat = nb > 0 && (double)np >= 2.0 * (double)nb;
   for (int form = (c->sorted_fk || must_repeat || fk_wide_plan) ? 1 : 0;
-       form < 2 && ordered && c->sorted_mode && c->sorted_cooldown == 0 && low >= 12; form++) {
+       form < 2 && ordered && c->sorted_mode && c->sorted_cooldown == 0; form++) {
     const bool fk = form == 1;
     bool half = false;
     int shape = 0;
     if (fk && nb > 0 && P > 0) {
-      const double avg_np = (double)np / (double)P, avg_nb = (double)nb / (double)P, f = (double)np / (double)nb;
+      // (density: the populated partitions hold that many times the mean -- the dense-build plan)
+      const double avg_np = density * (double)np / (double)P, avg_nb = density * (double)nb / (double)P, f = (double)np / (double)nb;
       const double hi_np = fk_probe_rows_hi(avg_np, f, (double)P), hi_nb = avg_nb + 6.0 * __builtin_sqrt(avg_nb) + 8.0;
       half = !no_half && f >= 2.0 && hi_np <= 3072.0 && hi_nb <= 2048.0;
       shape = half ? 1 : (fk_wide_plan && hi_nb <= 2560.0) ? 2 : 0;
@@ -715,12 +717,27 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   // Otherwise the ordered epilogue closes the gaps (and sorts, which an unordered caller may ignore).
   const bool dense_out = !ordered && out->n_matches == (u64)np;
   const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
-  if (!dense_out) {
+  if (!dense_out && ordered) {
     int retry = 0;
     if ((rc = order_rows(c, nullptr, in_base32, in_base64, P, 1, low, out->n_matches, false, out->n_matches > 2ull * nb,
                          &rk, &rr, &rs, &retry)) !=
         HMJ_OK)
       return rc;
+  } else if (!dense_out) {
+    // an unordered result only has to lose the gaps unmatched probe rows left: every partition's rows move to the
+    // partition's dense offset as they are.  (Until round 3 this went through the ordered epilogue, which also sorts:
+    // a foreign-key join with fan-out 16 and a fifth of its probe rows unmatched took 16.4 ms instead of 2.)
+    const size_t bytes = (size_t)out->n_matches * 8;
+    if ((rc = ensure_dev(c, c->ord_key, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->ord_rval, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->ord_sval, bytes)) != HMJ_OK) return rc;
+    const int sp2 = span_begin(c, K_ORDER, -1);
+    HIP_TRY(hmj::launch_compact((const u64*)c->part_out_off.p, in_base32, in_base64, P, rk, rr, rs, (u64*)c->ord_key.p,
+                                (u64*)c->ord_rval.p, (u64*)c->ord_sval.p, c->num_cus * 8, c->stream));
+    span_end(c, sp2);
+    rk = (const u64*)c->ord_key.p;
+    rr = (const u64*)c->ord_rval.p;
+    rs = (const u64*)c->ord_sval.p;
   }
   return deliver(rk, rr, rs);
 }
@@ -827,7 +844,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     //    large, two passes of at most 8 bits): 2^26 x 2^28 rows 8.3 -> 6.0 ms.  Otherwise the build-side plan
     //    with its big probe partitions is the faster one (one table serves tens of thousands of probe rows).
     int Bp, passes_p, pb_p[4];
-    plan_bits(np_plan, -1, &Bp, &passes_p, pb_p);
+    // (keys that fill 1 / dense_scale of the key range the partition bits span -- dimension ids 0 .. n - 1 with n a little
+    //  above a power of two -- crowd into that share of the partitions: plan for dense_scale times the rows.  Without
+    //  it an ordered join of 2^22 + 9 dense ids with 2^26 foreign keys made 8192-row partitions, had them cut into
+    //  virtual partitions and took 40.7 ms instead of 2.3.)
+    const u64 np_dense = (u64)((double)np_plan * dense_scale);
+    plan_bits(np_dense > 4000000000ull ? 4000000000ull : np_dense, -1, &Bp, &passes_p, pb_p);
     const double f = (double)np_plan / (double)nb;
     // ordered joins with fan-out >= 2.5 (their probe keys MUST repeat): the foreign-key form of the one-pass ordered
     // write has a 6144-row shape, so 16 bits still hold mean + 5 sigma of a 2^28-row probe side at fan-out 16 -- and
@@ -836,15 +858,15 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
                          c->sorted_wide && c->sorted_cooldown <= 1 && f >= 2.5;
     const int B_narrow = [&] {
       int b = Bp;
-      while (b < 18 && fk_probe_rows_hi((double)np_plan / (double)(1ull << b), f, (double)(1ull << b)) > 5120.0) b++;
+      while (b < 18 && fk_probe_rows_hi((double)np_dense / (double)(1ull << b), f, (double)(1ull << b)) > 5120.0) b++;
       return b;
     }();
-    while (Bp < 18 && fk_probe_rows_hi((double)np_plan / (double)(1ull << Bp), f, (double)(1ull << Bp)) > (wide_ok ? 6144.0 : 5120.0)) Bp++;
+    while (Bp < 18 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp), f, (double)(1ull << Bp)) > (wide_ok ? 6144.0 : 5120.0)) Bp++;
     // count joins on the slab path: the pipelined count kernel takes a partition's rows piece by piece, a quarter of
     // its threads per piece (1280 rows); a key's f probe rows spread over the four pieces (f = 8 at 4096-row partitions
     // overflowed a piece, the join started over with probe-side slabs only: 3.9 ms against 2.7 ms, tools/exp_cliffs_fk.py)
     if (!materialize)
-      while (Bp < 16 && fk_probe_rows_hi((double)np_plan / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
+      while (Bp < 16 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
     fk_wide_plan = wide_ok && Bp < B_narrow;
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 16 && slab_ok)))
@@ -935,7 +957,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // no count pass); it works on either partition layout
   if (c->uniq_cooldown > 0 && allow_fast_write && materialize) c->uniq_cooldown--;
   // the pipelined probe kernels hold one partition's probe rows in registers (5120 at most)
-  const bool probe_fits = ((u64)np_plan >> B) <= 4608;  // (the wide foreign-key plan keeps the mean at <= 4608 too)
+  const bool probe_fits = ((u64)((double)np_plan * dense_scale) >> B) <= 4608;  // (the wide foreign-key plan keeps the mean at <= 4608 too)
   // A small materialising join (fewer partitions than the probe grid has workgroups) would share every table among
   // several probe slices, which the unique-key write mode cannot take (a partition's rows go out as one piece): such
   // a join keeps Q = 1 while that mode is on offer -- one pass on half the chip beats count + write + order on all of
@@ -1040,7 +1062,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       wa.Q = 1;
       wa.accum = acc;
       return unique_key_write(c, wa, true, nb, np, low, extra, verify_pfx ? prefix : 0, pfx_ref,
-                                  (flags & HMJ_ORDERED) != 0, to_host, fk_wide_plan, out);
+                                  (flags & HMJ_ORDERED) != 0, to_host, fk_wide_plan, dense_scale, out);
     }
     hmj::ProbeArgs sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -1263,7 +1285,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     wa.Q = 1;
     wa.accum = (u64*)c->accum.p;
     rc = unique_key_write(c, wa, false, nb, np, low, extra, verify_pfx ? prefix : 0, pfx_ref,
-                                  (flags & HMJ_ORDERED) != 0, to_host, fk_wide_plan, out);
+                                  (flags & HMJ_ORDERED) != 0, to_host, fk_wide_plan, dense_scale, out);
     if (rc != kRetryNoFastWrite) return rc;
     // duplicate build keys: the partitions stay valid, carry on with the count / scan / write passes
     HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));

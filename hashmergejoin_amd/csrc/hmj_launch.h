@@ -119,6 +119,10 @@ hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);
 hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
                         int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
                         u64* bsval, u64* accum, u32 defer_rows, bool many_per_key, int grid, hipStream_t st);
+// partition p's rows [in_base[p], + out_off[p + 1] - out_off[p]) of the three columns a -> b at out_off[p] (closes the gaps
+// unmatched probe rows leave in the unique-key write mode's slot layout; no sorting)
+hipError_t launch_compact(const u64* part_out_off, const u32* in_base32, const u64* in_base64, u32 P, const u64* akey,
+                          const u64* arval, const u64* asval, u64* bkey, u64* brval, u64* bsval, int grid, hipStream_t st);
 hipError_t launch_rekey(void* pairs, u64 n, const u64* col, hipStream_t st);  // pairs[j].key = col[pairs[j].val]
 
 // gen.hip

@@ -33,6 +33,13 @@ struct ProbeSmem {
 constexpr u32 PB_BATCH = 2 * PB_THREADS;  // build rows inserted per step
 static_assert(PB_BATCH <= PB_CAP, "a batch must fit an empty table");
 
+// The bucket of a key inside its partition: the key bits right under the partition bits, as many as the bucket count
+// takes.  Keys with FEWER varying bits under the partition bits than that (dense integer ids: 2^22 ids in 2^14 partitions
+// leave eight) have sh < 0: their low bits become the TOP bits of the bucket number, which keeps buckets in key order.
+__device__ __forceinline__ u32 key_bucket(u64 key, int sh, u32 mask) {
+  return (sh >= 0 ? (u32)(key >> sh) : (u32)(key << (-sh))) & mask;
+}
+
 __device__ __forceinline__ u32 tab_hash(u64 k) {
   u32 x = (u32)k ^ ((u32)(k >> 32) * 0x85EBCA6Bu);
   x *= 0x9E3779B1u;
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         ha[k] = 0;
         if (i < nb) {
           if (a.pfx_shift && (br[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
-          const u32 h = (u32)(br[k].key >> bsh) & (NB - 1);
+          const u32 h = key_bucket(br[k].key, bsh, NB - 1);
           ha[k] = h | (atomicAdd(&sm.cnt[h], 1u) << 12);
         }
       }
@@ -1145,7 +1152,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           if (j < np) {
             if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             if (EXTRA) acc_p += pr[k].val;
-            const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
+            const u32 hh = key_bucket(pr[k].key, bsh, NB - 1);
             cur[k] = sm.bstart[hh];
             len[k] = (u32)sm.bstart[hh + 1] - cur[k];
           }
@@ -1197,7 +1204,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           if (j < np) {
             if (a.pfx_shift && (pr[k].key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
             if (EXTRA) acc_p += pr[k].val;
-            const u32 hh = (u32)(pr[k].key >> bsh) & (NB - 1);
+            const u32 hh = key_bucket(pr[k].key, bsh, NB - 1);
             cur[k] = sm.bstart[hh];
             len[k] = (u32)sm.bstart[hh + 1] - cur[k];
           }
@@ -1435,6 +1442,33 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
   block_accumulate(sm.red, a.accum, v, 1u << ACC_XOR);
 }
 
+// Unordered result of the unique-key write mode with unmatched probe rows: every partition's rows, written from the
+// partition's first probe-row slot on, move to the partition's dense offset (the order inside a partition stays).
+__global__ __launch_bounds__(256) void compact_rows_kernel(const u64* __restrict__ out_off, const u32* __restrict__ base32,
+                                                           const u64* __restrict__ base64, u32 P,
+                                                           const u64* __restrict__ akey, const u64* __restrict__ arval,
+                                                           const u64* __restrict__ asval, u64* __restrict__ bkey,
+                                                           u64* __restrict__ brval, u64* __restrict__ bsval) {
+  for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
+    const u64 dst = out_off[p], n = out_off[p + 1] - dst;
+    const u64 src = base64 ? base64[p] : (u64)base32[p];
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) {
+      bkey[dst + i] = akey[src + i];
+      brval[dst + i] = arval[src + i];
+      bsval[dst + i] = asval[src + i];
+    }
+  }
+}
+
+hipError_t launch_compact(const u64* part_out_off, const u32* in_base32, const u64* in_base64, u32 P, const u64* akey,
+                          const u64* arval, const u64* asval, u64* bkey, u64* brval, u64* bsval, int grid, hipStream_t st) {
+  if (P == 0) return hipSuccess;
+  if ((u32)grid > P) grid = (int)P;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(grid), dim3(256), 0, st, part_out_off, in_base32, in_base64, P, akey, arval,
+                     asval, bkey, brval, bsval);
+  return hipGetLastError();
+}
+
 // Exclusive scan of n u64 counts into n+1 offsets (single workgroup; n = partition count).
 __global__ __launch_bounds__(1024) void scan_u64_kernel(const u64* __restrict__ in,
                                                         u64* __restrict__ out, u32 n) {
@@ -1546,7 +1580,7 @@ __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const
     const u32 i = k * OS_THREADS + tid;
     bk[k] = 0;
     if (i < L) {
-      bk[k] = (u32)(key[k] >> bsh) & (OS_NB - 1);
+      bk[k] = key_bucket(key[k], bsh, OS_NB - 1);
       sm.stage[i] = key[k];
       sm.srv[i] = rv[k];
       sm.ssv[i] = sv[k];
@@ -1670,7 +1704,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
     if (L64 == 0) continue;
     bool done = false;
     u64 key[OS_ROWS], rv[OS_ROWS], sv[OS_ROWS];
-    if (bsh >= 0 && L64 <= OS_CAP) {
+    if (L64 <= OS_CAP) {
       const u32 L = (u32)L64;
 #pragma unroll
       for (int k = 0; k < OS_ROWS; k++) {
@@ -1683,7 +1717,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
         }
       }
       done = order_sort_registers<MANY>(sm, L, key, rv, sv, bsh, ob, bkey, brval, bsval, tid);
-    } else if (bsh >= 0 && L64 <= (u64)OS_CHUNKS * OS_CHUNK_ROWS) {
+    } else if (L64 <= (u64)OS_CHUNKS * OS_CHUNK_ROWS) {
       const u32 L = (u32)L64;
       // bucket counts of the whole segment -> bucket starts (kept in bstart32, aliased on sidx + bstart:
       // they are free until a chunk is sorted, so the starts are rebuilt per chunk from the counts instead)
@@ -1691,7 +1725,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
       for (u32 i = tid; i < (u32)OS_NB; i += OS_THREADS) sm.bcur[i] = 0;
       if (tid == 0) sm.fallback = 0;
       __syncthreads();
-      for (u32 i = tid; i < L; i += OS_THREADS) atomicAdd(&sm.bcur[(u32)(akey[b + i] >> bsh) & (OS_NB - 1)], 1u);
+      for (u32 i = tid; i < L; i += OS_THREADS) atomicAdd(&sm.bcur[key_bucket(akey[b + i], bsh, OS_NB - 1)], 1u);
       __syncthreads();
       u32 st[4];  // start of this thread's four buckets in the sorted segment
       {
@@ -1734,7 +1768,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
             const u32 i = i0r + tid;
             if (i < L) {
               const u64 kk = akey[b + i];
-              if (sm.sidx[(u32)(kk >> bsh) & (OS_NB - 1)] == (u16)cnk) {
+              if (sm.sidx[key_bucket(kk, bsh, OS_NB - 1)] == (u16)cnk) {
                 const u32 slot = atomicAdd(&sm.scratch[0], 1u);
                 sm.stage[slot] = kk;
                 sm.srv[slot] = arval[b + i];
@@ -1975,7 +2009,7 @@ static hipError_t launch_sorted_x(const ProbeArgs& a, u64* lookback, bool chaine
 // shape's capacities makes the kernel give up with "a partition does not fit"; key_low: the partition id's lowest key bit
 hipError_t launch_probe_write_sorted(const ProbeArgs& a, bool slab, bool fk, int shape, u64* lookback, bool chained, int key_low,
                                      int num_cus, hipStream_t st) {
-  if (key_low < SW_LOGB) return hipErrorInvalidValue;
+  if (key_low < 0 || key_low > 63) return hipErrorInvalidValue;  // (fewer key bits than buckets: key_bucket shifts left)
   if (slab && !slab_operands_ok(a)) return hipErrorInvalidValue;
   int grid = (fk && shape == 1) ? 2 * num_cus : num_cus;  // workgroups that fit a CU (LDS); partitions by stride or ticket
   if ((u32)grid > a.P) grid = (int)a.P;

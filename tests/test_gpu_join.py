@@ -1089,6 +1089,39 @@ def test_one_pass_ordered_write(ex_fresh, H, oracle):
     assert not (t["path"] & H.HMJ_PATH_SORTED_WRITE)
 
 
+def test_dense_dimension_ids_with_foreign_keys(ex_fresh, H, oracle):
+    # the everyday shape: a dimension table with ids 0 .. n - 1 (n a little above a power of two, shuffled) and a fact
+    # table whose foreign keys are drawn from the ids -- or from a range a quarter wider (unmatched rows).  The ids fill
+    # half of the key range their varying bits span and leave only a few key bits under the partition bits: the plan
+    # follows the density (probe side too), the one-pass ordered write takes its buckets from the bits that are there,
+    # and an unordered result with unmatched rows is compacted, not sorted.  (Round 3 found this shape 18 x slower than
+    # uniform keys: tools/exp_cliffs*.py.)
+    ex = ex_fresh
+    nb, npb = (1 << 18) + 9, (1 << 22) + 5
+    rng = np.random.default_rng(31)
+    B = np.stack([rng.permutation(nb).astype(np.uint64), np.arange(nb, dtype=np.uint64) * np.uint64(3)], 1)
+    for hi in (nb, nb + nb // 4):
+        P = np.stack([rng.integers(0, hi, npb).astype(np.uint64), np.arange(npb, dtype=np.uint64) + np.uint64(7)], 1)
+        ck, rows = oracle.equijoin(B, P)
+        for _ in range(2):  # (the second join goes straight to the exact prefix)
+            ex.set_profiling(True)
+            r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+            t = ex.last_timing()
+            ex.set_profiling(False)
+            assert r.checks() == ck and np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+        assert t["path"] & H.HMJ_PATH_SORTED_FK and not (t["path"] & H.HMJ_PATH_SPLIT) and t["ms_order"] == 0.0, hex(t["path"])
+        ex.set_profiling(True)
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM)
+        t = ex.last_timing()
+        ex.set_profiling(False)
+        got = ex.columns_to_numpy(r, host=False)
+        assert r.checks() == ck and t["path"] & H.HMJ_PATH_UNIQ_WRITE, hex(t["path"])
+        order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
+        assert np.array_equal(got[order], rows)
+        assert ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM).checks() == ck
+        ex.release_result()
+
+
 def test_one_pass_ordered_write_gives_up_on_clustered_keys(ex_fresh, H, oracle):
     # a tag in the top six bits, zeros below it, an id in the low forty: whatever window the planner takes, the
     # rows of a partition agree in the twelve bits under it or the partitions are no key ranges -> not this
