@@ -823,6 +823,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     if (c->dense_plan && c->force_bits < 0 && nb > 0 && smp[5] > smp[4] && pfx < 64 && even) {
       const double span = (double)(smp[5] - smp[4]) + 1.0, full = __builtin_ldexp(1.0, 64 - pfx);
       const double fraction = span / full;
+      // (between 0.7 and 1 the bits stay -- dense ids fill whole partitions of a power-of-two size either way -- but the
+      //  populated partitions still hold 1 / fraction times the mean, which the slab capacities, the foreign-key plan and
+      //  the kernel shapes must know: 1.5 x 2^24 dense ids overflowed a slab, count 1.20 ms against 0.80 / 1.07 ms for
+      //  1.25 x and 1.75 x 2^24)
+      if (fraction < 0.97) dense_scale = fraction > 1.0 / 64.0 ? 1.0 / fraction : 64.0;
       if (fraction < 0.7) {
         const double scale = fraction > 1.0 / 64.0 ? 1.0 / fraction : 64.0;
         const double eff = (double)n_build * scale;
