@@ -412,7 +412,11 @@ def test_skewed_build_side(ex, H, oracle):
     # (BASELINE configs[4] shape, scaled down): chained table + overflow chunks
     dom = 1 << 12
     w = 1.0 / np.arange(1, dom + 1, dtype=np.float64) ** 0.9
-    thr = np.minimum(np.cumsum(w) / w.sum() * 2.0 ** 64, float(M64)).astype(np.uint64)
+    cdf = np.cumsum(w) / w.sum()
+    top = cdf >= 1.0 - 2.0 ** -53  # (2^64 itself does not fit a uint64: those entries are set below, not cast)
+    thr = np.empty(dom, np.uint64)
+    thr[~top] = (cdf[~top] * 2.0 ** 64).astype(np.uint64)
+    thr[top] = M64
     thr[-1] = M64
     B = oracle.gen_from_cdf(1 << 16, thr)
     P = oracle.gen_uniform_domain(1 << 18, dom)
