@@ -20,6 +20,7 @@ HMJ_PATH_HOST_PIPELINE = 0x4000
 HMJ_PATH_SORTED_FK_HALF = 0x8000
 HMJ_PATH_LOOKBACK_TIMEOUT = 0x10000
 HMJ_PATH_SORTED_FK_WIDE = 0x20000
+HMJ_PATH_PRESORTED = 0x40000
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _U64P = C.POINTER(C.c_uint64)

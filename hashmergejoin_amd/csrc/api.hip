@@ -385,11 +385,32 @@ int radix_pass(hmj_ctx* c, const void* src, void* dst, u32 n, int shift, int bit
 }
 
 // all passes of one relation; *result = where the partitioned rows ended up
+// try_in_place: the key sample found the relation in ascending key order.  If its rows' partition numbers never
+// decrease (one pass over the keys: a sixth of what two radix passes move) the relation IS partitioned where it lies
+// -- the output of an ordered join fed into the next one, two tables exported in key order -- and no pass runs.
 int partition_relation(hmj_ctx* c, const void* in, u32 n, DevBuf buf[2], int top, int passes,
-                       const int pass_bits[4], int rel, const void** result) {
+                       const int pass_bits[4], int rel, const void** result, bool try_in_place = false) {
   *result = in;
   if (passes == 0 || n == 0) return HMJ_OK;
   int rc;
+  if (try_in_place) {
+    int bits = 0;
+    for (int i = 0; i < passes; i++) bits += pass_bits[i];
+    if ((rc = ensure_dev(c, c->offs64, 8 * sizeof(u64))) != HMJ_OK) return rc;
+    if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+    u32* flag = (u32*)((u64*)c->offs64.p + 7);
+    u32* hflag = (u32*)((u64*)c->h_accum.p + 7);
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+    const int sp = span_begin(c, K_HIST, rel);
+    HIP_TRY(hmj::launch_check_partitioned(in, n, top, bits, flag, c->num_cus, c->stream));
+    span_end(c, sp);
+    HIP_TRY(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*hflag == 0) {
+      c->timing.path |= HMJ_PATH_PRESORTED;
+      return HMJ_OK;  // *result == in
+    }
+  }
   if ((rc = ensure_dev(c, buf[0], (size_t)n * 16)) != HMJ_OK) return rc;
   if (passes > 1 && (rc = ensure_dev(c, buf[1], (size_t)n * 16)) != HMJ_OK) return rc;
   const void* src = in;
@@ -768,6 +789,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // ---- key sample (one small kernel): the top bits all keys share, a hot-key hint, and the range of the build keys
   u64 smp[8] = {0, 0, 0, 0, ~0ull, 0, 0, 0};
   double dense_scale = 1.0;   // dense-build plan: the populated partitions hold this many times the mean
+  bool asc_r = false, asc_s = false;  // the sample found the build / probe rows in ascending key order
   bool prefix_exact = false;  // smp[0] / [4] / [5] come from a pass over ALL keys (the retry after a prefix violation)
   const bool have_sample = c->prefix_bits < 0 && allow_auto_prefix && B > 0 && (u64)nb + np > 0;
   if (have_sample) {
@@ -809,6 +831,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
         return up + dn >= 64 && (up * 10 >= (up + dn) * 9 || dn * 10 >= (up + dn) * 9);
       };
       if (sorted_like(smp[2]) || sorted_like(smp[3])) allow_slab = allow_slab_probe = false;
+      auto ascending = [](u64 w) {
+        const u64 up = (w >> 16) & 0xFFFF, dn = (w >> 32) & 0xFFFF;
+        return up + dn >= 64 && up * 10 >= (up + dn) * 9;
+      };
+      asc_r = ascending(smp[2]);
+      asc_s = ascending(smp[3]);
     }
     // Build keys that cover only part of the key range the partition bits span (a dimension table's ids under a
     // fact table with a wider key domain; keys below 2^63 against full 64-bit keys) crowd into a fraction of
@@ -1119,7 +1147,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   if (reuse_exact) {
     Rp = c->prep.Rp;
   } else {
-    if ((rc = partition_relation(c, R, nb, c->rbuf, low, passes, pass_bits, 0, &Rp)) != HMJ_OK) return rc;
+    if ((rc = partition_relation(c, R, nb, c->rbuf, low, passes, pass_bits, 0, &Rp, asc_r)) != HMJ_OK) return rc;
     s = span_begin(c, K_OFFSETS, -1);
     HIP_TRY(hmj::launch_part_offsets(Rp, nb, low, B, (u32*)c->r_off.p, c->stream));
     span_end(c, s);
@@ -1203,7 +1231,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       return HMJ_OK;
     }
   }
-  if ((rc = partition_relation(c, S, np, c->sbuf, low, passes, pass_bits, 1, &Sp)) != HMJ_OK) return rc;
+  if ((rc = partition_relation(c, S, np, c->sbuf, low, passes, pass_bits, 1, &Sp, asc_s)) != HMJ_OK) return rc;
   s = span_begin(c, K_OFFSETS, -1);
   HIP_TRY(hmj::launch_part_offsets(Sp, np, low, B, (u32*)c->s_off.p, c->stream));
   span_end(c, s);

@@ -67,6 +67,8 @@ hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int s
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st);
 hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st,
                             bool ref_is_first_key = false);
+// *flag (zeroed by the caller) becomes 1 unless the rows' partition numbers (key >> low, `bits` bits) never decrease
+hipError_t launch_check_partitioned(const void* a, u32 n, int low, int bits, u32* flag, int num_cus, hipStream_t st);
 hipError_t launch_part_offsets(const void* a, u32 n, int low, int bits, u32* off, hipStream_t st);
 
 // probe.hip

@@ -1351,6 +1351,22 @@ hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 re
   return hipGetLastError();
 }
 
+// *flag |= 1 if some row's partition number is below its predecessor's: the relation is NOT already partitioned.
+__global__ __launch_bounds__(256) void check_partitioned_kernel(const Tup* __restrict__ a, u32 n, int low, u64 mask,
+                                                                u32* __restrict__ flag) {
+  bool bad = false;
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride)
+    bad |= ((a[i].key >> low) & mask) < ((a[i - 1].key >> low) & mask);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_check_partitioned(const void* a, u32 n, int low, int bits, u32* flag, int num_cus, hipStream_t st) {
+  const u64 mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+  hipLaunchKernelGGL(check_partitioned_kernel, dim3(num_cus * 8), dim3(256), 0, st, static_cast<const Tup*>(a), n, low, mask, flag);
+  return hipGetLastError();
+}
+
 hipError_t launch_key_sample(const void* R, u32 nb, const void* S, u32 np, u64* out, hipStream_t st) {
   hipLaunchKernelGGL(key_sample_kernel, dim3(1), dim3(1024), 0, st, static_cast<const Tup*>(R), nb,
                      static_cast<const Tup*>(S), np, out);

@@ -118,6 +118,7 @@ typedef struct {
 #define HMJ_PATH_SORTED_FK_HALF 0x8000u /* ... in its small shape: 512-thread workgroups, two per CU                */
 #define HMJ_PATH_SORTED_FK_WIDE 0x20000u /* ... in its wide shape: 6144 probe rows per partition (16-bit plan, slab path)    */
 #define HMJ_PATH_LOOKBACK_TIMEOUT 0x10000u /* a chained partition gave up waiting for its predecessor (a bug if seen) */
+#define HMJ_PATH_PRESORTED 0x40000u /* a relation arrived already partitioned (sorted by key): its radix passes were skipped */
 #define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

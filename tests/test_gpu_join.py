@@ -79,7 +79,10 @@ def test_generators_match_oracle(ex, oracle):
     assert np.array_equal(to_np(ex.gen_uniform_domain(5000, 300)), oracle.gen_uniform_domain(5000, 300))
     w = 1.0 / np.arange(1, 1001, dtype=np.float64) ** 0.9
     cdf = np.cumsum(w) / w.sum()
-    thr = np.minimum(cdf * 2.0 ** 64, float(M64)).astype(np.uint64)
+    top = cdf >= 1.0 - 2.0 ** -53  # (2^64 itself does not fit a uint64)
+    thr = np.empty(len(cdf), np.uint64)
+    thr[~top] = (cdf[~top] * 2.0 ** 64).astype(np.uint64)
+    thr[top] = M64
     thr[-1] = M64
     import torch
 
@@ -903,7 +906,29 @@ def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
     t = ex.last_timing()
     ex.set_profiling(False)
     assert r.checks() == cks and np.array_equal(ex.columns_to_numpy(r, host=False), rowss)
-    assert not (t["path"] & H.HMJ_PATH_SLAB), hex(t["path"])
+    # ... and since every row's partition number is at least its predecessor's, no radix pass runs at all
+    assert not (t["path"] & H.HMJ_PATH_SLAB) and t["path"] & H.HMJ_PATH_PRESORTED and t["ms_scatter"] == 0.0, (hex(t["path"]), t["ms_scatter"])
+    # sorted build side, shuffled probe side (and a first-wins join on a sorted build side with duplicate keys: the
+    # rows stay in input order, so "first" is the same row as after a stable pass)
+    Pm = Ps[rng.permutation(n3)]
+    ckm, rowsm = oracle.equijoin(Bs, Pm)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(Bs), to_dev(Pm), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    ex.set_profiling(False)
+    assert r.checks() == ckm and np.array_equal(ex.columns_to_numpy(r, host=False), rowsm) and t["path"] & H.HMJ_PATH_PRESORTED
+    Bd = np.stack([ks // np.uint64(3), ks + np.uint64(1)], 1)
+    ckd, _ = oracle.equijoin(Bd, Pm, first_wins=True, cap=0)
+    assert ex.join_device(to_dev(Bd), to_dev(Pm), H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM).checks() == ckd
+    # nearly sorted (one row out of place) is not partitioned: the passes run
+    Bn = Bs.copy()
+    Bn[[5, n3 - 7]] = Bn[[n3 - 7, 5]]
+    ckn, _ = oracle.equijoin(Bn, Pm, cap=0)
+    ex.set_profiling(True)
+    r = ex.join_device(to_dev(Bn), to_dev(Pm), H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    ex.set_profiling(False)
+    assert r.checks() == ckn and not (t["path"] & H.HMJ_PATH_PRESORTED)
     # reference known-answer shape: radix_hash_test.cc:82-93 keys 12345..1 (descending ints)
     k = np.arange(12345, 0, -1, dtype=np.uint64)
     D = np.stack([k, k], 1)
