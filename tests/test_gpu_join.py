@@ -1268,7 +1268,9 @@ def test_randomized_shapes_and_flags(ex, H, oracle):
         sizes += [(1 << 22) + 5, 4500000]
     flag_sets = [0, H.HMJ_CHECKSUM, H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_ORDERED | H.HMJ_CHECKSUM,
                  H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, H.HMJ_FIRST_WINS | H.HMJ_ORDERED,
-                 H.HMJ_ORDERED | H.HMJ_SUM_PROBE]
+                 H.HMJ_ORDERED | H.HMJ_SUM_PROBE,
+                 # (round 3: first-wins joins try the unique-key write modes and fall back on a duplicate build key)
+                 H.HMJ_FIRST_WINS | H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, H.HMJ_FIRST_WINS | H.HMJ_ORDERED | H.HMJ_CHECKSUM]
 
     def keys(kind, n, dom):
         if kind == "uniform":
