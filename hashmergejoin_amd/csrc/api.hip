@@ -538,16 +538,32 @@ int order_rows(hmj_ctx* c, const u32* vstart, const u32* in_base32, const u64* i
   if ((rc = ensure_dev(c, c->rbuf[1], (size_t)n * 16)) != HMJ_OK) return rc;
   sp = span_begin(c, K_ORDER, -1);
   const u64* cols[3] = {*rs, *rr, *rk};  // least significant sort key first
+  int cur = 0;  // rbuf[cur] holds the {column value, row} pairs
   for (int kcol = deferred ? 0 : 2; kcol < 3; kcol++) {
     if (kcol == (deferred ? 0 : 2))
-      HIP_TRY(hmj::launch_key_idx(cols[kcol], n, c->rbuf[0].p, c->stream));
+      HIP_TRY(hmj::launch_key_idx(cols[kcol], n, c->rbuf[cur].p, c->stream));
     else
-      HIP_TRY(hmj::launch_rekey(c->rbuf[0].p, n, cols[kcol], c->stream));
-    for (int pass = 0; pass < 8; pass++)  // eight passes end in rbuf[0] again
-      if ((rc = radix_pass(c, c->rbuf[pass & 1].p, c->rbuf[(pass & 1) ^ 1].p, (u32)n, 8 * pass, 8, -1, nullptr)) != HMJ_OK)
-        return rc;
+      HIP_TRY(hmj::launch_rekey(c->rbuf[cur].p, n, cols[kcol], c->stream));
+    // a pass only for the digits in which some value of the column differs (payloads that are row numbers, build
+    // payloads of a few thousand keys: half of the 24 passes and more are copies; as in hmj_sort_u64_device)
+    u32 digits = 0xFFu;
+    if (n >= (1u << 22)) {
+      if ((rc = ensure_dev(c, c->offs64, 8 * sizeof(u64))) != HMJ_OK) return rc;
+      const u64 init[3] = {0, ~0ull, 0};
+      HIP_TRY(hipMemcpyAsync(c->offs64.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hmj::launch_key_exact(c->rbuf[cur].p, (u32)n, nullptr, 0u, 0, (u64*)c->offs64.p, c->num_cus, c->stream, true));
+      HIP_TRY(hipMemcpyAsync(&h[7], c->offs64.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));  // (slot 7: no accumulator lives there)
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      digits = 0;
+      for (int d = 0; d < 8; d++) digits |= ((h[7] >> (8 * d)) & 0xFFu) ? (1u << d) : 0u;
+    }
+    for (int d = 0; d < 8; d++) {
+      if (!(digits & (1u << d))) continue;
+      if ((rc = radix_pass(c, c->rbuf[cur].p, c->rbuf[cur ^ 1].p, (u32)n, 8 * d, 8, -1, nullptr)) != HMJ_OK) return rc;
+      cur ^= 1;
+    }
   }
-  HIP_TRY(hmj::launch_gather3(c->rbuf[0].p, n, *rr, *rs, (u64*)c->out_key.p, (u64*)c->out_rval.p,
+  HIP_TRY(hmj::launch_gather3(c->rbuf[cur].p, n, *rr, *rs, (u64*)c->out_key.p, (u64*)c->out_rval.p,
                               (u64*)c->out_sval.p, c->stream));
   span_end(c, sp);
   *rk = (const u64*)c->out_key.p;
