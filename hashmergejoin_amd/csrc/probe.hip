@@ -1526,7 +1526,35 @@ struct OrderSmem {
   u32 bcur[OS_NB];    // bucket counts, then insertion cursors
   u32 scratch[OS_THREADS / kWave + 1];
   u32 fallback;
+  u32 mixed;                      // the segment holds more than one (key, rval) pair
+  unsigned long long svmin, svmax;  // smallest / largest sval of the segment
 };
+
+// How the rows of a segment are spread over the 4096 buckets of the in-LDS sort.  By key bits (what a join result
+// normally varies in) -- or, for a segment that is ONE key's run (a hot foreign key: thousands of rows that agree in key
+// and rval), by the position of the sval inside the segment's sval range: buckets then ascend in (key, rval, sval) order
+// all the same, and hold a handful of rows each where the key bits would put the whole run into one.  (Without it such a
+// segment went to the one-workgroup bitonic network in global memory: 2^12 build keys x 2^26 probe rows, ordered: 49 of
+// 55 ms; tools/exp_cliffs2.py.)
+struct OrderBuckets {
+  int by_sval;
+  int bsh;     // by key: bucket = key bits [bsh, bsh + 12) (key_bucket)
+  int svsh;    // by sval: bucket = (sval - svbase) >> svsh
+  u64 svbase;
+};
+__device__ __forceinline__ u32 order_bucket(const OrderBuckets& f, u64 key, u64 sval) {
+  return f.by_sval ? (u32)((sval - f.svbase) >> f.svsh) : key_bucket(key, f.bsh, OS_NB - 1);
+}
+// by-sval buckets for a segment whose svals span [mn, mx] (mx > mn)
+__device__ __forceinline__ OrderBuckets order_buckets_by_sval(u64 mn, u64 mx, int bsh) {
+  OrderBuckets f;
+  const int bits = 64 - __clzll((long long)(mx - mn));
+  f.by_sval = 1;
+  f.bsh = bsh;
+  f.svsh = bits > OS_LOGB ? bits - OS_LOGB : 0;
+  f.svbase = mn;
+  return f;
+}
 
 __device__ __forceinline__ void order_network_global(u64* k, u64* r, u64* s, u32 L, int tid) {
   u32 n2 = 2;
@@ -1567,7 +1595,7 @@ __device__ __forceinline__ void order_network_global(u64* k, u64* r, u64* s, u32
 // that the loads of consecutive candidates overlap (-11 % on a 16-fold fan-out, +13 % on unique keys).
 template <bool MANY>
 __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const u64 (&key)[OS_ROWS],
-                                                     const u64 (&rv)[OS_ROWS], const u64 (&sv)[OS_ROWS], int bsh,
+                                                     const u64 (&rv)[OS_ROWS], const u64 (&sv)[OS_ROWS], const OrderBuckets& bf,
                                                      u64 ob, u64* __restrict__ bkey, u64* __restrict__ brval,
                                                      u64* __restrict__ bsval, int tid) {
   u32 bk[OS_ROWS], dest[OS_ROWS];
@@ -1580,7 +1608,7 @@ __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const
     const u32 i = k * OS_THREADS + tid;
     bk[k] = 0;
     if (i < L) {
-      bk[k] = key_bucket(key[k], bsh, OS_NB - 1);
+      bk[k] = order_bucket(bf, key[k], sv[k]);
       sm.stage[i] = key[k];
       sm.srv[i] = rv[k];
       sm.ssv[i] = sv[k];
@@ -1695,6 +1723,11 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
   OrderSmem& sm = *reinterpret_cast<OrderSmem*>(smem_raw);
   const int tid = threadIdx.x;
   const int bsh = low - OS_LOGB;  // bucket = key bits [low-12, low)
+  OrderBuckets bf_key;
+  bf_key.by_sval = 0;
+  bf_key.bsh = bsh;
+  bf_key.svsh = 0;
+  bf_key.svbase = 0;
   for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
     // output segment: partition p's items are off[p*Q .. (p+1)*Q), or -- when oversized probe partitions
     // were split into virtual partitions -- the virtual partitions vstart[p] .. vstart[p+1]
@@ -1716,36 +1749,94 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
           sv[k] = asval[b + i];
         }
       }
-      done = order_sort_registers<MANY>(sm, L, key, rv, sv, bsh, ob, bkey, brval, bsval, tid);
+      done = order_sort_registers<MANY>(sm, L, key, rv, sv, bf_key, ob, bkey, brval, bsval, tid);
+      if (MANY && !done) {  // a bucket too long: one key's run?  then spread the rows by sval (uniform for the workgroup)
+        __syncthreads();
+        if (tid == 0) {
+          sm.mixed = 0;
+          sm.svmin = ~0ull;
+          sm.svmax = 0;
+        }
+        __syncthreads();
+        const u64 k0 = akey[b], r0 = arval[b];
+        bool mixed = false;
+        u64 mn = ~0ull, mx = 0;
+#pragma unroll
+        for (int k = 0; k < OS_ROWS; k++) {
+          if ((u32)(k * OS_THREADS + tid) < L) {
+            mixed |= key[k] != k0 || rv[k] != r0;
+            mn = sv[k] < mn ? sv[k] : mn;
+            mx = sv[k] > mx ? sv[k] : mx;
+          }
+        }
+        if (mixed) sm.mixed = 1;
+        atomicMin(&sm.svmin, (unsigned long long)mn);
+        atomicMax(&sm.svmax, (unsigned long long)mx);
+        __syncthreads();
+        if (sm.mixed == 0 && sm.svmax > sm.svmin)
+          done = order_sort_registers<MANY>(sm, L, key, rv, sv, order_buckets_by_sval(sm.svmin, sm.svmax, bsh), ob, bkey, brval, bsval, tid);
+      }
     } else if (L64 <= (u64)OS_CHUNKS * OS_CHUNK_ROWS) {
       const u32 L = (u32)L64;
       // bucket counts of the whole segment -> bucket starts (kept in bstart32, aliased on sidx + bstart:
       // they are free until a chunk is sorted, so the starts are rebuilt per chunk from the counts instead)
-      __syncthreads();
-      for (u32 i = tid; i < (u32)OS_NB; i += OS_THREADS) sm.bcur[i] = 0;
-      if (tid == 0) sm.fallback = 0;
-      __syncthreads();
-      for (u32 i = tid; i < L; i += OS_THREADS) atomicAdd(&sm.bcur[key_bucket(akey[b + i], bsh, OS_NB - 1)], 1u);
-      __syncthreads();
+      OrderBuckets bf = bf_key;
       u32 st[4];  // start of this thread's four buckets in the sorted segment
-      {
-        u32 c[4], sum = 0, mx = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          c[q] = sm.bcur[tid * 4 + q];
-          sum += c[q];
-          mx = c[q] > mx ? c[q] : mx;
+      for (int attempt = 0; attempt < (MANY ? 2 : 1); attempt++) {
+        __syncthreads();
+        for (u32 i = tid; i < (u32)OS_NB; i += OS_THREADS) sm.bcur[i] = 0;
+        if (tid == 0) sm.fallback = 0;
+        __syncthreads();
+        if (bf.by_sval) {
+          for (u32 i = tid; i < L; i += OS_THREADS) atomicAdd(&sm.bcur[order_bucket(bf, 0, asval[b + i])], 1u);
+        } else {
+          for (u32 i = tid; i < L; i += OS_THREADS) atomicAdd(&sm.bcur[order_bucket(bf, akey[b + i], 0)], 1u);
         }
-        if (mx > OS_MAXBUCKET) sm.fallback = 1;
-        u32 tot;
-        u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
+        __syncthreads();
+        {
+          u32 c[4], sum = 0, mx = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          st[q] = ex;
-          ex += c[q];
+          for (int q = 0; q < 4; q++) {
+            c[q] = sm.bcur[tid * 4 + q];
+            sum += c[q];
+            mx = c[q] > mx ? c[q] : mx;
+          }
+          if (mx > OS_MAXBUCKET) sm.fallback = 1;
+          u32 tot;
+          u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            st[q] = ex;
+            ex += c[q];
+          }
         }
+        __syncthreads();
+        if (sm.fallback == 0 || attempt == 1 || !MANY) break;
+        // a bucket too long: is the segment one key's run?  then spread its rows by sval and count again
+        if (tid == 0) {
+          sm.mixed = 0;
+          sm.svmin = ~0ull;
+          sm.svmax = 0;
+        }
+        __syncthreads();
+        {
+          const u64 k0 = akey[b], r0 = arval[b];
+          bool mixed = false;
+          u64 mn = ~0ull, mx = 0;
+          for (u32 i = tid; i < L; i += OS_THREADS) {
+            mixed |= akey[b + i] != k0 || arval[b + i] != r0;
+            const u64 x = asval[b + i];
+            mn = x < mn ? x : mn;
+            mx = x > mx ? x : mx;
+          }
+          if (mixed) sm.mixed = 1;
+          atomicMin(&sm.svmin, (unsigned long long)mn);
+          atomicMax(&sm.svmax, (unsigned long long)mx);
+        }
+        __syncthreads();
+        if (sm.mixed != 0 || sm.svmax <= sm.svmin) break;  // (fallback stays set)
+        bf = order_buckets_by_sval(sm.svmin, sm.svmax, bsh);
       }
-      __syncthreads();
       if (sm.fallback == 0) {
         // chunk c = the buckets whose start lies in [c * OS_CHUNK_ROWS, (c+1) * OS_CHUNK_ROWS): at most
         // OS_CHUNK_ROWS + OS_MAXBUCKET = OS_CAP rows.  chunk_of[bucket] goes to sidx (u16, free here).
@@ -1767,12 +1858,12 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
           for (u32 i0r = 0; i0r < L; i0r += OS_THREADS) {
             const u32 i = i0r + tid;
             if (i < L) {
-              const u64 kk = akey[b + i];
-              if (sm.sidx[key_bucket(kk, bsh, OS_NB - 1)] == (u16)cnk) {
+              const u64 kk = akey[b + i], ss = asval[b + i];
+              if (sm.sidx[order_bucket(bf, kk, ss)] == (u16)cnk) {
                 const u32 slot = atomicAdd(&sm.scratch[0], 1u);
                 sm.stage[slot] = kk;
                 sm.srv[slot] = arval[b + i];
-                sm.ssv[slot] = asval[b + i];
+                sm.ssv[slot] = ss;
               }
             }
           }
@@ -1794,7 +1885,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
           u32 cnt_keep[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) cnt_keep[q] = sm.bcur[tid * 4 + q];
-          order_sort_registers<MANY>(sm, n_c, key, rv, sv, bsh, ob + base_c, bkey, brval, bsval, tid);
+          order_sort_registers<MANY>(sm, n_c, key, rv, sv, bf, ob + base_c, bkey, brval, bsval, tid);
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             sm.sidx[tid * 4 + q] = (u16)(st[q] / OS_CHUNK_ROWS);
