@@ -316,6 +316,31 @@ def test_ordered_rows_of_very_few_keys(ex, H, oracle):
     ex.release_result()
 
 
+@pytest.mark.parametrize("n_keys,payloads", [(300, "distinct"), (50, "distinct"), (50, "ties"), (300, "few_values")])
+def test_ordered_epilogue_sorts_one_keys_run_by_its_payloads(ex, H, oracle, n_keys, payloads):
+    # a hot foreign key: thousands of result rows that agree in key and rval.  With one such key per partition (forced
+    # 12-bit plan) the ordered epilogue cannot spread the segment over its buckets by key bits; it spreads it by sval
+    # instead (one LDS sort for ~3500 rows, LDS chunks for ~20000) -- unless the svals themselves pile up (heavy ties:
+    # the sorting network as before).  Always the oracle's rows.
+    rng = np.random.default_rng(n_keys)
+    kb = np.unique(rng.integers(0, 1 << 63, size=n_keys, dtype=np.uint64))
+    B = np.stack([kb, rng.integers(0, 1 << 62, size=len(kb), dtype=np.uint64)], 1)
+    n = 1 << 20
+    sv = {"distinct": rng.permutation(n).astype(np.uint64) * np.uint64(977),
+          "ties": rng.integers(0, 2000, size=n).astype(np.uint64),
+          "few_values": rng.integers(0, 7, size=n).astype(np.uint64)}[payloads]
+    P = np.stack([kb[rng.integers(0, len(kb), size=n)], sv], 1)
+    ck, rows = oracle.equijoin(B, P)
+    ex.set_radix_bits(12)
+    try:
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    finally:
+        ex.set_radix_bits(None)
+    assert r.checks() == ck
+    assert np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+    ex.release_result()
+
+
 def test_ordered_many_to_many_uses_the_chunked_epilogue(ex, H, oracle):
     # Every key about twice on both sides: four result rows per key, so a partition's result is several times
     # the LDS sort's capacity.  The ordered epilogue then sorts it in chunks of consecutive key buckets (not
