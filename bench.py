@@ -305,13 +305,22 @@ def main():
         loc, glob = ex.exchange_join(R, S, flags)  # owner split, exchange rounds, prepared build, local join
         return glob, ex.last_timing(), ex.last_exchange_info()
 
+    # Workspace ahead of the first join, as a caller who cares about the first join's latency does (hmj_reserve):
+    # this is also where the library may search for well-placed partition buffers, under its wall-clock budget
+    # (`placement`; a join that allocates on its own only probes what it got).  Outside the timed region.
+    reserve_ms = None
+    if not distributed:
+        t_w = time.perf_counter()
+        ex.reserve(n, n, n if a.materialize else 0, flags)
+        torch.cuda.synchronize()
+        reserve_ms = (time.perf_counter() - t_w) * 1e3
     first_ms = None
     for i in range(a.warmup):
         t_w = time.perf_counter()
         res, _, _ = step()
         if i == 0:
             torch.cuda.synchronize()
-            first_ms = (time.perf_counter() - t_w) * 1e3  # creates the workspace (and probes its placement)
+            first_ms = (time.perf_counter() - t_w) * 1e3  # first join of the context (N > 1: it creates the workspace)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -340,6 +349,7 @@ def main():
         dt, probe_ms_slowest = float(t[0].item()), float(t[1].item())
     assert n_matches == n_total, "every probe row must match exactly once (%d != %d)" % (n_matches, n_total)
 
+    exit_code = 0
     if rank == 0:
         K = a.steps
         ms_step = dt / K * 1e3
@@ -427,8 +437,10 @@ def main():
             "phases_ms_per_step": {k[3:]: round(v / K, 4) for k, v in agg.items() if k.startswith("ms_")},
             # why the scatter passes ran at the rate they did on THIS box: the fill rate of each partition buffer the
             # library kept (write bandwidth is a property of the physical memory behind a buffer)
-            "placement": {"probing": os.environ.get("HMJ_PLACE", "default (on, <= 4 candidates)"),
+            "placement": {"probing": os.environ.get("HMJ_PLACE", "default: joins probe only; hmj_reserve searches (<= 4 candidates, "
+                                                                   "<= HMJ_PLACE_BUDGET_MS = 50 ms per buffer)"),
                           "buffers": ex.placement_info(),
+                          "reserve_ms": None if reserve_ms is None else round(reserve_ms, 2),
                           "first_join_ms": None if first_ms is None else round(first_ms, 2)},
         }
         if distributed:
@@ -456,10 +468,15 @@ def main():
             del R, S
             torch.cuda.empty_cache()
             if not a.no_extra:
+                # the extra runs CHECK their results (match counts, configs[4] against closed forms): a failure there
+                # is a wrong join, so the line says so and the process exits non-zero after printing it
                 try:
                     line["extra"] = extra_runs(ex, H, torch)
-                except Exception as e:  # reporting only
+                    line["extra_ok"] = True
+                except Exception as e:
                     line["extra"] = {"error": repr(e)}
+                    line["extra_ok"] = False
+                    exit_code = 3
             if not a.no_cpu:
                 try:
                     cores, aff = usable_cores()
@@ -470,6 +487,8 @@ def main():
     ex.close()
     if world > 1:
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -60,7 +60,8 @@ class Timing(C.Structure):
 
 class PlaceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 16), ("bytes", C.c_uint64), ("fill_TBps", C.c_float), ("candidates", C.c_int),
-                ("ms_search", C.c_float)]
+                ("ms_search", C.c_float), ("searched", C.c_int), ("aborted", C.c_int), ("budget_ms", C.c_float),
+                ("cand_ms_alloc", C.c_float * 4), ("cand_ms_fill", C.c_float * 4), ("cand_TBps", C.c_float * 4)]
 
 
 def lib_path():

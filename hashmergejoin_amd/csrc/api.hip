@@ -62,23 +62,31 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
     if (g) want = (want + g - 1) / g * g;
   }
 #endif
+  const auto t_alloc0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
     b.p = nullptr;
     (void)hipGetLastError();
     return fail(c, HMJ_E_OOM, "hipMalloc", e);
   }
+  const float ms_alloc0 = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count();
   b.cap = want;
   // ---- placement.  How fast a buffer can be WRITTEN depends on the physical memory the driver backs it with
   // (tools/micro/place_bw.hip, place_vmm.hip: allocations of one process fill at 4.4-4.6 TB/s or
   // at 5.3-5.7 TB/s, the same buffer always the same, whichever API created it; reads do not care).  Only the buffers
-  // the partition passes write -- where the effect was measured -- are probed: filled twice, the second fill timed,
-  // and while one fills slower than a good one does, another candidate is allocated (the previous one still held, so
-  // it is other memory) and the best is kept.  At most c->place_tries candidates (HMJ_PLACE=n; 0 = take what comes).
+  // the partition passes write -- where the effect was measured -- of 2 GiB and more (HMJ_PLACE_MIN_MB) are looked at:
+  //   * every such allocation is PROBED: filled twice, the second fill timed (2.4 ms for 6 GB), the rate logged
+  //     (hmj_placement_info) -- that is all a join does on its own;
+  //   * a SEARCH for better memory runs only when the caller asked for workspace ahead of time (hmj_reserve) or set
+  //     HMJ_PLACE=n in the environment: while the buffer fills slower than a good one does, another candidate is
+  //     allocated and the faster of the two kept -- never more than two alive (2 x want), at most c->place_tries
+  //     candidates, and under a wall-clock budget (c->place_budget_ms, HMJ_PLACE_BUDGET_MS; 50 ms): round 3's driver
+  //     run paid 1.3 s in the first join for one buffer whose three extra candidates took 435 ms each to create
+  //     (BENCH_r03: the other two buffers' searches cost 13 ms), for a gain of at most 0.3 ms per join.  The search
+  //     stops as soon as what it has spent plus what the last candidate cost would exceed the budget; every
+  //     candidate's hipMalloc and fill times are recorded.
   // Exchange buffers, result columns and upload targets are never probed (their (re)growth must not stall
-  // in-flight rounds with extra device-synchronising hipMalloc / hipFree calls), and nothing below 2 GiB is
-  // (HMJ_PLACE_MIN_MB): a fresh candidate costs ~30 ms per 1.5 GB (the driver clears new memory), so a 2^26-row
-  // join's one-shot host call took 374-407 ms with the search against 170 ms without it, for 0.1 ms per join.
+  // in-flight rounds with extra device-synchronising hipMalloc / hipFree calls).
   const char* pname = !c ? nullptr
                       : &b == &c->slab_a ? "slab_a" : &b == &c->slab_br ? "slab_b_build" : &b == &c->slab_bs ? "slab_b_probe"
                       : &b == &c->rbuf[0] ? "rbuf0" : &b == &c->rbuf[1] ? "rbuf1" : &b == &c->sbuf[0] ? "sbuf0"
@@ -90,9 +98,11 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
         c->place_tune = false;
       }
     }
-    const auto t_search = std::chrono::steady_clock::now();
+    typedef std::chrono::steady_clock clk;
+    const auto t_search = clk::now();
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); };
     // "good": 5.2 TB/s (bytes per ms) -- or, once this context has seen what the box gives, 92 % of the best fill so
-    // far if that is less (a box where every allocation writes slowly should not pay for two more candidates each time)
+    // far if that is less (a box where every allocation writes slowly should not pay for more candidates each time)
     const double good = c->place_best > 0.0 && 0.92 * c->place_best < 5.2e9 ? 0.92 * c->place_best : 5.2e9;
     auto probe = [&](void* p) -> double {
       float ms = 0.f;
@@ -104,45 +114,55 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
       if (hipEventElapsedTime(&ms, c->place_ev[0], c->place_ev[1]) != hipSuccess || ms <= 0.f) return 0.0;
       return (double)want / (double)ms;
     };
+    hmj_place_info pi;
+    std::memset(&pi, 0, sizeof(pi));
+    std::snprintf(pi.name, sizeof(pi.name), "%s", pname);
+    pi.bytes = want;
+    pi.budget_ms = c->place_budget_ms;
+    pi.cand_ms_alloc[0] = ms_alloc0;
+    auto t_c = clk::now();
     double best_rate = c->place_tune ? probe(b.p) : 0.0;
-    void* held = nullptr;  // the latest loser: freed only after the next candidate exists (so that one is other memory)
+    pi.cand_ms_fill[0] = ms_since(t_c);
+    pi.cand_TBps[0] = (float)(best_rate * 1e-9);
     int tried = 1;
-    for (; c->place_tune && tried < c->place_tries && best_rate > 0.0 && best_rate < good; tried++) {
+    const bool search = c->place_search_always || c->in_reserve;
+    for (; search && c->place_tune && tried < c->place_tries && tried < HMJ_PLACE_MAX_CAND && best_rate > 0.0 &&
+           best_rate < good; tried++) {
+      // budget: what the search has spent so far plus what the previous extra candidate cost (the first extra one is
+      // assumed to cost what the first allocation did) must stay inside it
+      const float spent = ms_since(t_search);
+      const float last = tried == 1 ? ms_alloc0 + pi.cand_ms_fill[0] : pi.cand_ms_alloc[tried - 1] + pi.cand_ms_fill[tried - 1];
+      if (spent + last > c->place_budget_ms) {
+        pi.aborted = 1;
+        break;
+      }
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
-      if (held && free_b < 3 * want) {  // memory is getting tight: at most two candidates alive at a time
-        (void)hipFree(held);
-        held = nullptr;
-        free_b += want;
-      }
       if (free_b < want + (8ull << 30)) break;
+      t_c = clk::now();
       void* cand = nullptr;
       if (hipMalloc(&cand, want) != hipSuccess) {
         (void)hipGetLastError();
         break;
       }
-      if (held) {
-        (void)hipFree(held);
-        held = nullptr;
-      }
+      pi.cand_ms_alloc[tried] = ms_since(t_c);
+      t_c = clk::now();
       const double r = probe(cand);
+      pi.cand_TBps[tried] = (float)(r * 1e-9);
+      void* loser = cand;
       if (r > best_rate) {
-        held = b.p;
+        loser = b.p;
         b.p = cand;
         best_rate = r;
-      } else {
-        held = cand;
       }
+      (void)hipFree(loser);  // (never more than two candidates alive: the kept one and the one being probed)
+      pi.cand_ms_fill[tried] = ms_since(t_c);  // fill + the loser's hipFree (device-synchronising)
     }
-    if (held) (void)hipFree(held);
     if (best_rate > c->place_best) c->place_best = best_rate;
-    hmj_place_info pi;
-    std::memset(&pi, 0, sizeof(pi));
-    std::snprintf(pi.name, sizeof(pi.name), "%s", pname);
-    pi.bytes = want;
     pi.fill_TBps = (float)(best_rate * 1e-9);
     pi.candidates = tried;
-    pi.ms_search = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_search).count();
+    pi.searched = search ? 1 : 0;
+    pi.ms_search = ms_since(t_search);
     bool replaced = false;
     for (hmj_place_info& e : c->place_log)
       if (std::strcmp(e.name, pi.name) == 0) {
@@ -151,8 +171,9 @@ int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
       }
     if (!replaced) c->place_log.push_back(pi);
     if (c->trace)
-      std::fprintf(stderr, "[hmj]   placement: %s %.1f MiB fill at %.2f TB/s after %d candidate%s (%.1f ms)\n", pname,
-                   (double)want / 1048576.0, best_rate * 1e-9, tried, tried == 1 ? "" : "s", pi.ms_search);
+      std::fprintf(stderr, "[hmj]   placement: %s %.1f MiB fill at %.2f TB/s after %d candidate%s (%.1f ms%s%s)\n", pname,
+                   (double)want / 1048576.0, best_rate * 1e-9, tried, tried == 1 ? "" : "s", pi.ms_search,
+                   search ? "" : ", probe only", pi.aborted ? ", budget reached" : "");
   }
   if (c && c->trace && want >= (64u << 20))
     std::fprintf(stderr, "[hmj] hipMalloc %.1f MiB -> %p (low 30 bits %#llx)\n", (double)want / 1048576.0, b.p,
@@ -1530,9 +1551,15 @@ int hmj_create(hmj_ctx** out, int device_id) {
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
-  if (const char* e = getenv("HMJ_PLACE")) {  // 0: off; n: at most n candidates per big allocation
+  if (const char* e = getenv("HMJ_PLACE")) {  // 0: nothing is probed; n: joins search too (at most n candidates per buffer)
     c->place_tune = atoi(e) != 0;
-    if (atoi(e) > 0) c->place_tries = atoi(e);
+    if (atoi(e) > 0) {
+      c->place_tries = atoi(e);
+      c->place_search_always = true;
+    }
+  }
+  if (const char* e = getenv("HMJ_PLACE_BUDGET_MS")) {
+    if (atof(e) >= 0.0) c->place_budget_ms = (float)atof(e);
   }
   if (const char* e = getenv("HMJ_PLACE_MIN_MB")) {
     const long long mb = atoll(e);
@@ -1724,6 +1751,11 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
   if (n_build > 0xFFFFFFFFull || n_probe > 0xFFFFFFFFull) return fail(c, HMJ_E_ARG, "too many rows");
   HIP_TRY(hipSetDevice(c->device));
   c->prep.valid = false;  // "any other call discards the prepared state" (hmj.h)
+  struct InReserve {  // the caller asked for the workspace ahead of time: big partition buffers may search for fast memory
+    hmj_ctx* c;
+    explicit InReserve(hmj_ctx* c_) : c(c_) { c->in_reserve = true; }
+    ~InReserve() { c->in_reserve = false; }
+  } in_reserve(c);
   int B, passes, pass_bits[4], rc;
   plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
   const size_t P = (size_t)1 << B;

@@ -64,7 +64,10 @@ struct hmj_ctx {
   bool prepare_only = false;
   int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
   // placement of big allocations (ensure_dev, api.hip): candidates are probed with a fill and the fastest kept
-  int place_tries = 4;     // candidates per allocation (HMJ_PLACE=n); a fresh candidate of 6 GB costs ~150 ms (the driver clears it)
+  int place_tries = 4;     // candidates per allocation when a search runs (HMJ_PLACE=n); a fresh candidate of 6 GB costs 3-450 ms
+  float place_budget_ms = 50.f;  // wall-clock budget of one buffer's search (HMJ_PLACE_BUDGET_MS)
+  bool place_search_always = false;  // HMJ_PLACE=n set in the environment: joins search too, not only hmj_reserve
+  bool in_reserve = false;           // inside hmj_reserve: the caller asked for workspace ahead of time -> search
   hipEvent_t place_ev[2] = {nullptr, nullptr};
   double place_best = 0.0;  // best fill rate (bytes per ms) any probed allocation of this context reached
   bool place_tune = true;  // HMJ_PLACE=0: take the buffers as the driver hands them out

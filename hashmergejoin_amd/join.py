@@ -98,12 +98,21 @@ class Executor:
         return t.as_dict()
 
     def placement_info(self):
-        """[{name, bytes, fill_TBps, candidates, ms_search}] for the big partition buffers this executor probed
-        (hmj_placement_info; empty with HMJ_PLACE=0)."""
+        """One dict per big partition buffer this executor probed (hmj_placement_info; empty with HMJ_PLACE=0):
+        name, bytes, fill rate of the allocation kept, candidates tried, whether a search ran (hmj_reserve or
+        HMJ_PLACE=n) and was cut short by its budget, and per candidate the hipMalloc ms, fill ms and fill rate."""
         arr = (_lib.PlaceInfo * 16)()
         n = self.L.hmj_placement_info(self.h, arr, 16)
-        return [{"name": arr[i].name.decode(), "bytes": int(arr[i].bytes), "fill_TBps": round(float(arr[i].fill_TBps), 3),
-                 "candidates": int(arr[i].candidates), "ms_search": round(float(arr[i].ms_search), 2)} for i in range(n)]
+        out = []
+        for i in range(n):
+            e, k = arr[i], int(arr[i].candidates)
+            out.append({"name": e.name.decode(), "bytes": int(e.bytes), "fill_TBps": round(float(e.fill_TBps), 3),
+                        "candidates": k, "ms_search": round(float(e.ms_search), 2), "searched": bool(e.searched),
+                        "aborted": bool(e.aborted), "budget_ms": round(float(e.budget_ms), 1),
+                        "cand_ms_alloc": [round(float(x), 2) for x in e.cand_ms_alloc[:k]],
+                        "cand_ms_fill": [round(float(x), 2) for x in e.cand_ms_fill[:k]],
+                        "cand_TBps": [round(float(x), 3) for x in e.cand_TBps[:k]]})
+        return out
 
     # ---- joins -------------------------------------------------------------------------------
     def join_device(self, build, probe, flags=0):

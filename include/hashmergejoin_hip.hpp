@@ -67,6 +67,8 @@ inline void check(hmj_ctx* c, int rc, const char* what) {
     throw std::runtime_error(std::string(what) + ": " + hmj_strerror(rc) + " (" + hmj_last_error(c) + ")");
 }
 
+// A relation the GPU path takes: std::pair<uint64_t, 8-byte trivially copyable payload> rows behind a random
+// access iterator -- all the reference asks of its iterators is `begin + k` (radix_hash.h:375-388).
 template <typename Iter>
 struct is_hmj_relation_iter {
   typedef typename std::iterator_traits<Iter>::value_type item;
@@ -77,6 +79,51 @@ struct is_hmj_relation_iter {
                             std::is_base_of<std::random_access_iterator_tag,
                                             typename std::iterator_traits<Iter>::iterator_category>::value;
 };
+
+// Only a range known to be CONTIGUOUS has one address to hand to the C ABI: raw pointers and std::vector's
+// iterators (C++11 has no contiguous_iterator_tag to ask).  Every other random access iterator -- std::deque's,
+// a reverse_iterator, a strided view -- is legal for the reference and is copied row by row into a contiguous
+// staging vector first (relation_rows below); it is never read as `addressof(*begin)` + n.
+template <typename Iter>
+struct is_contiguous_iter {
+  typedef typename std::remove_cv<typename std::iterator_traits<Iter>::value_type>::type T;
+  static const bool value = std::is_pointer<Iter>::value ||
+                            std::is_same<Iter, typename std::vector<T>::iterator>::value ||
+                            std::is_same<Iter, typename std::vector<T>::const_iterator>::value;
+};
+
+typedef std::vector<std::pair<std::uint64_t, std::uint64_t>> StagedRows;
+
+template <typename T>
+inline void check_pair_layout(const T& row) {  // std::pair<uint64_t,V> must be laid out {first, second}
+  const char* b = reinterpret_cast<const char*>(std::addressof(row));
+  if (reinterpret_cast<const char*>(std::addressof(row.first)) != b ||
+      reinterpret_cast<const char*>(std::addressof(row.second)) - b != 8)
+    throw std::runtime_error("HashMergeJoin: unexpected std::pair layout");
+}
+template <typename Iter>
+inline const void* relation_rows(Iter begin, std::size_t n, StagedRows&, std::true_type /*contiguous*/) {
+  if (!n) return nullptr;
+  check_pair_layout(*begin);
+  return static_cast<const void*>(std::addressof(*begin));
+}
+template <typename Iter>
+inline const void* relation_rows(Iter begin, std::size_t n, StagedRows& stage, std::false_type) {
+  if (!n) return nullptr;
+  check_pair_layout(*begin);
+  stage.resize(n);
+  for (std::size_t i = 0; i < n; i++, ++begin) {
+    stage[i].first = begin->first;
+    std::memcpy(&stage[i].second, std::addressof(begin->second), 8);
+  }
+  return static_cast<const void*>(stage.data());
+}
+// the rows of [begin, begin + n) as one contiguous block of n x {u64 key, 8-byte payload}: the caller's own
+// storage when the iterator type guarantees contiguity, else a copy held by `stage`
+template <typename Iter>
+inline const void* relation_rows(Iter begin, std::size_t n, StagedRows& stage) {
+  return relation_rows(begin, n, stage, std::integral_constant<bool, is_contiguous_iter<Iter>::value>());
+}
 
 // Join two relations given as {64-bit hash, row index} rows on the GPU and keep the pairs whose KEYS are
 // equal (eq(r_row, s_row)); inside a run of equal hashes the pairs are ordered by key (less(r_row_a,
@@ -134,16 +181,16 @@ class HashMergeJoin;
 
 template <typename RIter, typename SIter>
 class HashMergeJoin<RIter, SIter, true> {
-  static_assert(std::is_same<typename RIter::value_type::first_type,
-                             typename SIter::value_type::first_type>::value,
+  static_assert(std::is_same<typename std::iterator_traits<RIter>::value_type::first_type,
+                             typename std::iterator_traits<SIter>::value_type::first_type>::value,
                 "RIter and SIter key type must be the same");
-  static_assert(std::is_same<typename RIter::difference_type, typename SIter::difference_type>::value,
+  static_assert(std::is_same<typename std::iterator_traits<RIter>::difference_type, typename std::iterator_traits<SIter>::difference_type>::value,
                 "RIter and SIter difference type must be the same");
 
-  typedef typename RIter::difference_type distance_type;
-  typedef typename RIter::value_type::first_type Key;
-  typedef typename RIter::value_type::second_type RValue;
-  typedef typename SIter::value_type::second_type SValue;
+  typedef typename std::iterator_traits<RIter>::difference_type distance_type;
+  typedef typename std::iterator_traits<RIter>::value_type::first_type Key;
+  typedef typename std::iterator_traits<RIter>::value_type::second_type RValue;
+  typedef typename std::iterator_traits<SIter>::value_type::second_type SValue;
 
  public:
   HashMergeJoin() = default;
@@ -151,13 +198,9 @@ class HashMergeJoin<RIter, SIter, true> {
   // PCIe copy; the join itself runs on the GPU.
   HashMergeJoin(RIter r_begin, RIter r_end, SIter s_begin, SIter s_end, unsigned int num_threads = 1) {
     const distance_type r_size = std::distance(r_begin, r_end), s_size = std::distance(s_begin, s_end);
-    const void* r_ptr = r_size ? static_cast<const void*>(std::addressof(*r_begin)) : nullptr;
-    const void* s_ptr = s_size ? static_cast<const void*>(std::addressof(*s_begin)) : nullptr;
-    if (r_size) {  // std::pair<uint64_t,V> must be laid out {first, second}
-      const char* b = reinterpret_cast<const char*>(std::addressof(*r_begin));
-      if (reinterpret_cast<const char*>(std::addressof(r_begin->second)) - b != 8)
-        throw std::runtime_error("HashMergeJoin: unexpected std::pair layout");
-    }
+    hmj_detail::StagedRows r_stage, s_stage;  // used only by iterators that are not known to be contiguous
+    const void* r_ptr = hmj_detail::relation_rows(r_begin, (std::size_t)r_size, r_stage);
+    const void* s_ptr = hmj_detail::relation_rows(s_begin, (std::size_t)s_size, s_stage);
     hmj_ctx* c = hmj_detail::thread_ctx();
     hmj_set_host_threads(c, num_threads > 16 ? 16 : (int)num_threads);
     hmj_result res;
@@ -230,10 +273,10 @@ class HashMergeJoin<RIter, SIter, true> {
 // ---------------------------------------------------------------------------------------------------
 template <typename RIter, typename SIter>
 class HashMergeJoin<RIter, SIter, false> {
-  static_assert(std::is_same<typename RIter::value_type::first_type,
-                             typename SIter::value_type::first_type>::value,
+  static_assert(std::is_same<typename std::iterator_traits<RIter>::value_type::first_type,
+                             typename std::iterator_traits<SIter>::value_type::first_type>::value,
                 "RIter and SIter key type must be the same");
-  static_assert(std::is_same<typename RIter::difference_type, typename SIter::difference_type>::value,
+  static_assert(std::is_same<typename std::iterator_traits<RIter>::difference_type, typename std::iterator_traits<SIter>::difference_type>::value,
                 "RIter and SIter difference type must be the same");
   static_assert(std::is_base_of<std::random_access_iterator_tag,
                                 typename std::iterator_traits<RIter>::iterator_category>::value &&
@@ -241,10 +284,10 @@ class HashMergeJoin<RIter, SIter, false> {
                                     typename std::iterator_traits<SIter>::iterator_category>::value,
                 "random access iterators are required");
 
-  typedef typename RIter::difference_type distance_type;
-  typedef typename RIter::value_type::first_type Key;
-  typedef typename RIter::value_type::second_type RValue;
-  typedef typename SIter::value_type::second_type SValue;
+  typedef typename std::iterator_traits<RIter>::difference_type distance_type;
+  typedef typename std::iterator_traits<RIter>::value_type::first_type Key;
+  typedef typename std::iterator_traits<RIter>::value_type::second_type RValue;
+  typedef typename std::iterator_traits<SIter>::value_type::second_type SValue;
 
   template <typename Iter>
   static void hash_rows(Iter begin, std::size_t n, std::vector<std::pair<std::uint64_t, std::uint64_t>>& out,
@@ -298,8 +341,8 @@ class HashMergeJoin<RIter, SIter, false> {
     bool operator==(iterator other) const { return _pos == other._pos; }
     bool operator!=(iterator other) const { return _pos != other._pos; }
     std::tuple<Key*, RValue*, SValue*>& operator*() {
-      const typename RIter::value_type& rr = _owner->_r[_owner->_ri[_pos]];
-      const typename SIter::value_type& ss = _owner->_s[_owner->_si[_pos]];
+      const typename std::iterator_traits<RIter>::value_type& rr = _owner->_r[_owner->_ri[_pos]];
+      const typename std::iterator_traits<SIter>::value_type& ss = _owner->_s[_owner->_si[_pos]];
       tmp_val = std::make_tuple(const_cast<Key*>(&rr.first), const_cast<RValue*>(&rr.second),
                                 const_cast<SValue*>(&ss.second));
       return tmp_val;
@@ -339,10 +382,10 @@ class HashMergeJoin<RIter, SIter, false> {
 // ---------------------------------------------------------------------------------------------------
 template <typename RIter, typename SIter>
 class HashMergeJoin2 {
-  static_assert(std::is_same<typename std::tuple_element<1, typename RIter::value_type>::type,
-                             typename std::tuple_element<1, typename SIter::value_type>::type>::value,
+  static_assert(std::is_same<typename std::tuple_element<1, typename std::iterator_traits<RIter>::value_type>::type,
+                             typename std::tuple_element<1, typename std::iterator_traits<SIter>::value_type>::type>::value,
                 "RIter and SIter key type must be the same");
-  static_assert(std::is_same<typename RIter::difference_type, typename SIter::difference_type>::value,
+  static_assert(std::is_same<typename std::iterator_traits<RIter>::difference_type, typename std::iterator_traits<SIter>::difference_type>::value,
                 "RIter and SIter difference type must be the same");
   static_assert(std::is_base_of<std::random_access_iterator_tag,
                                 typename std::iterator_traits<RIter>::iterator_category>::value &&
@@ -350,9 +393,9 @@ class HashMergeJoin2 {
                                     typename std::iterator_traits<SIter>::iterator_category>::value,
                 "random access iterators are required");
 
-  typedef typename std::tuple_element<1, typename RIter::value_type>::type Key;
-  typedef typename std::tuple_element<2, typename RIter::value_type>::type RValue;
-  typedef typename std::tuple_element<2, typename SIter::value_type>::type SValue;
+  typedef typename std::tuple_element<1, typename std::iterator_traits<RIter>::value_type>::type Key;
+  typedef typename std::tuple_element<2, typename std::iterator_traits<RIter>::value_type>::type RValue;
+  typedef typename std::tuple_element<2, typename std::iterator_traits<SIter>::value_type>::type SValue;
 
   template <typename Iter>
   static void hash_column(Iter begin, std::size_t n, std::vector<std::pair<std::uint64_t, std::uint64_t>>& out) {
@@ -426,8 +469,8 @@ class HashMergeJoin2 {
     bool operator==(iterator other) const { return _pos == other._pos; }
     bool operator!=(iterator other) const { return _pos != other._pos; }
     std::tuple<Key*, RValue*, SValue*>& operator*() {
-      typename RIter::value_type& rr = _owner->_r[_owner->_ri[_pos]];
-      typename SIter::value_type& ss = _owner->_s[_owner->_si[_pos]];
+      typename std::iterator_traits<RIter>::value_type& rr = _owner->_r[_owner->_ri[_pos]];
+      typename std::iterator_traits<SIter>::value_type& ss = _owner->_s[_owner->_si[_pos]];
       tmp_val = std::make_tuple(&std::get<1>(rr), &std::get<2>(rr), &std::get<2>(ss));
       return tmp_val;
     }
@@ -465,14 +508,14 @@ template <typename RIter, typename SIter>
 std::uint64_t hash_merge_join_sum(RIter r_begin, RIter r_end, SIter s_begin, SIter s_end,
                                   std::uint64_t* n_matches = nullptr) {
   static_assert(hmj_detail::is_hmj_relation_iter<RIter>::value && hmj_detail::is_hmj_relation_iter<SIter>::value,
-                "the MI355X executor joins contiguous std::pair<uint64_t, 8-byte payload> relations");
+                "the MI355X executor joins std::pair<uint64_t, 8-byte payload> relations");
   const auto r_size = std::distance(r_begin, r_end), s_size = std::distance(s_begin, s_end);
+  hmj_detail::StagedRows r_stage, s_stage;
+  const void* r_ptr = hmj_detail::relation_rows(r_begin, (std::size_t)r_size, r_stage);
+  const void* s_ptr = hmj_detail::relation_rows(s_begin, (std::size_t)s_size, s_stage);
   hmj_ctx* c = hmj_detail::thread_ctx();
   hmj_result res;
-  hmj_detail::check(c, hmj_join_u64(c, r_size ? static_cast<const void*>(std::addressof(*r_begin)) : nullptr,
-                                    (uint64_t)r_size,
-                                    s_size ? static_cast<const void*>(std::addressof(*s_begin)) : nullptr,
-                                    (uint64_t)s_size, 0, &res), "hmj_join_u64");
+  hmj_detail::check(c, hmj_join_u64(c, r_ptr, (uint64_t)r_size, s_ptr, (uint64_t)s_size, 0, &res), "hmj_join_u64");
   if (n_matches) *n_matches = res.n_matches;
   return res.sum_r + res.sum_s;
 }

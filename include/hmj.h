@@ -156,16 +156,27 @@ int hmj_set_key_prefix_bits(hmj_ctx* ctx, int bits);
 /* The automatic plan for a build side of n_build rows: total bits and per-pass bits (LSD order).*/
 int hmj_plan(uint64_t n_build, int* total_bits, int* n_passes, int pass_bits[4]);
 /* Placement of the big partition buffers (how fast a buffer can be written is a property of the
- * physical memory behind it).  One entry per probed buffer of this ctx: the fill rate of the allocation that was kept,
- * the number of candidate allocations tried and what the search cost.  Returns the number of entries (<= max_entries),
- * 0 when probing is off (HMJ_PLACE=0) or nothing big was allocated yet.  Diagnostic only; nothing in the reference
- * corresponds to it (its buffers are std::vector storage, hashjoin.h:62-63).                                     */
+ * physical memory behind it).  Every partition buffer of 2 GiB and more is probed when it is created (two fills, the
+ * second timed: ~2.4 ms for 6 GB).  A SEARCH for faster memory -- further candidate allocations, the fastest kept --
+ * runs only inside hmj_reserve (the caller asked for the workspace ahead of time) or when HMJ_PLACE=n is set in the
+ * environment; a join that allocates on its own never searches.  A search keeps at most two candidates alive, tries
+ * at most n (default 4) and stops when its wall-clock budget (HMJ_PLACE_BUDGET_MS, default 50 ms per buffer) would be
+ * exceeded.  HMJ_PLACE=0: nothing is probed.  One entry per probed buffer of this ctx; returns the number of entries
+ * (<= max_entries).  Diagnostic only; nothing in the reference corresponds to it (its buffers are std::vector
+ * storage, hashjoin.h:62-63).                                                                                    */
+#define HMJ_PLACE_MAX_CAND 4
 typedef struct {
   char name[16];      /* slab_a, slab_b_build, slab_b_probe, rbuf0/1, sbuf0/1                                   */
   uint64_t bytes;
-  float fill_TBps;    /* second of two sequential fills                                                          */
-  int candidates;     /* allocations tried (1 = the first one was kept)                                          */
-  float ms_search;    /* host time of the probe(s), part of the join that allocated the buffer                   */
+  float fill_TBps;    /* of the allocation that was kept: second of two sequential fills                         */
+  int candidates;     /* allocations tried (1 = the first one was kept without a search)                         */
+  float ms_search;    /* host time of probe(s) and search, part of the call that allocated the buffer            */
+  int searched;       /* 1: a search was allowed (hmj_reserve / HMJ_PLACE=n); 0: probe only                      */
+  int aborted;        /* 1: the search stopped because its budget was reached                                    */
+  float budget_ms;
+  float cand_ms_alloc[HMJ_PLACE_MAX_CAND]; /* per candidate: hipMalloc                                           */
+  float cand_ms_fill[HMJ_PLACE_MAX_CAND];  /* per candidate: the two fills (+ the loser's hipFree)               */
+  float cand_TBps[HMJ_PLACE_MAX_CAND];     /* per candidate: fill rate                                           */
 } hmj_place_info;
 int hmj_placement_info(hmj_ctx* ctx, hmj_place_info* out, int max_entries);
 int hmj_set_profiling(hmj_ctx* ctx, int enabled);

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <string>
 #include <thread>
 #include <utility>
@@ -78,6 +79,65 @@ static int run_case(uint64_t nb, uint64_t np, uint64_t miss, bool time_it) {
                 "(PCIe included)\n", (unsigned long long)nb, (unsigned long long)np, (unsigned long long)n, ms, ms2);
   }
   return 0;
+}
+
+// ---- iterators other than std::vector<...>::iterator.  The reference only ever forms `begin + k`
+// (radix_hash.h:375-388), so any random access iterator is a legal argument: a std::deque of pairs (NOT
+// contiguous: its rows live in separate blocks), a reverse_iterator, a vector's const_iterator, a raw pointer.
+// The header may hand the C ABI the caller's storage only for the last two kinds; the others must be staged.
+template <typename RIt, typename SIt>
+static int check_iter_pair(const char* what, RIt rb, RIt re, SIt sb, SIt se, const std::vector<uint64_t>& want,
+                           uint64_t want_n, uint64_t want_sum) {
+  HashMergeJoin<RIt, SIt> hmj(rb, re, sb, se, 2);
+  uint64_t n = 0, sum = 0;
+  int bad = 0;
+  for (auto tuple : hmj) {
+    sum += *std::get<1>(tuple) + *std::get<2>(tuple);
+    if (n < want_n && (*std::get<0>(tuple) != want[3 * n] || *std::get<1>(tuple) != want[3 * n + 1] ||
+                       *std::get<2>(tuple) != want[3 * n + 2]))
+      bad++;
+    n++;
+  }
+  uint64_t n2 = 0;
+  const uint64_t sum2 = hash_merge_join_sum(rb, re, sb, se, &n2);
+  if (n != want_n || sum != want_sum || bad || n2 != want_n || sum2 != want_sum) {
+    std::printf("FAIL iterators (%s): n=%llu/%llu want %llu, sum=%llu/%llu want %llu, %d rows differ\n", what,
+                (unsigned long long)n, (unsigned long long)n2, (unsigned long long)want_n, (unsigned long long)sum,
+                (unsigned long long)sum2, (unsigned long long)want_sum, bad);
+    return 1;
+  }
+  return 0;
+}
+static int run_iterator_kinds_case(uint64_t nb, uint64_t np, uint64_t miss) {
+  std::vector<uint64_t> ba(2 * nb), pa(2 * np);
+  orc_gen_build(ba.data(), nb, 0, ORC_SEED_B);
+  orc_gen_probe(pa.data(), np, 0, nb ? nb : 1, ORC_SEED_B, miss);
+  const KeyValVec r = from_aos(ba), s = from_aos(pa);
+  std::vector<uint64_t> want(3 * (np + 1));
+  uint64_t want_sum = 0;
+  const uint64_t want_n = orc_hashmergejoin(ba.data(), nb, pa.data(), np, 2, want.data(), np + 1, &want_sum);
+  typedef std::deque<std::pair<uint64_t, uint64_t>> KeyValDeque;
+  static_assert(hmj_detail::is_hmj_relation_iter<KeyValDeque::iterator>::value &&
+                    !hmj_detail::is_contiguous_iter<KeyValDeque::iterator>::value &&
+                    !hmj_detail::is_contiguous_iter<KeyValVec::const_reverse_iterator>::value &&
+                    hmj_detail::is_contiguous_iter<KeyValVec::const_iterator>::value &&
+                    hmj_detail::is_contiguous_iter<KeyValVec::iterator>::value &&
+                    hmj_detail::is_contiguous_iter<const std::pair<uint64_t, uint64_t>*>::value,
+                "only pointers and std::vector iterators may be handed over as one address");
+  KeyValDeque rd, sd;  // pushed at both ends so the rows straddle several of the deque's blocks
+  for (uint64_t i = nb / 2; i < nb; i++) rd.push_back(r[i]);
+  for (uint64_t i = nb / 2; i-- > 0;) rd.push_front(r[i]);
+  for (uint64_t i = 0; i < np; i++) sd.push_back(s[i]);
+  int fails = 0;
+  fails += check_iter_pair("deque x deque", rd.begin(), rd.end(), sd.begin(), sd.end(), want, want_n, want_sum);
+  fails += check_iter_pair("deque x vector", rd.begin(), rd.end(), s.begin(), s.end(), want, want_n, want_sum);
+  fails += check_iter_pair("const_iterator", r.cbegin(), r.cend(), s.cbegin(), s.cend(), want, want_n, want_sum);
+  fails += check_iter_pair("pointers", r.data(), r.data() + nb, s.data(), s.data() + np, want, want_n, want_sum);
+  // a reversed view of a reversed copy is the same relation in the same order
+  const KeyValVec rrev(r.rbegin(), r.rend()), srev(s.rbegin(), s.rend());
+  fails += check_iter_pair("reverse_iterator", rrev.rbegin(), rrev.rend(), srev.rbegin(), srev.rend(), want, want_n,
+                           want_sum);
+  return fails;
 }
 
 // ---- std::string keys: the reference's own benchmark type (KeyValVec, hashjoin.h:29).  The same
@@ -284,6 +344,10 @@ int main(int argc, char** argv) {
   fails += run_case(1 << 16, 1 << 16, 2, false);
   fails += run_case(1 << 20, 1 << 20, 0, true);
   fails += run_case(1 << 22, 1 << 22, 0, true);
+  fails += run_iterator_kinds_case(0, 0, 0);
+  fails += run_iterator_kinds_case(1, 1, 0);
+  fails += run_iterator_kinds_case(5000, 3000, 3);
+  fails += run_iterator_kinds_case(300000, 200000, 2);
   fails += run_prehashed_case(0, 5, 0, 0);
   fails += run_prehashed_case(1000, 1000, 0, 0);
   fails += run_prehashed_case(5000, 3000, 3, 1);

@@ -166,30 +166,48 @@ def test_host_entry_pipeline_matches_oracle(ex, H, oracle, nb, npb, miss):
 
 
 def test_placement_info_reports_the_probed_buffers(H):
-    # hmj_placement_info: what the bench line's `placement` object is made of.  Default: every big partition buffer of
-    # the slab path is listed with the fill rate of the allocation that was kept; HMJ_PLACE=0: nothing is probed.
+    # hmj_placement_info: what the bench line's `placement` object is made of.  A join that allocates on its own only
+    # PROBES its big partition buffers (one candidate, no search: VERDICT r3 #3 -- a first join once paid 1.3 s for a
+    # search); hmj_reserve (or HMJ_PLACE=n) searches, at most n candidates, never past its wall-clock budget, and
+    # reports what every candidate cost; HMJ_PLACE=0: nothing is probed.
     import torch
 
     assert torch.cuda.is_available()
-    for env, expect in (("4", True), ("0", False)):
-        os.environ["HMJ_PLACE"] = env
+    n = 1 << 27  # slab buffers of 2.8-3.0 GB: above the 2 GiB from which an allocation is probed
+    for env, reserve, expect in ((None, False, "probe"), (None, True, "search"), ("3", False, "search"), ("0", True, None)):
+        if env is not None:
+            os.environ["HMJ_PLACE"] = env
         try:
             e = H.Executor(0)
         finally:
-            del os.environ["HMJ_PLACE"]
+            os.environ.pop("HMJ_PLACE", None)
         try:
-            n = 1 << 27  # slab buffers of 2.8-3.0 GB: above the 2 GiB from which an allocation is probed
+            if reserve:
+                e.reserve(n, n, 0, 0)
+                reserved = e.placement_info()
             R, S = e.gen_build(n), e.gen_probe(n, n)
             r = e.join_device(R, S, 0)
             assert int(r.n_matches) == n and e.last_timing()["path"] & H.HMJ_PATH_SLAB
             info = e.placement_info()
-            if expect:
-                names = {b["name"] for b in info}
-                assert {"slab_a", "slab_b_build", "slab_b_probe"} <= names, info
-                for b in info:
-                    assert b["bytes"] >= 2048 << 20 and 1.0 < b["fill_TBps"] < 8.0 and 1 <= b["candidates"] <= 4, b
-            else:
+            if expect is None:
                 assert info == []
+                continue
+            if reserve:
+                assert info == reserved, "the join must use the buffers hmj_reserve created, not allocate again"
+            names = {b["name"] for b in info}
+            assert {"slab_a", "slab_b_build", "slab_b_probe"} <= names, info
+            for b in info:
+                k = b["candidates"]
+                assert b["bytes"] >= 2048 << 20 and 1.0 < b["fill_TBps"] < 8.0, b
+                assert len(b["cand_ms_alloc"]) == len(b["cand_ms_fill"]) == len(b["cand_TBps"]) == k, b
+                assert abs(max(b["cand_TBps"]) - b["fill_TBps"]) < 2e-3, b  # the fastest candidate was kept
+                if expect == "probe":
+                    assert k == 1 and not b["searched"] and not b["aborted"], b
+                else:
+                    assert b["searched"] and 1 <= k <= (3 if env == "3" else 4), b
+                    # a candidate is only started while what was spent, plus what the previous one cost, fits the budget
+                    spent_before_last = sum(b["cand_ms_alloc"][1:k - 1]) + sum(b["cand_ms_fill"][:k - 1])
+                    assert k == 1 or spent_before_last <= b["budget_ms"] + 1.0, b
             del R, S
         finally:
             e.close()
