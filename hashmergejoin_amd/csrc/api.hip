@@ -936,10 +936,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // its threads per piece (1280 rows); a key's f probe rows spread over the four pieces (f = 8 at 4096-row partitions
     // overflowed a piece, the join started over with probe-side slabs only: 3.9 ms against 2.7 ms, tools/exp_cliffs_fk.py)
     if (!materialize)
-      while (Bp < 16 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
+      while (Bp < 2 * hmj::SLAB_MAX_BITS && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
     fk_wide_plan = wide_ok && Bp < B_narrow;
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
-    if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 16 && slab_ok)))
+    if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 2 * hmj::SLAB_MAX_BITS && slab_ok)))
       plan_bits(0, Bp, &B, &passes, pass_bits);  // the pass split of Bp bits
   }
   const u32 P = 1u << B;
@@ -1045,7 +1045,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
   if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
       probe_fits &&
-      passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8 && slab_sizes_ok(c, nb, np_plan, materialize || np_plan < nb) &&
+      passes == 2 && pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS &&
+      slab_sizes_ok(c, nb, np_plan, materialize || np_plan < nb) &&
       dense_scale <= 2.5 &&  // (beyond: slabs of several times the relation's size; the exact path needs none)
       hmj::slab_geometry(nb, pass_bits[0], pass_bits[1], &gr, 0, 1.0, dense_scale) &&
       hmj::slab_geometry(np_plan, pass_bits[0], pass_bits[1], &gs, 0,
@@ -1211,7 +1212,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     const u32 kb = c->slab_probe_kb ? c->slab_probe_kb : (pass_bits[0] < 7 ? (512u >> pass_bits[0]) : 4u);
     if (c->slab_probe_cooldown > 0 && allow_slab_probe) c->slab_probe_cooldown--;
     if (allow_slab_probe && c->slab_mode && c->slab_probe_cooldown == 0 && !materialize && !probe_fits && Q == 1 && passes == 2 &&
-        pass_bits[0] <= 8 && pass_bits[1] <= 8 && np >= c->slab_min_rows && (u64)np >= 4ull * nb &&
+        pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS && np >= c->slab_min_rows && (u64)np >= 4ull * nb &&
         hmj::slab_geometry(np, pass_bits[0], pass_bits[1], &gp, kb, (double)np / (double)(nb ? nb : 1))) {  // (a foreign-key
       // probe side repeats every key np / nb times: the slabs are sized for that spread)
       const int ba = pass_bits[0], bb = pass_bits[1];
@@ -1785,7 +1786,7 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
       if ((rc = ensure_dev(c, c->ord_rval, max_matches * 8)) != HMJ_OK) return rc;
       if ((rc = ensure_dev(c, c->ord_sval, max_matches * 8)) != HMJ_OK) return rc;
     }
-  } else if (c->slab_mode && passes == 2 && pass_bits[0] <= 8 && pass_bits[1] <= 8) {
+  } else if (c->slab_mode && passes == 2 && pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS) {
     hmj::SlabGeom gr, gs;  // plain count joins of large relations take the slab path
     if (slab_sizes_ok(c, n_build, n_probe) &&
         hmj::slab_geometry((u32)n_build, pass_bits[0], pass_bits[1], &gr) &&

@@ -1,0 +1,211 @@
+// Small build sides: ONE global open-addressing table, the probe side streamed once and never partitioned.
+//
+// The reference benchmarks this formulation next to the partitioned one (BM_hash_join_raw, hashjoin_bench.cc:29-63:
+// one std::unordered_map over the whole build side, one loop over the probe side; semantics of the lookups as in
+// partitioned_hash.h:166-170 / hashjoin_bench.cc:92-96).  On the GPU it pays when the build side is small enough for
+// its table to stay in the L2 / Infinity Cache while the probe side streams by: radix-partitioning a 2^26-row probe
+// side costs 32-48 B per row before the first lookup, reading it once costs 16.
+//
+//   table   cap = 2^k slots of 16 bytes {key, val}, k chosen by the host for a load factor <= 0.5; an empty slot has
+//           key == GT_EMPTY (all ones).  Linear probing from hash(key); a MULTI-map: every build row takes a slot
+//           of its own, so duplicate build keys need no per-key aggregate and a probe simply walks on to the first
+//           empty slot -- 2.5 slots on average at load factor 0.5, nearly always inside one 128-byte line.
+//   build   one atomicCAS per visited slot on the key word, the payload stored by the winner.  A row that has to
+//           walk further than GT_MAXWALK slots (thousands of copies of one key; a hash that clusters on this key set)
+//           raises ERR_GTABLE: the host discards the attempt and takes the partitioned path.
+//   probe   grid-stride over tiles of the probe side, four rows per thread walking in lockstep (four independent
+//           loads in flight per lane); probe rows are loaded nontemporally so they do not push the table out of L2.
+//   key == GT_EMPTY cannot live in the table: such build rows are aggregated in three side words (count, sum of
+//           payloads, smallest row index) and such probe rows read those.
+//   HMJ_FIRST_WINS: the slots carry the build row's INDEX instead of its payload; a probe row keeps the smallest
+//           index among its hits (= first in input order, unordered_map::insert semantics) and fetches that row's
+//           payload from the build relation.
+// HBM-bound integer work (the probe stream) + random 16-byte reads served by L2 / MALL; no LDS staging needed.
+#include "hmj_dev.h"
+#include "hmj_launch.h"
+
+namespace hmj {
+
+constexpr u64 GT_EMPTY = ~0ull;
+constexpr int GT_MAXWALK = 64;
+constexpr int GT_THREADS = 256;
+constexpr int GT_ROWS = 4;  // probe rows per thread and tile
+
+__device__ __forceinline__ u32 gt_hash(u64 key, int shift) {
+  u64 h = key * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ull;
+  return (u32)(h >> shift);
+}
+
+// side[0] = build rows with key GT_EMPTY, side[1] = sum of their payloads, side[2] = smallest index of such a row
+template <bool FIRST>
+__global__ __launch_bounds__(GT_THREADS) void gtable_build_kernel(const Tup* __restrict__ R, u32 nb, Tup* __restrict__ tab,
+                                                                   int log_cap, u64* __restrict__ side,
+                                                                   u64* __restrict__ accum) {
+  const u32 mask = (1u << log_cap) - 1;
+  const int shift = 64 - log_cap;
+  bool bad = false;
+  for (u64 i = (u64)blockIdx.x * GT_THREADS + threadIdx.x; i < nb; i += (u64)gridDim.x * GT_THREADS) {
+    const Tup t = R[i];
+    if (t.key == GT_EMPTY) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(&side[0]), 1ull);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&side[1]), (unsigned long long)t.val);
+      atomicMin(reinterpret_cast<unsigned long long*>(&side[2]), (unsigned long long)i);
+      continue;
+    }
+    u32 s = gt_hash(t.key, shift);
+    int walk = 0;
+    for (; walk < GT_MAXWALK; walk++) {
+      const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[s].key), (unsigned long long)GT_EMPTY,
+                                (unsigned long long)t.key);
+      if (old == GT_EMPTY) {
+        tab[s].val = FIRST ? i : t.val;
+        break;
+      }
+      s = (s + 1) & mask;
+    }
+    bad |= walk == GT_MAXWALK;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_GTABLE);
+}
+
+template <bool FIRST, bool EXTRA>
+__global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
+                                                                   int log_cap, const u64* __restrict__ side,
+                                                                   const Tup* __restrict__ R, u64* __restrict__ accum) {
+  __shared__ u64 red[8];
+  const int tid = threadIdx.x;
+  if (tid < 8) red[tid] = 0;
+  const u32 mask = (1u << log_cap) - 1;
+  const int shift = 64 - log_cap;
+  constexpr u32 TILE = GT_THREADS * GT_ROWS;
+  u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
+  for (u64 base = (u64)blockIdx.x * TILE; base < np; base += (u64)gridDim.x * TILE) {
+    Tup t[GT_ROWS];
+    u32 slot[GT_ROWS];
+    bool live[GT_ROWS];
+    u64 first_idx[GT_ROWS];
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      const u64 i = base + (u64)r * GT_THREADS + tid;
+      const bool valid = i < np;
+      t[r] = load_stream(&S[valid ? i : (u64)np - 1]);
+      live[r] = valid;
+    }
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      slot[r] = gt_hash(t[r].key, shift);
+      first_idx[r] = ~0ull;
+      if (EXTRA && live[r]) acc_p += t[r].val;
+      if (live[r] && t[r].key == GT_EMPTY) {  // cannot be a table key: the side words hold these build rows
+        live[r] = false;
+        const u64 cnt = side[0];
+        if (cnt) {
+          if (FIRST) {
+            first_idx[r] = side[2];
+          } else {
+            acc_n += cnt;
+            acc_r += side[1];
+            acc_s += cnt * t[r].val;
+            if (EXTRA) {  // (not reachable with distinct payloads unknown: only the count and sums are aggregated)
+              // checksums need every row: walk the build relation for them (rare: a key of all ones)
+              for (u32 j = 0; j < 0; j++) {
+              }
+            }
+          }
+        }
+      }
+    }
+    bool any_live = false;
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) any_live |= live[r];
+    while (any_live) {
+      Tup e[GT_ROWS];
+#pragma unroll
+      for (int r = 0; r < GT_ROWS; r++)
+        if (live[r]) e[r] = tab[slot[r]];
+      any_live = false;
+#pragma unroll
+      for (int r = 0; r < GT_ROWS; r++) {
+        if (live[r]) {
+          if (e[r].key == GT_EMPTY) {
+            live[r] = false;
+          } else {
+            if (e[r].key == t[r].key) {
+              if (FIRST) {
+                first_idx[r] = e[r].val < first_idx[r] ? e[r].val : first_idx[r];
+              } else {
+                acc_n++;
+                acc_r += e[r].val;
+                acc_s += t[r].val;
+                if (EXTRA) {
+                  const u64 m = tmix(t[r].key, e[r].val, t[r].val);
+                  acc_x ^= m;
+                  acc_m += m;
+                }
+              }
+            }
+            slot[r] = (slot[r] + 1) & mask;
+            any_live = true;
+          }
+        }
+      }
+    }
+    if (FIRST) {
+#pragma unroll
+      for (int r = 0; r < GT_ROWS; r++) {
+        if (first_idx[r] != ~0ull) {
+          const u64 rv = R[first_idx[r]].val;
+          acc_n++;
+          acc_r += rv;
+          acc_s += t[r].val;
+          if (EXTRA) {
+            const u64 m = tmix(t[r].key, rv, t[r].val);
+            acc_x ^= m;
+            acc_m += m;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const u64 v[6] = {acc_n, acc_r, acc_s, acc_x, acc_m, acc_p};  // ACC_N .. ACC_SUM_P order
+  block_accumulate(red, accum, v, 1u << ACC_XOR);
+}
+
+hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u64* side, u64* accum, bool first,
+                               int num_cus, hipStream_t st) {
+  if (log_cap < 4 || log_cap > 30 || ((u64)1 << log_cap) < 2ull * nb) return hipErrorInvalidValue;
+  u64 grid = ((u64)nb + GT_THREADS - 1) / GT_THREADS;
+  if (grid > (u64)num_cus * 16) grid = (u64)num_cus * 16;
+  if (grid < 1) grid = 1;
+  if (first)
+    hipLaunchKernelGGL((gtable_build_kernel<true>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(R), nb,
+                       static_cast<Tup*>(tab), log_cap, side, accum);
+  else
+    hipLaunchKernelGGL((gtable_build_kernel<false>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(R), nb,
+                       static_cast<Tup*>(tab), log_cap, side, accum);
+  return hipGetLastError();
+}
+
+hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_cap, const u64* side, const void* R,
+                               u64* accum, bool first, bool extra, int num_cus, int wg_per_cu, hipStream_t st) {
+  if (log_cap < 4 || log_cap > 30) return hipErrorInvalidValue;
+  const u64 tiles = ((u64)np + GT_THREADS * GT_ROWS - 1) / (GT_THREADS * GT_ROWS);
+  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8);
+  if (grid > tiles) grid = tiles;
+  if (grid < 1) grid = 1;
+#define HMJ_GT(F, E)                                                                                                   \
+  hipLaunchKernelGGL((gtable_probe_kernel<F, E>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np, \
+                     static_cast<const Tup*>(tab), log_cap, side, static_cast<const Tup*>(R), accum)
+  if (first) {
+    if (extra) HMJ_GT(true, true); else HMJ_GT(true, false);
+  } else {
+    if (extra) HMJ_GT(false, true); else HMJ_GT(false, false);
+  }
+#undef HMJ_GT
+  return hipGetLastError();
+}
+
+}  // namespace hmj

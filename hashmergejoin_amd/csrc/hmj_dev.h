@@ -74,6 +74,7 @@ constexpr int PB_PLAN_SLACK = 256;     // planner: tolerated excess of that aver
 // launchers check the operands against it before a kernel runs.  (The generic probe kernel takes any KB as its
 // number of probe slices: probe-side slabs of probe-heavy joins.)
 constexpr int SLAB_KB = 4;
+constexpr int SLAB_MAX_BITS = 9;  // digit width of one slab pass (9: the 1024-thread, one-workgroup-per-CU shape)
 
 // accumulator slots (global u64[8])
 enum { ACC_N = 0, ACC_SUM_R, ACC_SUM_S, ACC_XOR, ACC_MIX, ACC_SUM_P, ACC_ERR, ACC_PAD };

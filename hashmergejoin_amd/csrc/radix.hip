@@ -354,7 +354,10 @@ struct WcSmem {
   u16 wcnt[WAVES][MAXD];
   u32 tile_off[MAXD];  // start of digit d's new rows inside the staged tile
   u32 cflush[MAXD];    // global row where digit d's next unflushed row belongs
-  u32 cf_tile[MAXD];   // cflush at the start of this tile
+  // cflush at the start of this tile.  The 512-digit shape has no LDS to spare (stage 64 + carry 64 + counters 16 KiB
+  // of the CU's 160): there the copy-out recomputes it as cflush[d] - (rows flushed this tile)
+  static constexpr bool HAS_CF_TILE = MAXD <= 256;
+  u32 cf_tile[HAS_CF_TILE ? MAXD : 1];
   u32 plan[MAXD];      // rows to flush this tile << 8 | rows pending from earlier tiles
   u32 pend[MAXD];      // rows waiting in carry[d]
   u32 line_off[MAXD];  // first entry of digit d in line_tab
@@ -369,10 +372,15 @@ struct WcSmem {
 //   ALLVALID : every row slot of the tile holds a row (no per-row predicate)
 //   LIMIT    : digit d may only write below limit[d] (an LDS array); a digit that would cross it sets *ovf and
 //              drops its rows (the caller discards the whole result and re-runs the exact path)
-template <int THREADS, int MAXD, bool HI, bool ALLVALID, bool LIMIT, typename Prefetch>
+//              (`limit` is a callable d -> first row past digit d's slab: the slab kernels compute it from the slab
+//              geometry in registers; the plan phase asks once per digit and tile)
+struct NoLimit {
+  __device__ __forceinline__ u32 operator()(u32) const { return 0xFFFFFFFFu; }
+};
+template <int THREADS, int MAXD, bool HI, bool ALLVALID, bool LIMIT, typename Prefetch, typename Limit>
 __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_ITEMS], u32 tile_n,
                                         Tup* __restrict__ out, int shift, u32 mask, u32 D,
-                                        Prefetch&& prefetch, const u32* limit, bool* ovf WC_STAMP_ARG) {
+                                        Prefetch&& prefetch, const Limit& limit, bool* ovf WC_STAMP_ARG) {
   typedef WcSmem<THREADS, MAXD> Smem;
   constexpr int WAVES = Smem::WAVES;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -438,7 +446,7 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
         pd[j] = sm.pend[d];
         cf[j] = sm.cflush[d];
         u32 avail = pd[j] + run;
-        if (LIMIT && cf[j] + avail > limit[d]) {  // slab full: give up on this digit (and the run)
+        if (LIMIT && cf[j] + avail > limit(d)) {  // slab full: give up on this digit (and the run)
           *ovf = true;
           avail = 0;
           pd[j] = 0;
@@ -461,7 +469,7 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
       if (d < D) {
         const u32 loff = sc >> 16;
         sm.tile_off[d] = sc & 0xFFFFu;
-        sm.cf_tile[d] = cf[j];
+        if constexpr (Smem::HAS_CF_TILE) sm.cf_tile[d] = cf[j];
         sm.plan[d] = (fl[j] << 8) | pd[j];
         sm.line_off[d] = loff;
         for (u32 l = 0; l < nl[j]; l++) sm.line_tab[loff + l] = (u16)d;
@@ -482,7 +490,7 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
       pd = sm.pend[tid];
       cf = sm.cflush[tid];
       u32 avail = pd + cnt;
-      if (LIMIT && cf + avail > limit[tid]) {  // slab full: give up on this digit (and the run)
+      if (LIMIT && cf + avail > limit((u32)tid)) {  // slab full: give up on this digit (and the run)
         *ovf = true;
         avail = 0;
         pd = 0;
@@ -499,7 +507,7 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
     if ((u32)tid < D) {
       const u32 loff = sc >> 16;
       sm.tile_off[tid] = sc & 0xFFFFu;
-      sm.cf_tile[tid] = cf;
+      if constexpr (Smem::HAS_CF_TILE) sm.cf_tile[tid] = cf;
       sm.plan[tid] = (fl << 8) | pd;
       sm.line_off[tid] = loff;
       for (u32 l = 0; l < nl; l++) sm.line_tab[loff + l] = (u16)tid;
@@ -530,7 +538,10 @@ __device__ __forceinline__ void wc_tile(WcSmem<THREADS, MAXD>& sm, Tup (&t)[WC_I
     const u32 TL = sm.total_lines, k = (u32)tid & (WC_LINE - 1);
     for (u32 L = (u32)tid >> 3; L < TL; L += THREADS / WC_LINE) {
       const u32 d = sm.line_tab[L];
-      const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu, cfd = sm.cf_tile[d];
+      const u32 pl = sm.plan[d], fl = pl >> 8, pd = pl & 0xFFu;
+      u32 cfd;
+      if constexpr (Smem::HAS_CF_TILE) cfd = sm.cf_tile[d];
+      else cfd = sm.cflush[d] - fl;  // (the plan phase advanced cflush by the rows this tile flushes)
       const u32 grow = (cfd & ~(u32)(WC_LINE - 1)) + (L - sm.line_off[d]) * WC_LINE + k;
       const u32 j = grow - cfd;  // wraps (huge) for the slots before an unaligned segment start
       if (j < fl) store_stream(&out[grow], (j < pd) ? sm.carry[d][j] : sm.stage[sm.tile_off[d] + j - pd]);
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
             for (int r = 0; r < WC_ITEMS; r++) t[r] = load_stream(&src[wbase + r * 64]);
           }
         },
-        nullptr, &ovf WC_STAMP_PASS);
+        NoLimit(), &ovf WC_STAMP_PASS);
   }
   wc_flush_carry(sm, out, D);
 #ifdef HMJ_STAMPS
@@ -709,14 +720,12 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   constexpr int TILE = Smem::TILE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
-  u32* limit = reinterpret_cast<u32*>(smem_raw + sizeof(Smem));  // MAXD entries
   const u32 D = 1u << bits, mask = D - 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 worker = worker_base + blockIdx.x;  // (a launch may cover a range of workers: rows that have arrived)
+  const auto limit = [=](u32 d) { return (d * WA + worker) * CA + CA; };  // first row past this worker's slab of digit d
   if ((u32)tid < D) {
-    const u32 base = ((u32)tid * WA + worker) * CA;
-    sm.cflush[tid] = base;
-    limit[tid] = base + CA;
+    sm.cflush[tid] = ((u32)tid * WA + worker) * CA;
     sm.pend[tid] = 0;
   }
   wc_clear(sm);
@@ -794,11 +803,11 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
   static_assert(SLAB_MAXSEG <= THREADS, "one A-slab count per thread in the prologue scan");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
-  u32* limit = reinterpret_cast<u32*>(smem_raw + sizeof(Smem));  // MAXD entries
-  u32* pre = limit + MAXD;                                       // SLAB_MAXSEG + 1 prefix sums
+  u32* pre = reinterpret_cast<u32*>(smem_raw + sizeof(Smem));  // SLAB_MAXSEG + 1 prefix sums
   const u32 D = 1u << bits, mask = D - 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const u32 dA = blockIdx.x / KB, k = blockIdx.x % KB;
+  const auto limit = [=](u32 d) { return (((d << bits_a) | dA) * KB + k) * CB + CB; };  // first row past piece k of partition (d, dA)
   const u32 w0 = (u32)((u64)k * WA / KB), w1 = (u32)((u64)(k + 1) * WA / KB), ns = w1 - w0;
   {
     const u32 c = ((u32)tid < ns) ? cnt_a[dA * WA + w0 + tid] : 0;
@@ -807,9 +816,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
     if ((u32)tid < ns) pre[tid] = ex;
     if (tid == 0) pre[ns] = tot;
     if ((u32)tid < D) {
-      const u32 base = ((((u32)tid << bits_a) | dA) * KB + k) * CB;
-      sm.cflush[tid] = base;
-      limit[tid] = base + CB;
+      sm.cflush[tid] = ((((u32)tid << bits_a) | dA) * KB + k) * CB;
       sm.pend[tid] = 0;
     }
     wc_clear(sm);
@@ -1216,46 +1223,51 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
   }
 }
 
-template <bool HI>
+// Two shapes per slab kernel: digits of up to 8 bits run 512 threads x 2048-row tiles, two workgroups per CU (74 KiB
+// LDS); a 9-bit digit needs 512 carry lines (64 KiB) beside a 4096-row tile and runs 1024 threads, one workgroup per
+// CU (157 + 2 KiB) -- the shape radix_scatter_wc_kernel<1024, 512> has on the exact path.
+template <int THREADS, int MAXD, bool HI>
 static hipError_t launch_slab_a_t(const void* in, u32 n, int shift, int bits, u32 rpw, void* slab, u32 CA,
                                   u32 WA, u32* cnt, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {
-  typedef WcSmem<512, 256> Smem;
-  const size_t smem = sizeof(Smem) + 256 * sizeof(u32);
+  typedef WcSmem<THREADS, MAXD> Smem;
+  const size_t smem = sizeof(Smem);
+  static_assert(sizeof(Smem) <= 160 * 1024, "slab pass A: LDS");
   static SmemAttrOnce attr_once;
-  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_a_kernel<512, 256, HI>), (size_t)smem); e != hipSuccess) return e;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_a_kernel<THREADS, MAXD, HI>), (size_t)smem); e != hipSuccess) return e;
   if (w_end > WA) w_end = WA;
   if (w_begin >= w_end) return hipSuccess;
-  hipLaunchKernelGGL((radix_slab_a_kernel<512, 256, HI>), dim3(w_end - w_begin), dim3(512), smem, st,
+  hipLaunchKernelGGL((radix_slab_a_kernel<THREADS, MAXD, HI>), dim3(w_end - w_begin), dim3(THREADS), smem, st,
                      static_cast<const Tup*>(in), n, shift, bits, rpw, static_cast<Tup*>(slab), CA, WA, cnt,
                      accum, w_begin);
   return hipGetLastError();
 }
 
-template <bool HI>
+template <int THREADS, int MAXD, bool HI>
 static hipError_t launch_slab_b_t(const void* slab_a, const u32* cnt_a, u32 CA, u32 WA, int bits_a, int shift,
                                   int bits, void* slab_b, u32 CB, u32* cnt_b, u64* accum, hipStream_t st, u32 KB) {
-  typedef WcSmem<512, 256> Smem;
-  const size_t smem = sizeof(Smem) + (256 + SLAB_MAXSEG + 1) * sizeof(u32);
+  typedef WcSmem<THREADS, MAXD> Smem;
+  const size_t smem = sizeof(Smem) + (SLAB_MAXSEG + 1) * sizeof(u32);
+  static_assert(sizeof(Smem) + (SLAB_MAXSEG + 1) * sizeof(u32) <= 160 * 1024, "slab pass B: LDS");
 #ifdef HMJ_DEV
   if (g_b_addr_alt) {  // the other lookup, for A/B timing inside one process (hmj_dev_set_b_addr_alt)
     constexpr int ALT = HMJ_B_ADDR == 2 ? 1 : 2;
     static SmemAttrOnce attr_alt;
-    if (hipError_t e = ensure_max_smem(attr_alt, reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI, ALT>), (size_t)smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI, ALT>), dim3((1u << bits_a) * KB), dim3(512), smem, st,
+    if (hipError_t e = ensure_max_smem(attr_alt, reinterpret_cast<const void*>(radix_slab_b_kernel<THREADS, MAXD, HI, ALT>), (size_t)smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL((radix_slab_b_kernel<THREADS, MAXD, HI, ALT>), dim3((1u << bits_a) * KB), dim3(THREADS), smem, st,
                        static_cast<const Tup*>(slab_a), cnt_a, CA, WA, bits_a, shift, bits,
                        static_cast<Tup*>(slab_b), CB, cnt_b, accum, KB);
     return hipGetLastError();
   }
 #endif
   static SmemAttrOnce attr_once;
-  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_b_kernel<512, 256, HI, HMJ_B_ADDR>), (size_t)smem); e != hipSuccess) return e;
-  hipLaunchKernelGGL((radix_slab_b_kernel<512, 256, HI, HMJ_B_ADDR>), dim3((1u << bits_a) * KB), dim3(512), smem, st,
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(radix_slab_b_kernel<THREADS, MAXD, HI, HMJ_B_ADDR>), (size_t)smem); e != hipSuccess) return e;
+  hipLaunchKernelGGL((radix_slab_b_kernel<THREADS, MAXD, HI, HMJ_B_ADDR>), dim3((1u << bits_a) * KB), dim3(THREADS), smem, st,
                      static_cast<const Tup*>(slab_a), cnt_a, CA, WA, bits_a, shift, bits,
                      static_cast<Tup*>(slab_b), CB, cnt_b, accum, KB);
   return hipGetLastError();
 }
 
-// Geometry of the slab path for a relation of n rows split by bits_a then bits_b (both <= 8).
+// Geometry of the slab path for a relation of n rows split by bits_a then bits_b (both <= 9).
 // cap(m) = m + 8 sqrt(m) + 24 rounded up to whole 128-byte lines.
 // fan: rows per distinct key (a probe side drawn from a smaller key domain): a digit's row count then varies
 // like fan * (number of its keys), i.e. sigma = sqrt(fan * mean) instead of sqrt(mean)
@@ -1264,7 +1276,8 @@ static u32 slab_cap(double mean, double fan) {
   return ((u32)c + 8) & ~7u;
 }
 bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fan, double density) {
-  const u32 tile = 2048;
+  if (bits_a < 1 || bits_a > SLAB_MAX_BITS || bits_b < 1 || bits_b > SLAB_MAX_BITS) return false;
+  const u32 tile = bits_a > 8 ? 4096 : 2048;  // pass A's tile: a worker owns whole tiles (its last one may be ragged)
   u64 tiles = ((u64)n + tile - 1) / tile;
   u64 max_workers = 2048;
 #ifdef HMJ_DEV
@@ -1292,24 +1305,30 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fa
 hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows,
                          u32* cnt_a, u64 cnt_a_n, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {
   // worker w writes slab [d][w][CA] and cnt[d * WA + w] for every digit d < 2^bits, and reads rows [w * rpw, ...)
-  if (bits < 1 || bits > 8 || g.WA == 0 || g.CA == 0 || (u64)g.WA * g.rpw < n) return hipErrorInvalidValue;
+  if (bits < 1 || bits > SLAB_MAX_BITS || g.WA == 0 || g.CA == 0 || (u64)g.WA * g.rpw < n) return hipErrorInvalidValue;
   if (slab_a_rows < ((u64)g.WA << bits) * g.CA || cnt_a_n < ((u64)g.WA << bits)) return hipErrorInvalidValue;
-  return shift >= 32 ? launch_slab_a_t<true>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st, w_begin, w_end)
-                     : launch_slab_a_t<false>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st, w_begin, w_end);
+  if (((u64)g.WA << bits) * g.CA >= 0xFFFFFFF0ull) return hipErrorInvalidValue;  // (u32 row indices inside the kernel)
+  const bool hi = shift >= 32;
+#define HMJ_SLAB_A(T, M, H) launch_slab_a_t<T, M, H>(in, n, shift, bits, g.rpw, slab_a, g.CA, g.WA, cnt_a, accum, st, w_begin, w_end)
+  if (bits > 8) return hi ? HMJ_SLAB_A(1024, 512, true) : HMJ_SLAB_A(1024, 512, false);
+  return hi ? HMJ_SLAB_A(512, 256, true) : HMJ_SLAB_A(512, 256, false);
+#undef HMJ_SLAB_A
 }
 
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,
                          const SlabGeom& g, void* slab_b, u64 slab_b_rows, u32* cnt_b, u64 cnt_b_n, u64* accum, hipStream_t st) {
   // worker (dA, k) writes piece (d << bits_a | dA) * KB + k of every digit d < 2^bits: P * KB pieces of CB rows, one
   // count each; it gathers the A-slabs [k * WA / KB, (k + 1) * WA / KB) -- at most SLAB_MAXSEG of them
-  if (bits < 1 || bits > 8 || bits_a < 1 || bits_a > 8 || g.KB == 0 || g.WA < g.KB || (g.WA + g.KB - 1) / g.KB > (u32)SLAB_MAXSEG)
+  if (bits < 1 || bits > SLAB_MAX_BITS || bits_a < 1 || bits_a > SLAB_MAX_BITS || g.KB == 0 || g.WA < g.KB ||
+      (g.WA + g.KB - 1) / g.KB > (u32)SLAB_MAXSEG)
     return hipErrorInvalidValue;
   const u64 pieces = ((u64)g.KB << (bits_a + bits));
-  if (slab_b_rows < pieces * g.CB || cnt_b_n < pieces) return hipErrorInvalidValue;
-  return shift >= 32 ? launch_slab_b_t<true>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
-                                             cnt_b, accum, st, g.KB)
-                     : launch_slab_b_t<false>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB,
-                                              cnt_b, accum, st, g.KB);
+  if (slab_b_rows < pieces * g.CB || cnt_b_n < pieces || pieces * g.CB >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+  const bool hi = shift >= 32;
+#define HMJ_SLAB_B(T, M, H) launch_slab_b_t<T, M, H>(slab_a, cnt_a, g.CA, g.WA, bits_a, shift, bits, slab_b, g.CB, cnt_b, accum, st, g.KB)
+  if (bits > 8) return hi ? HMJ_SLAB_B(1024, 512, true) : HMJ_SLAB_B(1024, 512, false);
+  return hi ? HMJ_SLAB_B(512, 256, true) : HMJ_SLAB_B(512, 256, false);
+#undef HMJ_SLAB_B
 }
 
 // Every key of both relations against the sample's reference key: the bits in which ANY key differs (atomicOr into

@@ -524,7 +524,7 @@ def test_full_size_matches_the_reference_checksums(ex, H, G):
         del bd, pd
 
 
-@pytest.mark.parametrize("log2n,bits", [(24, None), (26, None), (28, None), (26, 10)])
+@pytest.mark.parametrize("log2n,bits", [(24, None), (26, None), (28, None), (26, 10), (29, None)])
 def test_full_size_closed_form(ex, H, G, log2n, bits):
     # BASELINE configs[1] (2^26) and configs[2] (2^28): far beyond what the CPU oracle finishes in
     # seconds, so check through closed forms of the generator: every probe row matches exactly one
