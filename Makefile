@@ -4,7 +4,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC     := hashmergejoin_amd/csrc
-OBJS     := $(CSRC)/radix.o $(CSRC)/probe.o $(CSRC)/gen.o $(CSRC)/api.o $(CSRC)/exchange.o
+OBJS     := $(CSRC)/radix.o $(CSRC)/probe.o $(CSRC)/gen.o $(CSRC)/gtable.o $(CSRC)/api.o $(CSRC)/exchange.o
 LIB      := hashmergejoin_amd/libhmj_hip.so
 
 all: $(LIB) oracle cpptest examples/hashjoin_bench_hip examples/exchange_join

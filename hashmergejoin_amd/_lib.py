@@ -16,6 +16,7 @@ HMJ_PATH_SLAB_PROBE = 0x400
 HMJ_PATH_SORTED_WRITE = 0x800
 HMJ_PATH_SORTED_FK = 0x1000
 HMJ_PATH_DENSE_BUILD = 0x2000
+HMJ_PATH_GLOBAL_TABLE = 0x20000
 HMJ_PATH_HOST_PIPELINE = 0x4000
 HMJ_PATH_SORTED_FK_HALF = 0x8000
 HMJ_PATH_LOOKBACK_TIMEOUT = 0x10000
@@ -177,6 +178,8 @@ def load_library():
     L.hmj_owner_split_u64_device.argtypes = [vp, vp, u, i, _U64P, vp, vp]
     L.hmj_last_exchange_info.restype = i
     L.hmj_last_exchange_info.argtypes = [vp, C.POINTER(ExchangeInfo)]
+    L.hmj_comm_set_owner_path.restype = i
+    L.hmj_comm_set_owner_path.argtypes = [vp, i]
     L.hmj_comm_set_self_exchange.restype = i
     L.hmj_comm_set_self_exchange.argtypes = [vp, i]
     L.hmj_exchange_digit_plan.restype = i

@@ -844,10 +844,15 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       // only in part (the dense-build plan: more bits) and the partitions stay key ranges.  (Round 2 kept the
       // sampled prefix and finished such a join with a sort of all result rows by key: 2^25 + 5 dense keys, ordered,
       // 7.2 ms against 1.4 ms for uniform keys, tools/exp_cliffs2.py.)
+      // (A probe side that was still arriving when the sample ran -- host pipeline, exchange rounds -- has arrived by
+      //  now, or will have once its events fire: this IS the retry.  Its keys must be in the exact prefix, or an
+      //  ordered join whose probe keys lie outside the build keys' prefix would fail a second time)
+      for (hipEvent_t ev : c->arrive_ev) HIP_TRY(hipStreamWaitEvent(c->stream, ev, 0));
+      const bool probe_readable = !c->sample_build_only || !c->arrive_ev.empty();
       u64* ex3 = (u64*)c->offs64.p;
       const u64 init[3] = {0, ~0ull, 0};
       HIP_TRY(hipMemcpyAsync(ex3, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hmj::launch_key_exact(R, nb, c->sample_build_only ? nullptr : S, c->sample_build_only ? 0u : np, smp[1], ex3,
+      HIP_TRY(hmj::launch_key_exact(R, nb, probe_readable ? S : nullptr, probe_readable ? np : 0u, smp[1], ex3,
                                     c->num_cus, c->stream));
       HIP_TRY(hipMemcpyAsync(c->h_accum.p, ex3, 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -885,7 +890,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     const int pfx = smp[0] ? __builtin_clzll(smp[0]) : 64;
     const u64 n_smp = nb < 2048 ? nb : 2048;
     const bool even = smp[6] >= 48 && smp[7] * 64 <= 4 * n_smp + 64;
-    if (c->dense_plan && c->force_bits < 0 && nb > 0 && smp[5] > smp[4] && pfx < 64 && even) {
+    // (a caller's minimum prefix hides top bits the keys DO differ in: the build keys' range says nothing about the window below it)
+    if (c->dense_plan && c->force_bits < 0 && nb > 0 && smp[5] > smp[4] && pfx < 64 && even && c->min_prefix_bits <= pfx) {
       const double span = (double)(smp[5] - smp[4]) + 1.0, full = __builtin_ldexp(1.0, 64 - pfx);
       const double fraction = span / full;
       // (between 0.7 and 1 the bits stay -- dense ids fill whole partitions of a power-of-two size either way -- but the
@@ -974,6 +980,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // dense / small-integer keys: skip the top bits every (sampled) key shares
     const u64* hs = smp;
     prefix = hs[0] ? __builtin_clzll(hs[0]) : 64;
+    // (a caller that consumed top key bits itself -- the exchange's digit owner -- says so with a MINIMUM: the sample
+    //  still runs for its hot-key / sorted-input / density hints, the partition window starts at or below the hint)
+    const bool hinted = c->min_prefix_bits > prefix;
+    if (hinted) prefix = c->min_prefix_bits > 64 ? 64 : c->min_prefix_bits;
     pfx_ref = hs[1];
     hot_hint = (hs[2] & 0xFFFF) >= 2 || (hs[3] & 0xFFFF) >= 2;  // neighbouring sample positions with equal keys: a hot key
     if (hot_hint && P >= 16 && Q > 1 && c->split_mode && !c->prepare_only) {
@@ -982,7 +992,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       Q = 1;
       items = P;
     }
-    sampled = prefix > 0;
+    sampled = prefix > 0 && !hinted;  // (a hinted prefix is not shared by the keys: nothing may verify or rely on it)
     if (prefix + B > 64) prefix = 64 - B;
     if (!c->prepare_only && c->window_mode && (!(flags & HMJ_ORDERED) || allow_win_ordered)) {
       // hs[0] has a 1 wherever two sampled keys differ.  Keys with structure (a tag in the top bits,
@@ -1481,8 +1491,83 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   return HMJ_OK;
 }
 
+// Small build side, count modes: one global hash table, the probe side streamed once (gtable.hip).  *done = the join
+// was answered here.  Not taken (or given up: duplicates / a clustering key set raise ERR_GTABLE, then the context
+// skips it for the next 8 joins) -> the partitioned paths run as before.
+// When: the table (16 B x 2^k slots, load factor <= 0.5) must stay cache-resident while the probe side streams by, and
+// the probe side must be big enough for the saved partitioning pass to matter -- build rows <= c->gtable_max_rows,
+// probe rows >= c->gtable_min_fanout x build rows.
+int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
+                     hmj_result* out, bool* done) {
+  *done = false;
+  if (!c->gtable_mode || (flags & (HMJ_MATERIALIZE | HMJ_ORDERED)) || c->prepare_only || c->force_bits >= 0 ||
+      !c->arrive_ev.empty() || n_build == 0 || n_build > (c->gtable_max_rows >> ((flags & HMJ_FIRST_WINS) ? 1 : 0)) || n_probe > 0xFFFFFFFFull ||
+      n_probe < c->gtable_min_probe || n_probe < (uint64_t)c->gtable_min_fanout * n_build ||
+      (c->prep.valid && c->prep.ptr == R && c->prep.n == (u32)n_build))
+    return HMJ_OK;
+  if (c->gtable_cooldown > 0) {
+    c->gtable_cooldown--;
+    return HMJ_OK;
+  }
+  int rc;
+  if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
+  if ((rc = check_rel(c, R, n_build, "build_aos is NULL")) != HMJ_OK) return rc;
+  if ((rc = check_rel(c, S, n_probe, "probe_aos is NULL")) != HMJ_OK) return rc;
+  int log_cap = 10;
+  // slots: 16 per build row while the table stays within 2^18 slots (4 MiB, an XCD's L2), never fewer than 4
+  while (((u64)1 << log_cap) < (u64)c->gtable_slots_per_row * n_build) log_cap++;
+  while (log_cap > c->gtable_max_log_cap && ((u64)1 << (log_cap - 1)) >= 4 * n_build) log_cap--;
+  const size_t tab_bytes = (size_t)16 << log_cap;
+  if ((rc = ensure_dev(c, c->gtab, tab_bytes)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  const bool first = flags & HMJ_FIRST_WINS, extra = flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE);
+  HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+  int sp = span_begin(c, K_PROBE_COUNT, -1);
+  HIP_TRY(hipMemsetAsync(c->gtab.p, 0xFF, tab_bytes, c->stream));  // every slot empty (key of all ones)
+  HIP_TRY(hmj::launch_gtable_build(R, (u32)n_build, c->gtab.p, log_cap, (u64*)c->accum.p, first, c->num_cus, c->stream));
+  HIP_TRY(hmj::launch_gtable_probe(S, (u32)n_probe, c->gtab.p, log_cap, R, (u64*)c->accum.p, first, extra, c->num_cus,
+                                   c->gtable_wg_per_cu, c->stream));
+  span_end(c, sp);
+  u64* hh = (u64*)c->h_accum.p;
+  HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) {
+    c->gtable_cooldown = 8;
+    std::vector<Span> keep;  // forget the abandoned attempt's span
+    for (const Span& s2 : c->spans)
+      if (s2.kind == K_TOTAL || s2.kind == K_H2D) keep.push_back(s2);
+    c->spans.swap(keep);
+    if (c->trace) std::fprintf(stderr, "[hmj] join nb=%llu np=%llu: global table gave up (long walk or reserved key) -> partitioned path\n",
+                               (unsigned long long)n_build, (unsigned long long)n_probe);
+    return HMJ_OK;
+  }
+  std::memset(out, 0, sizeof(*out));
+  out->n_matches = hh[hmj::ACC_N];
+  out->sum_r = hh[hmj::ACC_SUM_R];
+  out->sum_s = hh[hmj::ACC_SUM_S];
+  out->xor_fold = hh[hmj::ACC_XOR];
+  out->mix_sum = hh[hmj::ACC_MIX];
+  out->sum_probe_all = hh[hmj::ACC_SUM_P];
+  c->timing.path |= HMJ_PATH_GLOBAL_TABLE;
+  c->timing.radix_bits = 0;
+  c->timing.radix_passes = 0;
+  c->timing.n_probe_items = 1;
+  c->timing.bytes_probe_count = 16ull * (n_build + n_probe);
+  c->prep.valid = false;
+  if (c->trace) std::fprintf(stderr, "[hmj] join nb=%llu np=%llu flags=%#x: global table of 2^%d slots\n",
+                             (unsigned long long)n_build, (unsigned long long)n_probe, flags, log_cap);
+  *done = true;
+  return HMJ_OK;
+}
+
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
+  {
+    bool done = false;
+    const int rc = try_global_table(c, R, n_build, S, n_probe, flags, out, &done);
+    if (rc != HMJ_OK || done) return rc;
+  }
   bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true, prefix_unsafe = false, slab_probe = true;
   if ((flags & HMJ_ORDERED) && c->exact_prefix_joins > 0) {  // (a failed attempt costs more than the pass over the keys)
     c->exact_prefix_joins--;
@@ -1552,6 +1637,15 @@ int hmj_create(hmj_ctx** out, int device_id) {
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
+  if (const char* e = getenv("HMJ_GTABLE")) c->gtable_mode = atoi(e) != 0;  // 0: small build sides are partitioned too
+  if (const char* e = getenv("HMJ_GTABLE_MAX_LOG2")) {
+    const int l = atoi(e);
+    if (l >= 0 && l <= 28) c->gtable_max_rows = 1ull << l;
+  }
+  if (const char* e = getenv("HMJ_GTABLE_FANOUT")) c->gtable_min_fanout = atoi(e) > 0 ? (u32)atoi(e) : 1u;
+  if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+  if (const char* e = getenv("HMJ_GTABLE_SLOTS")) c->gtable_slots_per_row = atoi(e) >= 2 ? (u32)atoi(e) : 2u;
+  if (const char* e = getenv("HMJ_GTABLE_MAX_LOG_CAP")) c->gtable_max_log_cap = atoi(e);
   if (const char* e = getenv("HMJ_PLACE")) {  // 0: nothing is probed; n: joins search too (at most n candidates per buffer)
     c->place_tune = atoi(e) != 0;
     if (atoi(e) > 0) {
@@ -1618,7 +1712,7 @@ void hmj_destroy(hmj_ctx* c) {
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
                     &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched, &c->vparts,
-                    &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs, &c->lookback};
+                    &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs, &c->lookback, &c->gtab};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);
@@ -1885,6 +1979,12 @@ static int join_host_impl(hmj_ctx* c, const void* build_aos_host, uint64_t n_bui
   // the staging buffers may still be read by earlier work on the compute stream
   HIP_TRY(hipEventRecord(c->copy_ev[kChunks + 1], c->stream));
   HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->copy_ev[kChunks + 1], 0));
+  // From here on copies that read the CALLER'S buffers are queued: whichever way this function is left, they have
+  // completed first (free on success -- every join path has waited for all arrive events by then)
+  struct CopySync {
+    hipStream_t s;
+    ~CopySync() { (void)hipStreamSynchronize(s); }
+  } copy_sync{c->copy_stream};
   HIP_TRY(hipMemcpyAsync(c->in_r.p, build_aos_host, n_build * 16, hipMemcpyHostToDevice, c->copy_stream));
   HIP_TRY(hipEventRecord(c->copy_ev[kChunks], c->copy_stream));
   std::vector<u64> ends;
@@ -1911,7 +2011,6 @@ static int join_host_impl(hmj_ctx* c, const void* build_aos_host, uint64_t n_bui
   c->arrive_rows.clear();
   c->arrive_ev.clear();
   span_end(c, st);
-  if (rc != HMJ_OK) (void)hipStreamSynchronize(c->copy_stream);  // the caller's buffers are not read after return
   if (c->profiling) {
     (void)hipStreamSynchronize(c->stream);
     spans_collect(c);

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -109,6 +110,7 @@ struct hmj_comm {
   u64 max_msg_bytes = 1ull << 30;       // RCCL 2.26 truncates a single message of 2 GiB or more
   u64 target_round_bytes = 128ull << 20;  // probe side: several rounds, so the local pass A starts on arrived rows
   bool round_bytes_set = false;           // the host chose the round size itself (hmj_comm_set_message_bytes)
+  int owner_path = HMJ_OWNER_DIGIT;       // non-ordered joins: digit ranges (default) or round 2's hash owner split (hmj_comm_set_owner_path, HMJ_EXCHANGE_OWNER=split)
   hmj_exchange_info info;
 };
 
@@ -158,6 +160,9 @@ int comm_ensure(hmj_ctx* c) {
   if (!ok) {
     comm_free(m);
     return fail(c, HMJ_E_HIP, "communication stream / events");
+  }
+  if (const char* e = getenv("HMJ_EXCHANGE_OWNER")) {  // "split": round 2's owner-split path for all non-ordered joins
+    if (std::strcmp(e, "split") == 0) m->owner_path = HMJ_OWNER_SPLIT;
   }
   c->comm = m;
   return HMJ_OK;
@@ -418,8 +423,10 @@ namespace {
 
 // Exchange one relation: rounds of alltoallv queued on the communication stream.  ev_after_round (optional):
 // events recorded after each round (n_rounds of them).  Returns rows received.
+// soft_err: a failed event record does not stop the queuing (the peers' receives are matched by this rank's rounds);
+// it becomes the rank's pending error, which the caller carries to the final reduction
 int exchange_relation(hmj_ctx* c, const void* parted, const u64* counts_matrix, u32 n_rounds, int layout, void* recv,
-                      hipEvent_t* ev_after_round, u64* round_end) {
+                      hipEvent_t* ev_after_round, u64* round_end, int* soft_err) {
   hmj_comm* m = c->comm;
   const int G = m->n_ranks;
   std::vector<u64> so((size_t)n_rounds * G), sr(so.size()), ro(so.size()), rr(so.size());
@@ -436,7 +443,10 @@ int exchange_relation(hmj_ctx* c, const void* parted, const u64* counts_matrix, 
       rb[g] = rr[(size_t)r * G + g] * 16;
     }
     if ((rc = transport_round(c, (int)r, sp.data(), sb.data(), rp.data(), rb.data())) != HMJ_OK) return rc;
-    if (ev_after_round) HIP_TRY(hipEventRecord(ev_after_round[r], m->stream));
+    if (ev_after_round) {
+      const hipError_t e = hipEventRecord(ev_after_round[r], m->stream);
+      if (e != hipSuccess && *soft_err == HMJ_OK) *soft_err = fail(c, HMJ_E_HIP, "hipEventRecord", e);
+    }
   }
   return HMJ_OK;
 }
@@ -524,6 +534,13 @@ int hmj_comm_set_message_bytes(hmj_ctx* c, uint64_t max_message_bytes, uint64_t 
     c->comm->target_round_bytes = probe_round_bytes < 16 ? 16 : probe_round_bytes;
     c->comm->round_bytes_set = true;
   }
+  return HMJ_OK;
+}
+
+int hmj_comm_set_owner_path(hmj_ctx* c, int owner_path) {
+  if (!c || !c->comm) return c ? fail(c, HMJ_E_ARG, "no communicator") : HMJ_E_ARG;
+  if (owner_path != HMJ_OWNER_DIGIT && owner_path != HMJ_OWNER_SPLIT) return fail(c, HMJ_E_ARG, "owner_path");
+  c->comm->owner_path = owner_path;
   return HMJ_OK;
 }
 
@@ -801,6 +818,13 @@ int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np
       const u64* o = oh + (size_t)rel * noff;
       for (u32 d = 0; d < D; d++) msg[1 + d] = o[d + 1] - o[d];
     }
+    // the communication stream waits for this relation's pre-pass -- queued BEFORE the all-gather, so that a failure
+    // here travels in its status word and every rank leaves together (local failures after the first
+    // all-gather must not return on this rank alone).  Order on the stream: [wait R] R rounds [wait S] S rounds.
+    if (*err == HMJ_OK) {
+      hipError_t e = hipStreamWaitEvent(m->stream, rel == 0 ? m->ev_split : m->ev_split_s, 0);
+      if (e != hipSuccess) *err = fail(c, HMJ_E_HIP, "hipStreamWaitEvent", e);
+    }
     if (rel == 1 && c->profiling && *err == HMJ_OK) {  // both pre-passes are complete: their spans
       spans_collect(c);
       add_timing(&acc, c->timing);
@@ -838,9 +862,13 @@ int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np
     } else if (mine != HMJ_OK) {
       return mine;  // cannot happen: the buffer is at least as large as in an earlier step
     }
-    // queue the rounds
-    HIP_TRY(hipStreamWaitEvent(m->stream, rel == 0 ? m->ev_split : m->ev_split_s, 0));
-    HIP_TRY(hipEventRecord(rel == 0 ? m->ev_t0 : m->ev_t1, m->stream));
+    // queue the rounds.  From here on every rank queues ALL its rounds whatever happens to it locally (its peers'
+    // receives are matched by them); only a failure of the transport itself returns at once.  A failed event record
+    // becomes this rank's pending error: its local joins are skipped and the final reduction tells everybody.
+    auto note = [&](hipError_t e, const char* what) {
+      if (e != hipSuccess && *err == HMJ_OK) *err = fail(c, HMJ_E_HIP, what, e);
+    };
+    note(hipEventRecord(rel == 0 ? m->ev_t0 : m->ev_t1, m->stream), "hipEventRecord");
     const char* parted = static_cast<const char*>(rel == 0 ? m->parted_r.p : m->parted_s.p);
     char* rbase = static_cast<char*>(recv.p);
     const bool in_place = G == 1 && !m->self_exchange;  // (not reached today: one rank takes the plain join)
@@ -852,13 +880,13 @@ int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np
         rb[g] = rr[(size_t)r * G + g] * 16;
       }
       if ((rc = transport_round(c, (int)(rel * NR + r), sp.data(), sb.data(), rp.data(), rb.data())) != HMJ_OK) return rc;
-      if (rel == 1) HIP_TRY(hipEventRecord(m->round_ev[r], m->stream));
+      if (rel == 1) note(hipEventRecord(m->round_ev[r], m->stream), "hipEventRecord");
     }
     if (rel == 0) {
-      HIP_TRY(hipEventRecord(m->ev_t3, m->stream));
-      HIP_TRY(hipEventRecord(m->ev_build, m->stream));
+      note(hipEventRecord(m->ev_t3, m->stream), "hipEventRecord");
+      note(hipEventRecord(m->ev_build, m->stream), "hipEventRecord");
     } else {
-      HIP_TRY(hipEventRecord(m->ev_t2, m->stream));
+      note(hipEventRecord(m->ev_t2, m->stream), "hipEventRecord");
     }
   }
   if (!c->profiling) m->info.ms_split = ms_since(t_split);
@@ -869,8 +897,11 @@ int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np
   const auto t_local = std::chrono::steady_clock::now();
   std::memset(local_out, 0, sizeof(*local_out));
   int lerr = HMJ_OK;
-  const int saved_prefix = c->prefix_bits;
-  HIP_TRY(hipStreamWaitEvent(c->stream, m->ev_build, 0));
+  {
+    hipError_t e = *err == HMJ_OK ? hipStreamWaitEvent(c->stream, m->ev_build, 0) : hipSuccess;
+    if (e != hipSuccess) lerr = fail(c, HMJ_E_HIP, "hipStreamWaitEvent", e);
+  }
+  if (*err != HMJ_OK) lerr = *err;  // (a local failure while the rounds were queued: no joins, straight to the reduction)
   for (u32 r = 0; r < NR && lerr == HMJ_OK; r++) {
     const u64 nr_ = round_off_r[r + 1] - round_off_r[r], ns_ = round_off_s[r + 1] - round_off_s[r];
     hipError_t e = hipStreamWaitEvent(c->stream, m->round_ev[r], 0);
@@ -884,10 +915,12 @@ int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np
     spans_reset(c);
     // count modes: skip the bits the digit consumed (a round of several digits differs in them, which any
     // partition function may ignore); materialising joins (one round) let the planner sample the keys itself
-    if (!materialize) c->prefix_bits = 64 - low;
+    // (as a MINIMUM: the key sample of the round's join still runs, so sorted shards, hot keys and dense build keys
+    //  keep their plans -- forcing prefix_bits switched the sample off)
+    if (!materialize) c->min_prefix_bits = 64 - low;
     const int rc = join_device(c, static_cast<const char*>(m->recv_r.p) + round_off_r[r] * 16, nr_,
                                static_cast<const char*>(m->recv_s.p) + round_off_s[r] * 16, ns_, flags, &res, false);
-    c->prefix_bits = saved_prefix;
+    c->min_prefix_bits = 0;
     if (rc != HMJ_OK) {
       lerr = rc;
       break;
@@ -949,6 +982,7 @@ int exchange_owner_path(hmj_ctx* c, const void* build_shard_dev, u64 n_build, co
         hipError_t e = hipSuccess;
         if (rc == HMJ_OK) e = hipMemcpyAsync(oh, od, 2 * noff * 8, hipMemcpyDeviceToHost, c->stream);
         if (rc == HMJ_OK && e == hipSuccess) e = hipEventRecord(m->ev_split, c->stream);
+        if (rc == HMJ_OK && e == hipSuccess) e = hipStreamWaitEvent(m->stream, m->ev_split, 0);  // (before the all-gather: a failure travels in its status word)
         if (rc == HMJ_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (rc == HMJ_OK && e != hipSuccess) rc = fail(c, HMJ_E_HIP, "owner split", e);
         if (rc == HMJ_OK)
@@ -964,7 +998,11 @@ int exchange_owner_path(hmj_ctx* c, const void* build_shard_dev, u64 n_build, co
   } else {
     cnt[1] = n_build;
     cnt[2] = n_probe;
-    HIP_TRY(hipEventRecord(m->ev_split, c->stream));
+    if (*err == HMJ_OK) {
+      hipError_t e = hipEventRecord(m->ev_split, c->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(m->stream, m->ev_split, 0);
+      if (e != hipSuccess) *err = fail(c, HMJ_E_HIP, "owner split", e);
+    }
   }
   m->info.ms_split = ms_since(t_split);
   cnt[0] = *err == HMJ_OK ? 0ull : (u64)(int64_t)*err;
@@ -1024,21 +1062,25 @@ int exchange_owner_path(hmj_ctx* c, const void* build_shard_dev, u64 n_build, co
     }
   }
 
-  // ---- exchange: everything is queued on the communication stream behind the splits
-  HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_split, 0));
-  HIP_TRY(hipEventRecord(m->ev_t0, m->stream));
-  if ((rc = exchange_relation(c, parted_r, MR.data(), rounds_r, 0, m->recv_r.p, nullptr, nullptr)) != HMJ_OK) return rc;
-  HIP_TRY(hipEventRecord(m->ev_build, m->stream));
-  HIP_TRY(hipEventRecord(m->ev_t1, m->stream));
+  // ---- exchange: everything is queued on the communication stream behind the splits (the stream was told to wait
+  // for them before the counts were gathered).  Every rank queues all its rounds; a failed event record becomes
+  // this rank's pending error (no local join, reported by the final reduction); only the transport returns at once.
+  auto note = [&](hipError_t e2, const char* what) {
+    if (e2 != hipSuccess && *err == HMJ_OK) *err = fail(c, HMJ_E_HIP, what, e2);
+  };
+  note(hipEventRecord(m->ev_t0, m->stream), "hipEventRecord");
+  if ((rc = exchange_relation(c, parted_r, MR.data(), rounds_r, 0, m->recv_r.p, nullptr, nullptr, err)) != HMJ_OK) return rc;
+  note(hipEventRecord(m->ev_build, m->stream), "hipEventRecord");
+  note(hipEventRecord(m->ev_t1, m->stream), "hipEventRecord");
   std::vector<u64> round_end(rounds_s);
-  if ((rc = exchange_relation(c, parted_s, MS.data(), rounds_s, 1, m->recv_s.p, m->round_ev.data(), round_end.data())) != HMJ_OK)
+  if ((rc = exchange_relation(c, parted_s, MS.data(), rounds_s, 1, m->recv_s.p, m->round_ev.data(), round_end.data(), err)) != HMJ_OK)
     return rc;
-  HIP_TRY(hipEventRecord(m->ev_t2, m->stream));
+  note(hipEventRecord(m->ev_t2, m->stream), "hipEventRecord");
 
   // ---- local join: build side as soon as it is complete, probe side as its rounds arrive
   const auto t_local = std::chrono::steady_clock::now();
-  int lerr = HMJ_OK;
-  hipError_t e = hipStreamWaitEvent(c->stream, m->ev_build, 0);
+  int lerr = *err;
+  hipError_t e = lerr == HMJ_OK ? hipStreamWaitEvent(c->stream, m->ev_build, 0) : hipSuccess;
   if (e != hipSuccess) lerr = fail(c, HMJ_E_HIP, "hipStreamWaitEvent", e);
   spans_reset(c);
   c->sample_build_only = true;
@@ -1150,12 +1192,12 @@ extern "C" int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_
     nr64 = std::min<u64>(std::max<u64>(nr64, 1), HMJ_MAX_ROUNDS);
     hmj_digit_plan plan;
     if (hmj_exchange_digit_plan(G, smp.keys.data(), smp.keys.size(), (u32)nr64, &plan) != HMJ_OK) return fail(c, HMJ_E_ARG, "digit plan");
-    if (plan.usable) {
+    if (plan.usable && m->owner_path == HMJ_OWNER_DIGIT) {
       rc = exchange_digit_path(c, build_shard_dev, n_build, probe_shard_dev, n_probe, flags, plan, local_out, &err);
     } else {
       // a few clusters of keys: no contiguous digit ranges balance the ranks -- the hash owner spreads ANY key set
       own.mode = 1;
-      m->info.fallback = 1;
+      m->info.fallback = plan.usable ? 0 : 1;  // (0: the caller asked for this path, hmj_comm_set_owner_path)
       m->info.sample_max_share = plan.max_share;
       rc = exchange_owner_path(c, build_shard_dev, n_build, probe_shard_dev, n_probe, flags, own, local_out, &err);
     }

@@ -15,8 +15,7 @@
 //           raises ERR_GTABLE: the host discards the attempt and takes the partitioned path.
 //   probe   grid-stride over tiles of the probe side, four rows per thread walking in lockstep (four independent
 //           loads in flight per lane); probe rows are loaded nontemporally so they do not push the table out of L2.
-//   key == GT_EMPTY cannot live in the table: such build rows are aggregated in three side words (count, sum of
-//           payloads, smallest row index) and such probe rows read those.
+//   key == GT_EMPTY cannot live in the table: a build row with that key raises ERR_GTABLE as well (partitioned path).
 //   HMJ_FIRST_WINS: the slots carry the build row's INDEX instead of its payload; a probe row keeps the smallest
 //           index among its hits (= first in input order, unordered_map::insert semantics) and fetches that row's
 //           payload from the build relation.
@@ -29,7 +28,10 @@ namespace hmj {
 constexpr u64 GT_EMPTY = ~0ull;
 constexpr int GT_MAXWALK = 64;
 constexpr int GT_THREADS = 256;
-constexpr int GT_ROWS = 4;  // probe rows per thread and tile
+#ifndef HMJ_GT_ROWS
+#define HMJ_GT_ROWS 8
+#endif
+constexpr int GT_ROWS = HMJ_GT_ROWS;  // probe rows per thread and tile
 
 __device__ __forceinline__ u32 gt_hash(u64 key, int shift) {
   u64 h = key * 0x9E3779B97F4A7C15ull;
@@ -38,20 +40,16 @@ __device__ __forceinline__ u32 gt_hash(u64 key, int shift) {
   return (u32)(h >> shift);
 }
 
-// side[0] = build rows with key GT_EMPTY, side[1] = sum of their payloads, side[2] = smallest index of such a row
 template <bool FIRST>
 __global__ __launch_bounds__(GT_THREADS) void gtable_build_kernel(const Tup* __restrict__ R, u32 nb, Tup* __restrict__ tab,
-                                                                   int log_cap, u64* __restrict__ side,
-                                                                   u64* __restrict__ accum) {
+                                                                   int log_cap, u64* __restrict__ accum) {
   const u32 mask = (1u << log_cap) - 1;
   const int shift = 64 - log_cap;
-  bool bad = false;
+  bool bad = false, dup = false;
   for (u64 i = (u64)blockIdx.x * GT_THREADS + threadIdx.x; i < nb; i += (u64)gridDim.x * GT_THREADS) {
     const Tup t = R[i];
     if (t.key == GT_EMPTY) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(&side[0]), 1ull);
-      atomicAdd(reinterpret_cast<unsigned long long*>(&side[1]), (unsigned long long)t.val);
-      atomicMin(reinterpret_cast<unsigned long long*>(&side[2]), (unsigned long long)i);
+      bad = true;
       continue;
     }
     u32 s = gt_hash(t.key, shift);
@@ -63,17 +61,21 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_build_kernel(const Tup* __r
         tab[s].val = FIRST ? i : t.val;
         break;
       }
+      dup |= old == t.key;
       s = (s + 1) & mask;
     }
     bad |= walk == GT_MAXWALK;
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_GTABLE);
+  // a key met twice: probe walks must go on past a hit (multi-map).  Otherwise -- unique build keys, the usual case --
+  // the probe kernel stops a walk at its hit (accum[ACC_PAD] is read there as a wave-uniform flag)
+  if (__any(dup) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_PAD]), 1ull);
 }
 
 template <bool FIRST, bool EXTRA>
 __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
-                                                                   int log_cap, const u64* __restrict__ side,
-                                                                   const Tup* __restrict__ R, u64* __restrict__ accum) {
+                                                                   int log_cap, const Tup* __restrict__ R,
+                                                                   u64* __restrict__ accum) {
   __shared__ u64 red[8];
   const int tid = threadIdx.x;
   if (tid < 8) red[tid] = 0;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __r
   const int shift = 64 - log_cap;
   constexpr u32 TILE = GT_THREADS * GT_ROWS;
   u64 acc_n = 0, acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
+  const bool multi = accum[ACC_PAD] != 0;  // duplicate build keys: a walk ends at an empty slot only
   for (u64 base = (u64)blockIdx.x * TILE; base < np; base += (u64)gridDim.x * TILE) {
     Tup t[GT_ROWS];
     u32 slot[GT_ROWS];
@@ -98,24 +101,7 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __r
       slot[r] = gt_hash(t[r].key, shift);
       first_idx[r] = ~0ull;
       if (EXTRA && live[r]) acc_p += t[r].val;
-      if (live[r] && t[r].key == GT_EMPTY) {  // cannot be a table key: the side words hold these build rows
-        live[r] = false;
-        const u64 cnt = side[0];
-        if (cnt) {
-          if (FIRST) {
-            first_idx[r] = side[2];
-          } else {
-            acc_n += cnt;
-            acc_r += side[1];
-            acc_s += cnt * t[r].val;
-            if (EXTRA) {  // (not reachable with distinct payloads unknown: only the count and sums are aggregated)
-              // checksums need every row: walk the build relation for them (rare: a key of all ones)
-              for (u32 j = 0; j < 0; j++) {
-              }
-            }
-          }
-        }
-      }
+      if (t[r].key == GT_EMPTY) live[r] = false;  // never a table key (the build kernel refuses such rows)
     }
     bool any_live = false;
 #pragma unroll
@@ -146,8 +132,12 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __r
                 }
               }
             }
-            slot[r] = (slot[r] + 1) & mask;
-            any_live = true;
+            if (!multi && e[r].key == t[r].key) {
+              live[r] = false;
+            } else {
+              slot[r] = (slot[r] + 1) & mask;
+              any_live = true;
+            }
           }
         }
       }
@@ -174,23 +164,23 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __r
   block_accumulate(red, accum, v, 1u << ACC_XOR);
 }
 
-hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u64* side, u64* accum, bool first,
-                               int num_cus, hipStream_t st) {
-  if (log_cap < 4 || log_cap > 30 || ((u64)1 << log_cap) < 2ull * nb) return hipErrorInvalidValue;
+hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u64* accum, bool first, int num_cus,
+                               hipStream_t st) {
+  if (log_cap < 4 || log_cap > 30 || ((u64)1 << log_cap) < (u64)nb + nb / 4 + 1) return hipErrorInvalidValue;  // (load factor <= 0.8: walks must end)
   u64 grid = ((u64)nb + GT_THREADS - 1) / GT_THREADS;
   if (grid > (u64)num_cus * 16) grid = (u64)num_cus * 16;
   if (grid < 1) grid = 1;
   if (first)
     hipLaunchKernelGGL((gtable_build_kernel<true>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(R), nb,
-                       static_cast<Tup*>(tab), log_cap, side, accum);
+                       static_cast<Tup*>(tab), log_cap, accum);
   else
     hipLaunchKernelGGL((gtable_build_kernel<false>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(R), nb,
-                       static_cast<Tup*>(tab), log_cap, side, accum);
+                       static_cast<Tup*>(tab), log_cap, accum);
   return hipGetLastError();
 }
 
-hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_cap, const u64* side, const void* R,
-                               u64* accum, bool first, bool extra, int num_cus, int wg_per_cu, hipStream_t st) {
+hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_cap, const void* R, u64* accum, bool first,
+                               bool extra, int num_cus, int wg_per_cu, hipStream_t st) {
   if (log_cap < 4 || log_cap > 30) return hipErrorInvalidValue;
   const u64 tiles = ((u64)np + GT_THREADS * GT_ROWS - 1) / (GT_THREADS * GT_ROWS);
   u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8);
@@ -198,7 +188,7 @@ hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_c
   if (grid < 1) grid = 1;
 #define HMJ_GT(F, E)                                                                                                   \
   hipLaunchKernelGGL((gtable_probe_kernel<F, E>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np, \
-                     static_cast<const Tup*>(tab), log_cap, side, static_cast<const Tup*>(R), accum)
+                     static_cast<const Tup*>(tab), log_cap, static_cast<const Tup*>(R), accum)
   if (first) {
     if (extra) HMJ_GT(true, true); else HMJ_GT(true, false);
   } else {

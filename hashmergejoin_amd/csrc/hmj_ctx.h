@@ -45,7 +45,7 @@ struct hmj_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
       out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
-      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback;
+      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback, gtab;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int host_threads = 0;  // staging threads for pageable input (0 = default)
   std::vector<hipStream_t> up_streams;
@@ -53,6 +53,7 @@ struct hmj_ctx {
   std::vector<HostBuf> up_slots;      // 2 per staging thread
   int force_bits = -1;
   int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
+  int min_prefix_bits = 0;  // with sampling: the partition window starts at or below this many top bits (internal: exchange rounds)
   // build side partitioned ahead of the join by hmj_prepare_build_u64_device (one-shot)
   struct Prep {
     bool valid = false, slab = false;
@@ -84,6 +85,20 @@ struct hmj_ctx {
   bool sorted_fk = false;  // the last ordered join's probe keys repeated: start with the foreign-key form of the kernel
   int sorted_fk_age = 0;
   u64 probe_hint = 0;
+  // small build sides: one global hash table, probe side streamed unpartitioned (gtable.hip, count modes).  Measured
+  // (tools/exp_gtable.py, profiles/r04b_*; 2^26 probe rows, ms per join, partitioned path -> global table): build rows
+  // 2^13 1.01 -> 0.42, 2^14 0.98 -> 0.42, 2^15 0.99 -> 0.46, 2^16 1.00 -> 0.58, 2^17 0.99 -> 0.72, 2^18 1.01 -> 1.05 (a
+  // 16 MiB table: past an XCD's 4 MiB of L2 every lookup is a 128-byte line from the Infinity Cache), 2^20 1.05 -> 1.5.
+  // The load factor matters as much as the size (a wave walks until its longest walk ends): 16 slots per build row
+  // while the table stays within 2^18 slots = 4 MiB, never fewer than 4.
+  bool gtable_mode = true;         // HMJ_GTABLE=0 disables
+  uint64_t gtable_max_rows = 1ull << 17;  // build rows (HMJ_GTABLE_MAX_LOG2); HMJ_FIRST_WINS: half of it (the extra payload fetch from the build relation)
+  u32 gtable_min_fanout = 1;       // probe rows >= this x build rows (HMJ_GTABLE_FANOUT); it wins from fan-out 1 on (2^17 x 2^18: 0.125 -> 0.06 ms)
+  uint64_t gtable_min_probe = 1ull << 16;
+  int gtable_wg_per_cu = 8;        // probe grid (HMJ_GTABLE_WG)
+  u32 gtable_slots_per_row = 16;   // table slots per build row (HMJ_GTABLE_SLOTS) ...
+  int gtable_max_log_cap = 18;     // ... while the table has at most 2^this slots; beyond, down to 4 per row (HMJ_GTABLE_MAX_LOG_CAP)
+  int gtable_cooldown = 0;         // joins to skip it for after it gave up
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged
   bool host_pipeline = true;   // HMJ_HOST_PIPELINE=0: host entry points upload, join and download one after the other

@@ -83,6 +83,7 @@ constexpr u64 ERR_ORDER_DEFER = 16;  // ordered epilogue left a very large segme
 constexpr u64 ERR_ORDER_FAIL = 32;   // ordered epilogue: a segment too large to sort in place AND to defer (result > 2^32-1 rows)
 constexpr u64 ERR_SORTED = 64;   // one-pass ordered write met duplicate keys / clustered keys / an oversized partition
 constexpr u64 ERR_FASTPATH = 8;  // unique-key write mode met duplicate build keys / an oversized partition
+constexpr u64 ERR_GTABLE = 128;  // global-table path: a build row walked too far (duplicates / clustering hash) or has the empty marker as its key
 constexpr u64 ERR_PREFIX = 4;  // a key does not carry the sampled common prefix (ordered mode re-plans)
 
 __device__ __forceinline__ u64 mix64(u64 x) {  // same constants as oracle/hmj_oracle.c

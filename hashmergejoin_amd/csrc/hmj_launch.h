@@ -127,6 +127,13 @@ hipError_t launch_compact(const u64* part_out_off, const u32* in_base32, const u
                           const u64* arval, const u64* asval, u64* bkey, u64* brval, u64* bsval, int grid, hipStream_t st);
 hipError_t launch_rekey(void* pairs, u64 n, const u64* col, hipStream_t st);  // pairs[j].key = col[pairs[j].val]
 
+// gtable.hip: small build sides -- one global open-addressing table (2^log_cap slots of 16 bytes, pre-filled with 0xFF),
+// the probe side streamed once.  Count modes only.  R: the build relation (first-wins fetches payloads from it).
+hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u64* accum, bool first, int num_cus,
+                               hipStream_t st);
+hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_cap, const void* R, u64* accum, bool first,
+                               bool extra, int num_cus, int wg_per_cu, hipStream_t st);
+
 // gen.hip
 hipError_t launch_gen_build(void* out, u64 n, u64 start, u64 seed, hipStream_t st);
 hipError_t launch_gen_probe(void* out, u64 n, u64 start, u64 n_build, u64 seed, u64 miss_mod,

@@ -176,6 +176,11 @@ class Executor:
         """One-rank communicators: run the whole exchange path (tests / rehearsals) instead of the plain local join."""
         self._check(self.L.hmj_comm_set_self_exchange(self.h, int(bool(on))))
 
+    def comm_set_owner_path(self, split=False):
+        """Non-ordered distributed joins: digit-range owners with per-round joins (default) or, split=True, round 2's
+        hash owner with its separate owner split and one local join (hmj_comm_set_owner_path)."""
+        self._check(self.L.hmj_comm_set_owner_path(self.h, 1 if split else 0))
+
     def comm_set_message_bytes(self, max_message_bytes=0, probe_round_bytes=0):
         self._check(self.L.hmj_comm_set_message_bytes(self.h, max_message_bytes, probe_round_bytes))
 

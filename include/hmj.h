@@ -119,6 +119,7 @@ typedef struct {
 #define HMJ_PATH_SORTED_FK_WIDE 0x20000u /* ... in its wide shape: 6144 probe rows per partition (16-bit plan, slab path)    */
 #define HMJ_PATH_LOOKBACK_TIMEOUT 0x10000u /* a chained partition gave up waiting for its predecessor (a bug if seen) */
 #define HMJ_PATH_PRESORTED 0x40000u /* a relation arrived already partitioned (sorted by key): its radix passes were skipped */
+#define HMJ_PATH_GLOBAL_TABLE 0x20000u /* small build side: one global hash table, the probe side streamed unpartitioned */
 #define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -290,7 +291,12 @@ int hmj_comm_set_message_bytes(hmj_ctx* ctx, uint64_t max_message_bytes, uint64_
  * columns NULL.  Collective: all ranks, same flags; an error on one rank (bad sizes, out of memory, a failed
  * local join) makes EVERY rank return -- the failing one its own code, the others HMJ_E_PEER -- instead of
  * leaving its peers blocked in the next collective.  One rank: the plain local join (nothing to exchange),
- * unless hmj_comm_set_self_exchange asked for the whole path.                                                */
+ * unless hmj_comm_set_self_exchange asked for the whole path.
+ * STATUS: the digit-owner path (round 3, the default for non-ordered joins) has been verified with several ranks
+ * sharing one GPU over the callback transport and with one rank over RCCL; it has NOT yet run over RCCL between
+ * two real GPUs (no such box was available).  hmj_comm_set_owner_path(ctx, HMJ_OWNER_SPLIT) -- or
+ * HMJ_EXCHANGE_OWNER=split in the environment when the communicator is created -- selects round 2's owner-split
+ * path (hash owner, separate split, ONE local join) for all non-ordered joins instead.                         */
 int hmj_exchange_join_u64_device(hmj_ctx* ctx, const void* build_shard_dev, uint64_t n_build_shard,
                                  const void* probe_shard_dev, uint64_t n_probe_shard, uint32_t flags,
                                  hmj_result* local_out, hmj_result* global_out);
@@ -298,6 +304,13 @@ int hmj_exchange_join_u64_device(hmj_ctx* ctx, const void* build_shard_dev, uint
  * pre-pass, rounds through the transport (RCCL self send/recv), per-round joins -- where the default is the plain
  * local join.                                                                                                */
 int hmj_comm_set_self_exchange(hmj_ctx* ctx, int on);
+/* Which owner function non-ordered distributed joins use (collective setting: the same on every rank).
+ * HMJ_OWNER_DIGIT (default): ranges of the first radix pass's digit, per-round joins.  HMJ_OWNER_SPLIT: the hash
+ * owner with its separate owner split and one local join -- the path every clustered key set falls back to anyway.
+ * Nothing in the reference corresponds (one address space, radix_hash.h:375-405).                              */
+#define HMJ_OWNER_DIGIT 0
+#define HMJ_OWNER_SPLIT 1
+int hmj_comm_set_owner_path(hmj_ctx* ctx, int owner_path);
 /* The owner split on its own: rows grouped by owner rank, stably (owner-major; within an owner in input
  * order), offsets_dev[g] = first row of owner g (2^ceil(log2 n_ranks) + 1 uint64, device).  splitters: NULL =
  * hash owner; else n_ranks - 1 ascending keys (host memory) = key-range owner.  in/out must not overlap.   */

@@ -61,6 +61,8 @@ kind = hdist.init_comm(ex)
 assert kind == ("rccl" if backend == "nccl" else "group")
 if os.environ.get("MAXMSG"):
     ex.comm_set_message_bytes(int(os.environ["MAXMSG"]), int(os.environ["MAXMSG"]) // 4)
+if os.environ.get("OWNER_SPLIT") == "1":
+    ex.comm_set_owner_path(split=True)
 bd, pd = to_dev(Bs), to_dev(Ps)
 out, infos = {}, {}
 ex.set_profiling(True)
@@ -86,20 +88,21 @@ def free_port():
     return p
 
 
-def run_world(tmp_path, world, nb, npb, miss, dup, maxmsg, backend="gloo"):
+def run_world(tmp_path, world, nb, npb, miss, dup, maxmsg, backend="gloo", owner_split=False):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HMJ_ROOT=ROOT, NB=str(nb), NP=str(npb), MISS=str(miss), DUP=str(dup), OUT=str(tmp_path),
-                   MAXMSG=str(maxmsg) if maxmsg else "", OMP_NUM_THREADS="1", HMJ_SLAB_MIN_LOG2="22", BACKEND=backend)
+                   MAXMSG=str(maxmsg) if maxmsg else "", OMP_NUM_THREADS="1", HMJ_SLAB_MIN_LOG2="22", BACKEND=backend,
+                   OWNER_SPLIT="1" if owner_split else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=500)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     return [json.load(open(tmp_path / ("out%d.json" % r))) for r in range(world)]
 
 
-def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
+def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg, owner_split=False):
     B = oracle.gen_build(nb)
     if dup == 1:
         B[nb // 2:, 0] = B[: nb - nb // 2, 0]
@@ -129,7 +132,11 @@ def check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg):
     for o in res:
         i = o["info"]["count"]
         assert o["info"]["ordered"]["owner_mode"] == 2 and i["n_ranks"] == world
-        if dup == 3:
+        if owner_split:  # the caller asked for round 2's path (hmj_comm_set_owner_path): hash owner, not a fallback
+            assert i["owner_mode"] == 1 and i["fallback"] == (1 if dup == 3 else 0) and i["n_subjoins"] == 1, i
+            for name in ("checksum", "first"):
+                assert o["info"][name]["owner_mode"] == 1
+        elif dup == 3:
             assert i["owner_mode"] == 1 and i["fallback"] == 1 and i["sample_max_share"] > 1.3, i
         else:
             assert i["owner_mode"] == 3 and i["fallback"] == 0 and i["digit_bits"] == 8, i
@@ -159,6 +166,15 @@ def test_distributed_join_on_one_gpu(oracle, tmp_path, world, nb, npb, miss, dup
         for o in res:
             i = o["info"]["count"]
             assert i["path"] & H.HMJ_PATH_SLAB and i["n_subjoins"] == i["rounds_probe"] >= 1, i
+
+
+@pytest.mark.parametrize("world,nb,npb,miss,dup,maxmsg", [(3, 300000, 200000, 3, 0, 0), (2, 1 << 20, (1 << 20) + 777, 0, 1, 1 << 20)])  # (dup = 1 shares keys across the two halves: 2 or 4 ranks)
+def test_owner_split_path_stays_selectable(oracle, tmp_path, world, nb, npb, miss, dup, maxmsg):
+    # the digit-owner path is the default for non-ordered joins but has never crossed real links; round 2's
+    # owner-split path (hash owner, separate split, one local join) must stay selectable -- hmj_comm_set_owner_path /
+    # HMJ_EXCHANGE_OWNER=split -- and give the same results (first-wins across shards included).
+    res = run_world(tmp_path, world, nb, npb, miss, dup, maxmsg, owner_split=True)
+    check_world(oracle, tmp_path, res, world, nb, npb, miss, dup, maxmsg, owner_split=True)
 
 
 ERR_WORKER = r"""

@@ -1037,6 +1037,73 @@ def test_slab_path_parity_and_fallback(ex_fresh, H, oracle):
     assert t["ms_hist"] > 0.0  # the exact path produced this result
 
 
+def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
+    # A build side small enough for ONE cache-resident hash table is not radix-partitioned at all: the probe side is
+    # streamed once against a global open-addressing table (csrc/gtable.hip; the reference's own BM_hash_join_raw
+    # formulation, hashjoin_bench.cc:29-63, lookup semantics partitioned_hash.h:166-170).  Count modes, against the
+    # oracle: unique and duplicate build keys (a multi-map: cross product, or first in input order), unmatched probe
+    # rows, every flag set, sizes around the kernel's 1024-row probe tiles.
+    ex = ex_fresh
+    GT = H.HMJ_PATH_GLOBAL_TABLE
+    flagsets = (0, H.HMJ_CHECKSUM, H.HMJ_SUM_PROBE, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE,
+                H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE)
+    for nb, npb, miss, dup in [(1, 65536, 0, 0), (2, 70000, 2, 0), (1000, 65536 + 1023, 3, 0), (1000, 65536 + 1025, 0, 7),
+                               (4097, 300001, 5, 3), (60000, 262144, 0, 0), (65536, 1 << 20, 4, 5), (120000, 600000, 2, 0)]:
+        B = oracle.gen_build(nb)
+        if dup:  # every dup-th key a second (third ...) time, a few rows further down: first-wins must mean input order
+            m = len(B[dup - 1::dup])
+            B[dup - 1::dup, 0] = B[0::dup, 0][:m]
+        P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
+        Bd, Pd = to_dev(B), to_dev(P)
+        for fl in flagsets:
+            ck, _ = oracle.equijoin(B, P, first_wins=bool(fl & H.HMJ_FIRST_WINS), cap=0)
+            r = ex.join_device(Bd, Pd, fl)
+            t = ex.last_timing()
+            if fl & H.HMJ_FIRST_WINS and nb > 1 << 16:  # (first-wins fetches payloads from the build relation: half the row limit)
+                assert not t["path"] & GT
+            else:
+                assert t["path"] & GT and t["radix_passes"] == 0, (nb, npb, fl, hex(t["path"]))
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck, (nb, npb, fl)
+            if fl & H.HMJ_SUM_PROBE:
+                assert int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+        # materialising joins: partitioned as before
+        ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE)
+        assert not ex.last_timing()["path"] & GT
+    # a build side beyond 2^17 rows (its table would leave the L2), a forced plan: partitioned as before
+    B, P = oracle.gen_build(200000), oracle.gen_probe(800000, 200000)
+    ex.join_device(to_dev(B), to_dev(P), 0)
+    assert not ex.last_timing()["path"] & GT
+    B, P = oracle.gen_build(20000), oracle.gen_probe(100000, 20000)
+    ex.set_radix_bits(3)
+    try:
+        ex.join_device(to_dev(B), to_dev(P), 0)
+        assert not ex.last_timing()["path"] & GT and ex.last_timing()["radix_bits"] == 3
+    finally:
+        ex.set_radix_bits(None)
+    # what the table cannot hold sends the join to the partitioned path with the same answer, and the context skips
+    # the attempt for the next 8 joins: (a) a build key equal to the empty-slot marker (all ones), (b) a key with
+    # more copies than a lookup may walk
+    nb, npb = 5000, 200000
+    for case in ("marker", "copies"):
+        B, P = oracle.gen_build(nb), oracle.gen_uniform_domain(npb, nb)
+        if case == "marker":
+            B[77, 0] = np.uint64(M64)
+            P[5::1000, 0] = np.uint64(M64)
+        else:
+            B[100:400, 0] = B[50, 0]
+        ck, _ = oracle.equijoin(B, P, cap=0)
+        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
+        assert not ex.last_timing()["path"] & GT and r.checks() == ck, case
+        U, V = oracle.gen_build(1000), oracle.gen_uniform_domain(100000, 1000)
+        ex.join_device(to_dev(U), to_dev(V), 0)
+        assert not ex.last_timing()["path"] & GT  # cooling down
+        for _ in range(8):
+            ex.join_device(to_dev(U), to_dev(V), 0)
+        assert ex.last_timing()["path"] & GT
+
+
 def test_ordered_unique_key_write_mode(ex, H, oracle):
     # Ordered joins with unique build keys take the single-pass write mode (no count pass) on both
     # partition layouts; duplicate build keys make it give up and the count/scan/write passes run.

@@ -7,7 +7,7 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/build/variants
 mkdir -p $OUT/obj_$NAME
-for f in radix probe gen api exchange; do
+for f in radix probe gen gtable api exchange; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DHMJ_DEV "$@" \
     -c $ROOT/hashmergejoin_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
