@@ -111,7 +111,26 @@ def extra_runs(ex, H, torch):
         return round(best, 3), r
 
     out = {}
+    # the reference's own sweep goes on to 10^9 rows (hashjoin_bench.cc:269-283): 5 * 10^8 x 5 * 10^8, count mode, on the
+    # 17-bit plan the histogram-free slab partitioning makes since round 4 (9-bit + 8-bit pass)
+    n = 500000000
+    R, S = ex.gen_build(n), ex.gen_probe(n, n)
+    ms, r = timed(lambda: ex.join_device(R, S, 0), reps=2)
+    assert int(r.n_matches) == n and int(r.sum_r) == (n * (n - 1) // 2) % (1 << 64)
+    t = ex.last_timing()
+    out["scale_5e8_count_ms"] = ms
+    out["scale_5e8_plan"] = "%d bits, %s" % (t["radix_bits"], "slab path" if t["path"] & H.HMJ_PATH_SLAB else "exact path")
+    del R, S
+    torch.cuda.empty_cache()
+    # small build sides (the reference's BM_hash_join_raw formulation, hashjoin_bench.cc:29-63): one global table, probe side unpartitioned
     n = 1 << 26
+    for lb in (16, 20):
+        R, S = ex.gen_build(1 << lb), ex.gen_uniform_domain(n, 1 << lb)
+        ms, r = timed(lambda: ex.join_device(R, S, 0))
+        assert int(r.n_matches) == n
+        out["small_build_2p%d_x_2p26_count_ms" % lb] = ms
+        out["small_build_2p%d_path" % lb] = "global table" if ex.last_timing()["path"] & H.HMJ_PATH_GLOBAL_TABLE else "partitioned (%d bits)" % ex.last_timing()["radix_bits"]
+        del R, S
     R, S = ex.gen_build(n), ex.gen_probe(n, n)
     ms, r = timed(lambda: ex.join_device(R, S, 0))
     assert int(r.n_matches) == n
@@ -160,6 +179,23 @@ def extra_runs(ex, H, torch):
     out["fk_2p22_x_2p28_ordered_ms"] = ms
     ex.release_result()
     del R, Rf, Sf
+    torch.cuda.empty_cache()
+    # duplicate keys on BOTH sides (outside the reference's domain: its iterator drops matches there): 2^24 rows per side
+    # drawn from 2^21 keys, ~1.3 * 10^8 result rows in (key, rval, sval) order
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    nd = 1 << 24
+    mk = lambda: torch.stack([torch.randint(0, nd // 8, (nd,), device="cuda", generator=g, dtype=torch.int64) * 0x9E3779B97F4A7C15 % (1 << 62),
+                              torch.arange(nd, device="cuda", dtype=torch.int64)], 1).contiguous()
+    Rd, Sd = mk(), mk()
+    ms, r = timed(lambda: ex.join_device(Rd, Sd, 0), reps=2)
+    want_n = int(r.n_matches)
+    ms, r = timed(lambda: ex.join_device(Rd, Sd, H.HMJ_ORDERED), reps=2)
+    assert int(r.n_matches) == want_n
+    out["dup8_ordered_ms"] = ms
+    out["dup8_rows"] = want_n
+    ex.release_result()
+    del Rd, Sd
     torch.cuda.empty_cache()
     # configs[4]: Zipf(0.9) build side of 2^24 rows over 2^24 distinct values, probe 2^30 uniform over the domain
     nb, npb, theta = 1 << 24, 1 << 30, 0.9

@@ -932,18 +932,40 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // 16 bits partition on the slab path (32 instead of 48 B per row and pass)
     const bool wide_ok = materialize && (flags & HMJ_ORDERED) && allow_fast_write && !c->prepare_only && c->sorted_mode &&
                          c->sorted_wide && c->sorted_cooldown <= 1 && f >= 2.5;
+    bool wide_ok_override = true;
     const int B_narrow = [&] {
       int b = Bp;
       while (b < 18 && fk_probe_rows_hi((double)np_dense / (double)(1ull << b), f, (double)(1ull << b)) > 5120.0) b++;
       return b;
     }();
-    while (Bp < 18 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp), f, (double)(1ull << Bp)) > (wide_ok ? 6144.0 : 5120.0)) Bp++;
+    // ... and its small shape (512 threads, 3072 probe / 2048 build rows, TWO workgroups per CU, which overlap each
+    // other's barrier-separated LDS phases with memory) wants partitions of about half that size.  Since round 4 the
+    // slab path partitions 17 and 18 bits too (9-bit passes), so the extra bit costs 0.1-0.2 ms of partitioning instead
+    // of a fall to the exact path: 2^24 x 2^28 ordered, wide 16-bit plan 3.79 + 4.27 ms, 17-bit plan + small shape
+    // 3.93 + 3.78 ms (profiles/r04c_*).  HMJ_FK_PLAN=wide|half|narrow pins the choice (measurements).
+    const bool half_ok = materialize && (flags & HMJ_ORDERED) && allow_fast_write && !c->prepare_only && c->sorted_mode &&
+                         c->sorted_half && c->sorted_cooldown <= 1 && f >= 2.0 && c->fk_plan != 1 && c->fk_plan != 3;
+    int B_half = Bp;
+    while (B_half < 18 && fk_probe_rows_hi((double)np_dense / (double)(1ull << B_half), f, (double)(1ull << B_half)) > 3072.0) B_half++;
+    const bool half_fits = fk_probe_rows_hi((double)np_dense / (double)(1ull << B_half), f, (double)(1ull << B_half)) <= 3072.0 &&
+                           (double)nb * dense_scale / (double)(1ull << B_half) <= 1536.0;
+    // Measured (tools/exp_fk_plans.py, profiles/r04c_side_fk_plans.txt, 2^b x 2^28 ordered, ms: wide or narrow plan | half
+    // plan): b = 26 8.00 | 8.17, 25 7.65 | 7.80, 24 8.16 | 8.00, 23 8.78 | 10.76, 22 12.02 | 12.40 -- the second
+    // workgroup per CU does not pay for the extra partition bit: the write kernel is bound by its own instructions
+    // (run ranking, LDS), not by exposed memory latency.  The half plan therefore stays an option (HMJ_FK_PLAN=half).
+    const bool take_half = half_ok && half_fits && c->fk_plan == 2;
+    if (c->fk_plan == 3) wide_ok_override = false;
+    if (take_half) {
+      Bp = B_half;
+    } else {
+      while (Bp < 18 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp), f, (double)(1ull << Bp)) > ((wide_ok && wide_ok_override) ? 6144.0 : 5120.0)) Bp++;
+    }
     // count joins on the slab path: the pipelined count kernel takes a partition's rows piece by piece, a quarter of
     // its threads per piece (1280 rows); a key's f probe rows spread over the four pieces (f = 8 at 4096-row partitions
     // overflowed a piece, the join started over with probe-side slabs only: 3.9 ms against 2.7 ms, tools/exp_cliffs_fk.py)
     if (!materialize)
       while (Bp < 2 * hmj::SLAB_MAX_BITS && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
-    fk_wide_plan = wide_ok && Bp < B_narrow;
+    fk_wide_plan = wide_ok && wide_ok_override && !take_half && Bp < B_narrow;
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 2 * hmj::SLAB_MAX_BITS && slab_ok)))
       plan_bits(0, Bp, &B, &passes, pass_bits);  // the pass split of Bp bits
@@ -1667,6 +1689,8 @@ int hmj_create(hmj_ctx** out, int device_id) {
     c->sorted_chained_forced = atoi(e) == 2 || atoi(e) == 3;  // 3: never chained
   }
   if (const char* e = getenv("HMJ_SORTED_HALF")) c->sorted_half = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_FK_PLAN"))  // ordered foreign-key joins: pin the plan (1 wide, 2 half, 3 narrow; else automatic)
+    c->fk_plan = std::strcmp(e, "wide") == 0 ? 1 : std::strcmp(e, "half") == 0 ? 2 : std::strcmp(e, "narrow") == 0 ? 3 : 0;
   if (const char* e = getenv("HMJ_SORTED_WIDE")) c->sorted_wide = atoi(e) != 0;
   if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;

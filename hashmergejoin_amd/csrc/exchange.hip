@@ -1182,12 +1182,12 @@ extern "C" int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_
     const u64 per_round = std::max<u64>(1, m->target_round_bytes / 16);
     u64 nr64 = (flags & HMJ_MATERIALIZE) ? 1 : (pair_rows + per_round - 1) / per_round;
     // a round's join should keep the efficient kernels busy: with the default round size, no more rounds than give
-    // every round about 2^25 probe rows per rank (smaller joins cost more per row: 2^24 rows 0.039 ns, 2^25 0.037,
+    // every round about 2^26 probe rows per rank (smaller joins cost more per row: 2^24 rows 0.039 ns, 2^25 0.037,
     // 2^28 0.029 -- and every round costs a host round trip for its result)
     if (!m->round_bytes_set) {
       u64 total_np = 0;
       for (int g = 0; g < G; g++) total_np += smp.np[g];
-      nr64 = std::min<u64>(nr64, std::max<u64>(1, (total_np / (u64)G) >> 25));
+      nr64 = std::min<u64>(nr64, std::max<u64>(1, (total_np / (u64)G) >> 26));
     }
     nr64 = std::min<u64>(std::max<u64>(nr64, 1), HMJ_MAX_ROUNDS);
     hmj_digit_plan plan;

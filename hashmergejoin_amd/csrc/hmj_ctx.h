@@ -82,6 +82,7 @@ struct hmj_ctx {
   bool sorted_chained_forced = false;
   bool sorted_wide = true;   // HMJ_SORTED_WIDE=0: ordered foreign-key joins are never planned for the 6144-row shape
   bool sorted_half = true;   // HMJ_SORTED_HALF=0: the foreign-key form never takes its two-workgroups-per-CU shape
+  int fk_plan = 0;           // HMJ_FK_PLAN: 0 automatic, 1 wide (6144-row shape), 2 half (3072-row shape, two workgroups per CU), 3 narrow (5120 rows)
   bool sorted_fk = false;  // the last ordered join's probe keys repeated: start with the foreign-key form of the kernel
   int sorted_fk_age = 0;
   u64 probe_hint = 0;

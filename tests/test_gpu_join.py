@@ -1037,6 +1037,43 @@ def test_slab_path_parity_and_fallback(ex_fresh, H, oracle):
     assert t["ms_hist"] > 0.0  # the exact path produced this result
 
 
+@pytest.mark.parametrize("bits", [17, 18])
+def test_nine_bit_slab_passes_against_the_oracle(ex_fresh, H, oracle, bits):
+    # Joins beyond 2^28 * 1.06 rows plan 17 (9 + 8) and 18 (9 + 9) bits; the histogram-free slab kernels run 9-bit
+    # digits in a shape of their own (1024 threads, 4096-row tiles, 512 carry lines, one workgroup per CU).  The oracle
+    # cannot check 5 * 10^8 rows in seconds (test_full_size_closed_form[29-None] does that through closed forms), so the
+    # same plans are forced onto relations it can: every mode, ragged sizes, unmatched rows, duplicate build keys
+    # (first-wins = first in input order: the 9-bit passes must be stable too).
+    ex = ex_fresh
+    ex.set_radix_bits(bits)
+    try:
+        for nb, npb, miss, dup in [(1 << 22, 1 << 22, 0, 0), ((1 << 22) + 12345, 4500000 - 777, 3, 0), ((1 << 22) + 555, (1 << 22) + 11, 4, 5)]:
+            B = oracle.gen_build(nb)
+            if dup:
+                m = len(B[dup - 2::dup])
+                B[dup - 2::dup, 0] = B[0::dup, 0][:m]
+            P = oracle.gen_probe(npb, nb, miss_mod=miss)
+            Bd, Pd = to_dev(B), to_dev(P)
+            for fl in (0, H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE):
+                ck, _ = oracle.equijoin(B, P, first_wins=bool(fl & H.HMJ_FIRST_WINS), cap=0)
+                ex.set_profiling(True)
+                r = ex.join_device(Bd, Pd, fl)
+                t = ex.last_timing()
+                ex.set_profiling(False)
+                assert t["radix_bits"] == bits and t["path"] & H.HMJ_PATH_SLAB and t["ms_hist"] == 0.0, (bits, fl, t)
+                assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (bits, nb, fl)
+                if fl & H.HMJ_CHECKSUM:
+                    assert r.checks() == ck and int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+            if not dup:  # the operator's own mode on the same plan (unique-key write on the slab layout)
+                ck, rows = oracle.equijoin(B, P)
+                r = ex.join_device(Bd, Pd, H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+                assert r.checks() == ck and ex.last_timing()["radix_bits"] == bits
+                assert np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+                ex.release_result()
+    finally:
+        ex.set_radix_bits(None)
+
+
 def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
     # A build side small enough for ONE cache-resident hash table is not radix-partitioned at all: the probe side is
     # streamed once against a global open-addressing table (csrc/gtable.hip; the reference's own BM_hash_join_raw
