@@ -1516,6 +1516,17 @@ __global__ __launch_bounds__(1024) void scan_u64_kernel(const u64* __restrict__ 
 // copy A -> B, then a bitonic network on the global columns ("all ascending" form, no padding).
 constexpr int OS_THREADS = 1024, OS_ROWS = 5, OS_CAP = OS_THREADS * OS_ROWS, OS_LOGB = 12;
 constexpr int OS_NB = 1 << OS_LOGB, OS_MAXBUCKET = 48;
+// MANY (more result rows than twice the build rows: keys repeat on the probe side, or on both): a key's rows share
+// their bucket, so buckets of f_build x f_probe rows are the normal case, not a sign of trouble -- 8 copies of every
+// key on both sides make 64-row buckets, which the 48-row limit sent to the one-workgroup bitonic network in global
+// memory (2^24 x 2^24 rows of 2^21 keys, ordered: 116 ms for 1.3 * 10^8 rows against 3.1 ms unordered).  The
+// in-bucket ranking is linear in the bucket, which stays cheap up to a few hundred rows.
+constexpr int OS_MAXBUCKET_MANY = 640;
+template <bool MANY>
+struct OrderLimits {
+  static constexpr u32 MAXBUCKET = MANY ? OS_MAXBUCKET_MANY : OS_MAXBUCKET;
+  static constexpr u32 CHUNK_ROWS = OS_CAP - MAXBUCKET;  // a chunk = the buckets that START inside one such window
+};
 
 struct OrderSmem {
   u64 stage[OS_CAP];  // the segment's three columns: unsorted while ranking (rows of one key are ranked on
@@ -1624,7 +1635,7 @@ __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const
       sum += c[q];
       mx = c[q] > mx ? c[q] : mx;
     }
-    if (mx > OS_MAXBUCKET) sm.fallback = 1;
+    if (mx > OrderLimits<MANY>::MAXBUCKET) sm.fallback = 1;
     u32 tot;
     u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
 #pragma unroll
@@ -1709,7 +1720,6 @@ __device__ __forceinline__ bool order_sort_registers(OrderSmem& sm, u32 L, const
 //                            at most OS_CAP rows, and every chunk is gathered from the segment and sorted in
 //                            LDS -- the segment's keys are re-read once per chunk;
 //   otherwise, or when one bucket holds more than OS_MAXBUCKET rows: the global bitonic network.
-constexpr u32 OS_CHUNK_ROWS = OS_CAP - OS_MAXBUCKET;  // a chunk = the buckets that START inside one such window
 constexpr u32 OS_CHUNKS = 16;
 
 template <bool MANY>
@@ -1723,6 +1733,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
   OrderSmem& sm = *reinterpret_cast<OrderSmem*>(smem_raw);
   const int tid = threadIdx.x;
   const int bsh = low - OS_LOGB;  // bucket = key bits [low-12, low)
+  constexpr u32 OS_CHUNK_ROWS = OrderLimits<MANY>::CHUNK_ROWS;
   OrderBuckets bf_key;
   bf_key.by_sval = 0;
   bf_key.bsh = bsh;
@@ -1801,7 +1812,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void order_kernel(
             sum += c[q];
             mx = c[q] > mx ? c[q] : mx;
           }
-          if (mx > OS_MAXBUCKET) sm.fallback = 1;
+          if (mx > OrderLimits<MANY>::MAXBUCKET) sm.fallback = 1;
           u32 tot;
           u32 ex = block_excl_scan_u32<OS_THREADS>(sum, sm.scratch, &tot);
 #pragma unroll
