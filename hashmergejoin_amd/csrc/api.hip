@@ -1879,13 +1879,32 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
   plan_bits(n_build, c->force_bits, &B, &passes, pass_bits);
   const size_t P = (size_t)1 << B;
   const size_t items = P < 4096 ? 4096 : P;
-  if (passes >= 1) {
+  // which partitioning path joins of these sizes take: the histogram-free slab path needs its slabs and nothing of the
+  // exact path's ping-pong buffers (4 x 4.5 GB at 2^28 rows, which round 3 reserved -- and probed -- for nothing; a join
+  // that falls back to the exact path on skewed keys creates them then)
+  hmj::SlabGeom gr, gs;
+  const bool count_mode = !(flags & (HMJ_MATERIALIZE | HMJ_ORDERED));
+  const bool slab_plan = c->slab_mode && passes == 2 && pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS &&
+                         slab_sizes_ok(c, n_build, n_probe, !count_mode) &&
+                         hmj::slab_geometry((u32)n_build, pass_bits[0], pass_bits[1], &gr) &&
+                         hmj::slab_geometry((u32)n_probe, pass_bits[0], pass_bits[1], &gs);
+  if (passes >= 1 && !slab_plan) {
     if ((rc = ensure_dev(c, c->rbuf[0], n_build * 16)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->sbuf[0], n_probe * 16)) != HMJ_OK) return rc;
   }
-  if (passes >= 2) {
+  if (passes >= 2 && !slab_plan) {
     if ((rc = ensure_dev(c, c->rbuf[1], n_build * 16)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->sbuf[1], n_probe * 16)) != HMJ_OK) return rc;
+  }
+  if (slab_plan) {
+    const u64 rows_a = gr.rows_a > gs.rows_a ? gr.rows_a : gs.rows_a;
+    const u32 wa = gr.WA > gs.WA ? gr.WA : gs.WA;
+    if ((rc = ensure_dev(c, c->slab_a, rows_a * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_a, ((size_t)wa << pass_bits[0]) * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->slab_br, gr.rows_b * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->slab_bs, gs.rows_b * 16)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_br, P * gr.KB * 4)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->cnt_bs, P * gs.KB * 4)) != HMJ_OK) return rc;
   }
   if ((rc = ensure_dev(c, c->hist, (size_t)hmj::RP_MAXD * hmj::RP_MAX_BLOCKS * 4)) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->totals, (size_t)hmj::RP_MAXD * 4)) != HMJ_OK) return rc;
@@ -1903,20 +1922,6 @@ int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_mat
       if ((rc = ensure_dev(c, c->ord_key, max_matches * 8)) != HMJ_OK) return rc;
       if ((rc = ensure_dev(c, c->ord_rval, max_matches * 8)) != HMJ_OK) return rc;
       if ((rc = ensure_dev(c, c->ord_sval, max_matches * 8)) != HMJ_OK) return rc;
-    }
-  } else if (c->slab_mode && passes == 2 && pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS) {
-    hmj::SlabGeom gr, gs;  // plain count joins of large relations take the slab path
-    if (slab_sizes_ok(c, n_build, n_probe) &&
-        hmj::slab_geometry((u32)n_build, pass_bits[0], pass_bits[1], &gr) &&
-        hmj::slab_geometry((u32)n_probe, pass_bits[0], pass_bits[1], &gs)) {
-      const u64 rows_a = gr.rows_a > gs.rows_a ? gr.rows_a : gs.rows_a;
-      const u32 wa = gr.WA > gs.WA ? gr.WA : gs.WA;
-      if ((rc = ensure_dev(c, c->slab_a, rows_a * 16)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->cnt_a, ((size_t)wa << pass_bits[0]) * 4)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->slab_br, gr.rows_b * 16)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->slab_bs, gs.rows_b * 16)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->cnt_br, P * gr.KB * 4)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->cnt_bs, P * gs.KB * 4)) != HMJ_OK) return rc;
     }
   }
   return HMJ_OK;
