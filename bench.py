@@ -129,7 +129,10 @@ def extra_runs(ex, H, torch):
         ms, r = timed(lambda: ex.join_device(R, S, 0))
         assert int(r.n_matches) == n
         out["small_build_2p%d_x_2p26_count_ms" % lb] = ms
-        out["small_build_2p%d_path" % lb] = "global table" if ex.last_timing()["path"] & H.HMJ_PATH_GLOBAL_TABLE else "partitioned (%d bits)" % ex.last_timing()["radix_bits"]
+        tp = ex.last_timing()
+        out["small_build_2p%d_path" % lb] = ("global table, probe side unpartitioned" if tp["path"] & H.HMJ_PATH_GLOBAL_TABLE else
+                                              "one %d-bit slab pass over the probe side, its slabs probed in place" % tp["radix_bits"]
+                                              if tp["path"] & H.HMJ_PATH_SLAB_ONE_PASS else "partitioned (%d bits)" % tp["radix_bits"])
         del R, S
     R, S = ex.gen_build(n), ex.gen_probe(n, n)
     ms, r = timed(lambda: ex.join_device(R, S, 0))

@@ -819,6 +819,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // slab cool-down that ran out in between must not make the join partition the build side a second time)
   if (!c->prepare_only && c->prep.valid && !c->prep.slab && c->prep.ptr == R && c->prep.n == nb) allow_slab = false;
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;  // before the plan: one decision per join
+  if (c->slab_probe_cooldown > 0 && allow_slab_probe) c->slab_probe_cooldown--;  // (likewise: the plan below asks about it)
 
   int B, passes, pass_bits[4];
   bool fk_wide_plan = false;  // the plan relies on the wide shape of the one-pass ordered write (foreign-key form)
@@ -967,7 +968,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       while (Bp < 2 * hmj::SLAB_MAX_BITS && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
     fk_wide_plan = wide_ok && wide_ok_override && !take_half && Bp < B_narrow;
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
-    if (Bp > B && ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 2 * hmj::SLAB_MAX_BITS && slab_ok)))
+    // (count joins whose build-side plan is ONE pass keep it when the probe side can stay in that pass's slabs -- the
+    //  one-pass slab path below: 2^21 x 2^28 rows, 18-bit probe-side plan 7.0 ms, 9-bit build-side plan 2.9 ms)
+    const bool one_pass_count = !materialize && !first && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
+                                c->slab_probe_cooldown == 0 && !c->prepare_only && np_plan >= (1u << 22) && (u64)np_plan >= 8ull * nb;
+    if (Bp > B && !one_pass_count &&
+        ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 2 * hmj::SLAB_MAX_BITS && slab_ok)))
       plan_bits(0, Bp, &B, &passes, pass_bits);  // the pass split of Bp bits
   }
   const u32 P = 1u << B;
@@ -1242,7 +1248,6 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     hmj::SlabGeom gp;
     // 2^bits_a * KB >= 512 pass-B workers (HMJ_SLAB_PROBE_KB: any piece count, for the bounds regression tests)
     const u32 kb = c->slab_probe_kb ? c->slab_probe_kb : (pass_bits[0] < 7 ? (512u >> pass_bits[0]) : 4u);
-    if (c->slab_probe_cooldown > 0 && allow_slab_probe) c->slab_probe_cooldown--;
     if (allow_slab_probe && c->slab_mode && c->slab_probe_cooldown == 0 && !materialize && !probe_fits && Q == 1 && passes == 2 &&
         pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS && np >= c->slab_min_rows && (u64)np >= 4ull * nb &&
         hmj::slab_geometry(np, pass_bits[0], pass_bits[1], &gp, kb, (double)np / (double)(nb ? nb : 1))) {  // (a foreign-key
@@ -1289,6 +1294,64 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // a probe slab overflowed (skewed probe keys)
+        c->slab_probe_cooldown = 8;
+        return kRetryNoSlabProbe;
+      }
+      out->n_matches = hh[hmj::ACC_N];
+      out->sum_r = hh[hmj::ACC_SUM_R];
+      out->sum_s = hh[hmj::ACC_SUM_S];
+      out->xor_fold = hh[hmj::ACC_XOR];
+      out->mix_sum = hh[hmj::ACC_MIX];
+      out->sum_probe_all = hh[hmj::ACC_SUM_P];
+      return HMJ_OK;
+    }
+  }
+  // ---- count joins of a mid-size build side (2^18 ... 2^20 rows: ONE radix pass, too big for the global table of
+  // gtable.hip) with a probe side several times larger -- a dimension table under a fact table.  The exact path costs the
+  // probe side 16 (histogram) + 32 (scatter) + 16 (probe) bytes per row.  Here its one pass is the histogram-free slab
+  // pass A (32 B), and the generic kernel reads a partition straight out of the pass's worker-private slabs: partition p =
+  // the WA pieces [p][0 .. WA), an item = (partition, a run of pieces), a wave per piece.  48 instead of 64 B per row.
+  if (allow_slab_probe && c->slab_mode && c->one_pass_slab && c->slab_probe_cooldown == 0 && !materialize && !first && passes == 1 &&
+      B >= 5 && B <= hmj::SLAB_MAX_BITS && np >= (1u << 22) && (u64)np >= 8ull * nb && nb > 0) {
+    hmj::SlabGeom g1;
+    if (hmj::slab_geometry_one_pass(np, B, dense_scale * (double)nb / (double)P, 512, &g1)) {
+      if ((rc = ensure_dev(c, c->slab_a, g1.rows_a * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_a, ((size_t)g1.WA << B) * 4)) != HMJ_OK) return rc;
+      u64* acc = (u64*)c->accum.p;
+      int sp = span_begin(c, K_SCATTER, 1, 0);
+      HIP_TRY(hmj::launch_slab_a(S, np, low, B, g1, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->stream));
+      span_end(c, sp);
+      c->timing.bytes_scatter += 32ull * np;
+      c->timing.path |= HMJ_PATH_SLAB_PROBE | HMJ_PATH_SLAB_ONE_PASS;
+      // items: about eight per CU; an item walks ppi of its partition's WA pieces
+      u32 qi = 2048u / P;
+      if (qi < 1) qi = 1;
+      if (qi > g1.WA) qi = g1.WA;
+      const u32 ppi = (g1.WA + qi - 1) / qi;
+      qi = (g1.WA + ppi - 1) / ppi;
+      hmj::ProbeArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.R = Rp;
+      a.r_off = (const u32*)c->r_off.p;
+      a.S = c->slab_a.p;
+      a.s_cnt = (const u32*)c->cnt_a.p;
+      a.s_cap = g1.CA;
+      a.s_wa = g1.WA;
+      a.s_ppi = ppi;
+      a.s_cnt_n = c->cnt_a.cap / 4;
+      a.s_rows = c->slab_a.cap / 16;
+      a.P = P;
+      a.Q = qi;
+      a.accum = acc;
+      c->timing.n_probe_items = P * qi;
+      sp = span_begin(c, K_PROBE_COUNT, -1);
+      HIP_TRY(hmj::launch_probe(a, 0, false, extra, hmj::probe_default_grid(c->num_cus) * 2, c->stream));
+      span_end(c, sp);
+      c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
+      u64* hh = (u64*)c->h_accum.p;
+      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // a slab overflowed (skewed probe keys): the exact path, and not again for a while
         c->slab_probe_cooldown = 8;
         return kRetryNoSlabProbe;
       }
@@ -1659,6 +1722,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   hmj_ctx* c = new hmj_ctx();
   c->device = device_id;
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
+  if (const char* e = getenv("HMJ_ONE_PASS_SLAB")) c->one_pass_slab = atoi(e) != 0;  // 0: mid-size build sides keep the exact one-pass plan
   if (const char* e = getenv("HMJ_GTABLE")) c->gtable_mode = atoi(e) != 0;  // 0: small build sides are partitioned too
   if (const char* e = getenv("HMJ_GTABLE_MAX_LOG2")) {
     const int l = atoi(e);

@@ -116,6 +116,7 @@ struct hmj_ctx {
   int exact_prefix_joins = 0;  // ordered joins that still take the shared key prefix from a pass over ALL keys: the
                                // sample of an earlier join missed a few keys above an otherwise dense range
   u32 slab_probe_kb = 0;  // HMJ_SLAB_PROBE_KB: pieces per partition of the probe-side slabs (0 = 512 >> bits of pass A)
+  bool one_pass_slab = true;  // HMJ_ONE_PASS_SLAB=0: count joins of a one-pass plan never leave the probe side in pass-A slabs
   int slab_probe_cooldown = 0;  // the same for the probe-side-only slab partitioning of probe-heavy count joins
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;

@@ -57,6 +57,9 @@ struct SlabGeom {
 // fan: expected rows per distinct key (>= 1): widens the slabs by sqrt(fan) standard deviations
 // density: the populated partitions hold this many times the mean (keys that fill only part of the key range)
 bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb = 0, double fan = 1.0, double density = 1.0);
+// one slab pass only (its worker-private slabs are what the probe kernel reads): workers, rows per worker, slab capacity.
+// keys_per_digit: distinct keys a digit holds on average (the digit's share of a worker's rows varies with it)
+bool slab_geometry_one_pass(u32 n, int bits, double keys_per_digit, u32 max_workers, SlabGeom* g);
 // slab_*_rows / cnt_*_n: what the caller ALLOCATED (rows of 16 bytes, u32 entries).  The launchers compare them with
 // what the kernel and its grid will touch for this geometry and refuse (hipErrorInvalidValue) instead of launching
 // a kernel that would write past a buffer.
@@ -92,6 +95,8 @@ struct ProbeArgs {
   const u32* r_cnt;
   const u32* s_cnt;
   u32 r_cap, s_cap;
+  u32 s_wa, s_ppi;         // generic kernel, probe side after ONE slab pass: partition p = pieces [p * s_wa, (p + 1) * s_wa), item
+                           // (p, q) walks s_ppi of them (s_ppi == 0: off); count modes without first-wins
   u64 r_cnt_n, s_cnt_n;    // slab layout: u32 entries allocated behind r_cnt / s_cnt, rows allocated behind R / S --
   u64 r_rows, s_rows;      // checked by the launchers against P * pieces (* cap) before a kernel runs
   const u64* item_base;    // unique-key write mode, slab layout: first output slot of partition p

@@ -89,7 +89,16 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
     const u32 p = (u32)(w / a.Q), q = (u32)(w % a.Q);
     const u32 rb = a.r_off[p], nb = (a.r_end ? a.r_end[p] : a.r_off[p + 1]) - rb;
     u32 sb, np;  // this item's slice of partition p's probe rows
-    if (a.s_cnt) {  // probe side in the slab layout (radix.hip): slice q is the partition's q-th piece
+    // probe side left in the worker-private slabs of ONE slab pass (round 4, count modes): partition p is its s_wa pieces
+    // (one per pass-A worker: count s_cnt[p * s_wa + j], rows [(p * s_wa + j) * s_cap, ...)), item (p, q) takes s_ppi of them
+    u32 npieces = 0;
+    u64 piece0 = 0;
+    if (a.s_ppi) {
+      piece0 = (u64)p * a.s_wa + (u64)q * a.s_ppi;
+      npieces = a.s_wa - q * a.s_ppi < a.s_ppi ? a.s_wa - q * a.s_ppi : a.s_ppi;
+      sb = 0;
+      np = 1;  // (unknown without summing the piece counts; "some" is all the code below needs)
+    } else if (a.s_cnt) {  // probe side in the slab layout (radix.hip): slice q is the partition's q-th piece
       sb = (u32)w * a.s_cap;
       np = a.s_cnt[w];
     } else {
@@ -99,7 +108,13 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
       np = hi - lo;
     }
     if (nb == 0 || np == 0) {
-      if (EXTRA && MODE != 2)
+      if (EXTRA && MODE != 2 && npieces) {
+        for (u32 pi = 0; pi < npieces; pi++) {
+          const u32 cnt = a.s_cnt[piece0 + pi];
+          const Tup* __restrict__ base = S + (piece0 + pi) * a.s_cap;
+          for (u32 j = tid; j < cnt; j += PB_THREADS) acc_p += base[j].val;
+        }
+      } else if (EXTRA && MODE != 2)
         for (u32 j = tid; j < np; j += PB_THREADS) acc_p += S[sb + j].val;
       if (MODE == 1 && tid == 0) a.part_count[w] = 0;
       continue;
@@ -204,18 +219,9 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
 
       // ---- probe
       if (MODE != 2) {
-        for (u32 j0 = 0; j0 < np; j0 += PB_THREADS * 4) {
-          Tup t[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            u32 j = j0 + k * PB_THREADS + tid;
-            if (j < np) t[k] = S[(u64)sb + j];
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            u32 j = j0 + k * PB_THREADS + tid;
-            if (j < np) {
-              const u64 key = t[k].key, sval = t[k].val;
+        // one probe row against the table (row: its index in the probe relation -- first-wins' bitmap of paired rows)
+        auto probe_row = [&](const Tup& tr, u32 row) __attribute__((always_inline)) {
+              const u64 key = tr.key, sval = tr.val;
               if (a.pfx_shift && (key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
               if (EXTRA && first_table) acc_p += sval;
               u32 i = sm.head[tab_hash(key)];
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
                   } while (i != NIL);
                 }
               }
-              if (FIRST && hit && first_claim(a.matched, multi, sb + j)) {
+              if (FIRST && hit && first_claim(a.matched, multi, row)) {
                 const u64 rval = R[(u64)rb + best].val;  // the row itself is not kept in LDS
                 pc++;
                 acc_r += rval;
@@ -257,8 +263,48 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
                   acc_m += m;
                 }
               }
+        };
+        if (npieces) {
+          // a wave per piece (pieces are a few hundred to a few thousand contiguous rows), eight rows per lane in flight.
+          // The piece counts come in 64 at a time, one per lane (a count read per piece put a dependent global load --
+          // a microsecond -- in front of every few hundred rows), and are handed out by readlane.
+          constexpr u32 NW = PB_THREADS / kWave, PR = 8;
+          const u32 wv = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
+          for (u32 pb = 0; pb < npieces; pb += kWave) {
+            const u32 cnt_l = pb + (u32)lane < npieces ? a.s_cnt[piece0 + pb + lane] : 0u;
+            const u32 pe = npieces - pb < (u32)kWave ? npieces - pb : (u32)kWave;
+            for (u32 pi = wv; pi < pe; pi += NW) {
+              const u32 cnt = (u32)__builtin_amdgcn_readlane((int)cnt_l, (int)pi);
+              const Tup* __restrict__ base = S + (piece0 + pb + pi) * a.s_cap;
+              for (u32 j0 = 0; j0 < cnt; j0 += kWave * PR) {
+                Tup t[PR];
+#pragma unroll
+                for (int k = 0; k < (int)PR; k++) {
+                  const u32 j = j0 + k * kWave + lane;
+                  t[k] = load_stream(&base[j < cnt ? j : cnt - 1]);  // (clamped, unpredicated: the loads issue back to back)
+                }
+#pragma unroll
+                for (int k = 0; k < (int)PR; k++) {
+                  const u32 j = j0 + k * kWave + lane;
+                  if (j < cnt) probe_row(t[k], 0u);
+                }
+              }
             }
           }
+        } else {
+        for (u32 j0 = 0; j0 < np; j0 += PB_THREADS * 4) {
+          Tup t[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            u32 j = j0 + k * PB_THREADS + tid;
+            if (j < np) t[k] = S[(u64)sb + j];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            u32 j = j0 + k * PB_THREADS + tid;
+            if (j < np) probe_row(t[k], sb + j);
+          }
+        }
         }
       } else {
         for (u32 j0 = 0; j0 < np; j0 += PB_THREADS) {
@@ -2158,7 +2204,11 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
   if (!a.item_list && (u64)grid > (u64)a.P * a.Q) grid = (int)((u64)a.P * a.Q);
   if (grid < 1) grid = 1;
   // probe side in slabs (probe-heavy count joins): item w = p * Q + q is piece w -- count w, rows [w * cap, + count)
-  if (a.s_cnt && (a.s_cnt_n < (u64)a.P * a.Q || a.s_rows < (u64)a.P * a.Q * a.s_cap || (u64)a.P * a.Q * a.s_cap > 0xFFFFFFFFull))
+  if (a.s_ppi) {  // pieces of one slab pass: P * s_wa pieces, Q items of s_ppi pieces cover a partition's s_wa
+    if (!a.s_cnt || mode != 0 || first_wins || a.s_wa == 0 || (u64)a.Q * a.s_ppi < a.s_wa || (u64)(a.Q - 1) * a.s_ppi >= a.s_wa ||
+        a.s_cnt_n < (u64)a.P * a.s_wa || a.s_rows < (u64)a.P * a.s_wa * a.s_cap)
+      return hipErrorInvalidValue;
+  } else if (a.s_cnt && (a.s_cnt_n < (u64)a.P * a.Q || a.s_rows < (u64)a.P * a.Q * a.s_cap || (u64)a.P * a.Q * a.s_cap > 0xFFFFFFFFull))
     return hipErrorInvalidValue;
 #define HMJ_DISPATCH(M)                                                          \
   if (first_wins)                                                                \

@@ -1301,6 +1301,28 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fa
   return rows_a < 0xFFFFFFF0ull && rows_b < 0xFFFFFFF0ull;
 }
 
+// One slab pass whose worker-private slabs the probe kernel reads directly (probe_kernel's piece walk).  A worker's m rows
+// fall into digit d with probability p_d = (keys of d) / (all keys); p_d varies over the digits like a Poisson count of
+// keys_per_digit, so a slab's row count has variance mean + mean^2 / keys_per_digit (sampling noise + key-count noise) --
+// NOT fan-out x mean, which is the spread of a digit's rows over the WHOLE relation.
+bool slab_geometry_one_pass(u32 n, int bits, double keys_per_digit, u32 max_workers, SlabGeom* g) {
+  if (bits < 1 || bits > SLAB_MAX_BITS || max_workers == 0) return false;
+  const u32 tile = bits > 8 ? 4096 : 2048;
+  const u64 tiles = ((u64)n + tile - 1) / tile;
+  u64 tpw = (tiles + max_workers - 1) / max_workers;
+  if (tpw == 0) tpw = 1;
+  g->WA = (u32)((tiles + tpw - 1) / tpw);
+  g->rpw = (u32)(tpw * tile);
+  g->KB = 0;
+  g->CB = 0;
+  g->rows_b = 0;
+  const double mean = (double)g->rpw / (double)(1u << bits);
+  if (keys_per_digit < 1.0) keys_per_digit = 1.0;
+  g->CA = slab_cap(mean, 1.0 + mean / keys_per_digit);
+  g->rows_a = (u64)(1u << bits) * g->WA * g->CA;
+  return g->WA >= 1 && g->rows_a < 0xFFFFFFF0ull;
+}
+
 // workers [w_begin, w_end) of the pass (default: all): worker w reads input rows [w * g.rpw, (w + 1) * g.rpw)
 hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows,
                          u32* cnt_a, u64 cnt_a_n, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {

@@ -1074,6 +1074,45 @@ def test_nine_bit_slab_passes_against_the_oracle(ex_fresh, H, oracle, bits):
         ex.set_radix_bits(None)
 
 
+def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
+    # A dimension table of 2^18 ... 2^20 rows under a fact table several times larger, count modes: ONE radix pass, and the
+    # probe side's pass is the histogram-free slab pass A whose worker-private slabs the generic probe kernel walks piece
+    # by piece (HMJ_PATH_SLAB_ONE_PASS; 48 instead of 64 B per probe row).  Against the oracle: foreign-key probe sides,
+    # unmatched rows, duplicate build keys (aggregating and enumerating tables), ragged sizes; first-wins and materialising
+    # joins keep the exact plan; a hot probe key overflows a slab and the join falls back with the same answer.
+    ex = ex_fresh
+    ONE = H.HMJ_PATH_SLAB_ONE_PASS
+    for nb, npb, miss, dup in [(300000, (1 << 22) + 777, 0, 0), (262145, 4500000, 3, 0), (600000, 5000000 - 3, 4, 6), (1 << 20, 9000001, 0, 0)]:
+        B = oracle.gen_build(nb)
+        if dup:
+            m = len(B[dup - 1::dup])
+            B[dup - 1::dup, 0] = B[0::dup, 0][:m]
+        P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
+        Bd, Pd = to_dev(B), to_dev(P)
+        for fl in (0, H.HMJ_CHECKSUM, H.HMJ_SUM_PROBE, H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE):
+            ck, _ = oracle.equijoin(B, P, cap=0)
+            ex.set_profiling(True)
+            r = ex.join_device(Bd, Pd, fl)
+            t = ex.last_timing()
+            ex.set_profiling(False)
+            assert t["path"] & ONE and t["radix_passes"] == 1 and t["n_scatter_launches"] == 2, (nb, npb, fl, hex(t["path"]), t)
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck, (nb, npb, fl)
+            if fl & H.HMJ_SUM_PROBE:
+                assert int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+        ckf, _ = oracle.equijoin(B, P, first_wins=True, cap=0)
+        r = ex.join_device(Bd, Pd, H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM)
+        assert not ex.last_timing()["path"] & ONE and r.checks() == ckf
+    # a hot foreign key: half of the probe rows carry one key -> one digit's slabs overflow -> exact path, same answer
+    nb, npb = 300000, 1 << 22
+    B, P = oracle.gen_build(nb), oracle.gen_uniform_domain(npb, nb)
+    P[::2, 0] = B[12345, 0]
+    ck, _ = oracle.equijoin(B, P, cap=0)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
+    assert r.checks() == ck and not ex.last_timing()["path"] & ONE
+
+
 def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
     # A build side small enough for ONE cache-resident hash table is not radix-partitioned at all: the probe side is
     # streamed once against a global open-addressing table (csrc/gtable.hip; the reference's own BM_hash_join_raw
