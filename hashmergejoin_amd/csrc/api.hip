@@ -970,7 +970,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     // (count joins whose build-side plan is ONE pass keep it when the probe side can stay in that pass's slabs -- the
     //  one-pass slab path below: 2^21 x 2^28 rows, 18-bit probe-side plan 7.0 ms, 9-bit build-side plan 2.9 ms)
-    const bool one_pass_count = !materialize && !first && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
+    const bool one_pass_count = !materialize && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
                                 c->slab_probe_cooldown == 0 && !c->prepare_only && np_plan >= (1u << 22) && (u64)np_plan >= 8ull * nb;
     if (Bp > B && !one_pass_count &&
         ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 2 * hmj::SLAB_MAX_BITS && slab_ok)))
@@ -1311,7 +1311,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // probe side 16 (histogram) + 32 (scatter) + 16 (probe) bytes per row.  Here its one pass is the histogram-free slab
   // pass A (32 B), and the generic kernel reads a partition straight out of the pass's worker-private slabs: partition p =
   // the WA pieces [p][0 .. WA), an item = (partition, a run of pieces), a wave per piece.  48 instead of 64 B per row.
-  if (allow_slab_probe && c->slab_mode && c->one_pass_slab && c->slab_probe_cooldown == 0 && !materialize && !first && passes == 1 &&
+  if (allow_slab_probe && c->slab_mode && c->one_pass_slab && c->slab_probe_cooldown == 0 && !materialize && passes == 1 &&
       B >= 5 && B <= hmj::SLAB_MAX_BITS && np >= (1u << 22) && (u64)np >= 8ull * nb && nb > 0) {
     hmj::SlabGeom g1;
     if (hmj::slab_geometry_one_pass(np, B, dense_scale * (double)nb / (double)P, 512, &g1)) {
@@ -1344,8 +1344,14 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       a.Q = qi;
       a.accum = acc;
       c->timing.n_probe_items = P * qi;
+      if (first) {  // one bit per probe row SLOT of the slab buffer (used where a build partition needs several tables)
+        const size_t mb = ((size_t)g1.rows_a / 32 + 1) * 4;
+        if ((rc = ensure_dev(c, c->matched, mb)) != HMJ_OK) return rc;
+        a.matched = (u32*)c->matched.p;
+        HIP_TRY(hipMemsetAsync(c->matched.p, 0, mb, c->stream));
+      }
       sp = span_begin(c, K_PROBE_COUNT, -1);
-      HIP_TRY(hmj::launch_probe(a, 0, false, extra, hmj::probe_default_grid(c->num_cus) * 2, c->stream));
+      HIP_TRY(hmj::launch_probe(a, 0, first, extra, hmj::probe_default_grid(c->num_cus) * 2, c->stream));
       span_end(c, sp);
       c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
       u64* hh = (u64*)c->h_accum.p;

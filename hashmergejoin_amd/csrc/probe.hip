@@ -286,7 +286,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
 #pragma unroll
                 for (int k = 0; k < (int)PR; k++) {
                   const u32 j = j0 + k * kWave + lane;
-                  if (j < cnt) probe_row(t[k], 0u);
+                  if (j < cnt) probe_row(t[k], (u32)((piece0 + pb + pi) * a.s_cap) + j);  // (row = its slot in the slab buffer: first-wins' bitmap)
                 }
               }
             }
@@ -2205,7 +2205,7 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
   if (grid < 1) grid = 1;
   // probe side in slabs (probe-heavy count joins): item w = p * Q + q is piece w -- count w, rows [w * cap, + count)
   if (a.s_ppi) {  // pieces of one slab pass: P * s_wa pieces, Q items of s_ppi pieces cover a partition's s_wa
-    if (!a.s_cnt || mode != 0 || first_wins || a.s_wa == 0 || (u64)a.Q * a.s_ppi < a.s_wa || (u64)(a.Q - 1) * a.s_ppi >= a.s_wa ||
+    if (!a.s_cnt || mode != 0 || (first_wins && !a.matched) || a.s_wa == 0 || (u64)a.P * a.s_wa * a.s_cap > 0xFFFFFFFFull || (u64)a.Q * a.s_ppi < a.s_wa || (u64)(a.Q - 1) * a.s_ppi >= a.s_wa ||
         a.s_cnt_n < (u64)a.P * a.s_wa || a.s_rows < (u64)a.P * a.s_wa * a.s_cap)
       return hipErrorInvalidValue;
   } else if (a.s_cnt && (a.s_cnt_n < (u64)a.P * a.Q || a.s_rows < (u64)a.P * a.Q * a.s_cap || (u64)a.P * a.Q * a.s_cap > 0xFFFFFFFFull))

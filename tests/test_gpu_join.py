@@ -1078,8 +1078,8 @@ def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
     # A dimension table of 2^18 ... 2^20 rows under a fact table several times larger, count modes: ONE radix pass, and the
     # probe side's pass is the histogram-free slab pass A whose worker-private slabs the generic probe kernel walks piece
     # by piece (HMJ_PATH_SLAB_ONE_PASS; 48 instead of 64 B per probe row).  Against the oracle: foreign-key probe sides,
-    # unmatched rows, duplicate build keys (aggregating and enumerating tables), ragged sizes; first-wins and materialising
-    # joins keep the exact plan; a hot probe key overflows a slab and the join falls back with the same answer.
+    # unmatched rows, duplicate build keys (aggregating and enumerating tables), ragged sizes, first-wins; materialising
+    # joins keep their plans; a hot probe key overflows a slab and the join falls back with the same answer.
     ex = ex_fresh
     ONE = H.HMJ_PATH_SLAB_ONE_PASS
     for nb, npb, miss, dup in [(300000, (1 << 22) + 777, 0, 0), (262145, 4500000, 3, 0), (600000, 5000000 - 3, 4, 6), (1 << 20, 9000001, 0, 0)]:
@@ -1101,9 +1101,20 @@ def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
                 assert r.checks() == ck, (nb, npb, fl)
             if fl & H.HMJ_SUM_PROBE:
                 assert int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+        # first-wins (the reference's partitioned loop, hashjoin_bench.cc:88-96: first insert wins, a miss adds 0) takes it too
         ckf, _ = oracle.equijoin(B, P, first_wins=True, cap=0)
-        r = ex.join_device(Bd, Pd, H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM)
-        assert not ex.last_timing()["path"] & ONE and r.checks() == ckf
+        r = ex.join_device(Bd, Pd, H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE)
+        assert ex.last_timing()["path"] & ONE and r.checks() == ckf and int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+        # ... also when a forced plan makes build partitions of several tables each (the bitmap of paired probe rows)
+        if nb == 600000:
+            ex.set_radix_bits(5)
+            try:
+                r = ex.join_device(Bd, Pd, H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM)
+                assert r.checks() == ckf and ex.last_timing()["radix_bits"] == 5
+            finally:
+                ex.set_radix_bits(None)
+        ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE)
+        assert not ex.last_timing()["path"] & ONE
     # a hot foreign key: half of the probe rows carry one key -> one digit's slabs overflow -> exact path, same answer
     nb, npb = 300000, 1 << 22
     B, P = oracle.gen_build(nb), oracle.gen_uniform_domain(npb, nb)
