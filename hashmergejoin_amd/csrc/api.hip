@@ -1326,7 +1326,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       // items: about eight per CU; an item walks ppi of its partition's WA pieces
       u32 qi = 2048u / P;
       if (qi < 1) qi = 1;
-      if (qi > g1.WA) qi = g1.WA;
+      if (qi > g1.WA / 16) qi = g1.WA / 16;  // (a wave per piece, 16 waves per workgroup: an item of fewer pieces idles some)
+      if (qi < 1) qi = 1;
       const u32 ppi = (g1.WA + qi - 1) / qi;
       qi = (g1.WA + ppi - 1) / ppi;
       hmj::ProbeArgs a;
@@ -1592,8 +1593,12 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
                      hmj_result* out, bool* done) {
   *done = false;
   if (!c->gtable_mode || (flags & (HMJ_MATERIALIZE | HMJ_ORDERED)) || c->prepare_only || c->force_bits >= 0 ||
-      !c->arrive_ev.empty() || n_build == 0 || n_build > (c->gtable_max_rows >> ((flags & HMJ_FIRST_WINS) ? 1 : 0)) || n_probe > 0xFFFFFFFFull ||
-      n_probe < c->gtable_min_probe || n_probe < (uint64_t)c->gtable_min_fanout * n_build ||
+      !c->arrive_ev.empty() || n_build == 0 || n_probe > 0xFFFFFFFFull || n_probe < c->gtable_min_probe ||
+      // big probe sides: the table must stay in an XCD's L2.  Small joins (a few hundred microseconds of dependent launches on
+      // the partitioned paths: sample + read-back, histogram, scan, scatter, offsets, probe) take it up to 2^20 build rows:
+      // 2^18 x 2^18 rows 0.124 -> 0.078 ms, tools/exp_gtable.py / profiles/r04h_sweep_build_x_probe_sizes.txt
+      (n_build > c->gtable_max_rows && !(n_build <= 8 * c->gtable_max_rows && n_build + n_probe <= 16 * c->gtable_max_rows)) ||
+      n_probe < (uint64_t)c->gtable_min_fanout * n_build ||
       (c->prep.valid && c->prep.ptr == R && c->prep.n == (u32)n_build))
     return HMJ_OK;
   if (c->gtable_cooldown > 0) {
@@ -1607,7 +1612,7 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   int log_cap = 10;
   // slots: 16 per build row while the table stays within 2^18 slots (4 MiB, an XCD's L2), never fewer than 4
   while (((u64)1 << log_cap) < (u64)c->gtable_slots_per_row * n_build) log_cap++;
-  while (log_cap > c->gtable_max_log_cap && ((u64)1 << (log_cap - 1)) >= 4 * n_build) log_cap--;
+  while (log_cap > c->gtable_max_log_cap && ((u64)1 << (log_cap - 1)) >= (n_build > c->gtable_max_rows ? 2 : 4) * n_build) log_cap--;  // (small joins of a bigger build side: 2 slots per row)
   const size_t tab_bytes = (size_t)16 << log_cap;
   if ((rc = ensure_dev(c, c->gtab, tab_bytes)) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
@@ -1734,7 +1739,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
     const int l = atoi(e);
     if (l >= 0 && l <= 28) c->gtable_max_rows = 1ull << l;
   }
-  if (const char* e = getenv("HMJ_GTABLE_FANOUT")) c->gtable_min_fanout = atoi(e) > 0 ? (u32)atoi(e) : 1u;
+  if (const char* e = getenv("HMJ_GTABLE_FANOUT")) c->gtable_min_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;
   if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char* e = getenv("HMJ_GTABLE_SLOTS")) c->gtable_slots_per_row = atoi(e) >= 2 ? (u32)atoi(e) : 2u;
   if (const char* e = getenv("HMJ_GTABLE_MAX_LOG_CAP")) c->gtable_max_log_cap = atoi(e);

@@ -93,9 +93,9 @@ struct hmj_ctx {
   // The load factor matters as much as the size (a wave walks until its longest walk ends): 16 slots per build row
   // while the table stays within 2^18 slots = 4 MiB, never fewer than 4.
   bool gtable_mode = true;         // HMJ_GTABLE=0 disables
-  uint64_t gtable_max_rows = 1ull << 17;  // build rows (HMJ_GTABLE_MAX_LOG2); HMJ_FIRST_WINS: half of it (the extra payload fetch from the build relation)
-  u32 gtable_min_fanout = 1;       // probe rows >= this x build rows (HMJ_GTABLE_FANOUT); it wins from fan-out 1 on (2^17 x 2^18: 0.125 -> 0.06 ms)
-  uint64_t gtable_min_probe = 1ull << 16;
+  uint64_t gtable_max_rows = 1ull << 17;  // build rows (HMJ_GTABLE_MAX_LOG2); 8 x that for joins of <= 16 x that many rows in all
+  u32 gtable_min_fanout = 0;       // probe rows >= this x build rows (HMJ_GTABLE_FANOUT); it wins at every fan-out (2^17 x 2^18: 0.125 -> 0.06 ms)
+  uint64_t gtable_min_probe = 1;
   int gtable_wg_per_cu = 8;        // probe grid (HMJ_GTABLE_WG)
   u32 gtable_slots_per_row = 16;   // table slots per build row (HMJ_GTABLE_SLOTS) ...
   int gtable_max_log_cap = 18;     // ... while the table has at most 2^this slots; beyond, down to 4 per row (HMJ_GTABLE_MAX_LOG_CAP)

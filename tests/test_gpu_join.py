@@ -30,6 +30,24 @@ def ex():
 
 
 @pytest.fixture(scope="module")
+def ex_part():
+    # an executor whose count joins always take the PARTITIONED paths (HMJ_GTABLE=0): tests of the planner -- key window,
+    # dense-build plan, prepared build side -- assert on the plan of small count joins, which otherwise go through the
+    # global table (round 4) and never plan anything
+    import hashmergejoin_amd as H
+
+    os.environ["HMJ_SLAB_MIN_LOG2"] = "22"
+    os.environ["HMJ_GTABLE"] = "0"
+    try:
+        e = H.Executor(0)
+    finally:
+        del os.environ["HMJ_SLAB_MIN_LOG2"]
+        del os.environ["HMJ_GTABLE"]
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
 def H():
     import hashmergejoin_amd as H
 
@@ -380,7 +398,8 @@ def test_ordered_many_to_many_uses_the_chunked_epilogue(ex, H, oracle):
         ex.release_result()
 
 
-def test_keys_with_structure_tag_gap_id(ex, H, oracle):
+def test_keys_with_structure_tag_gap_id(ex_part, H, oracle):
+    ex = ex_part
     # Keys like (tag << 61) | id: the bits right under the shared prefix are almost constant.  Unordered
     # joins partition on the id bits instead; ordered joins do the same and finish with a stable sort of the
     # rows by key.  Exact rows (duplicate build keys included), and no giant-partition slow path.
@@ -1146,10 +1165,7 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
             ck, _ = oracle.equijoin(B, P, first_wins=bool(fl & H.HMJ_FIRST_WINS), cap=0)
             r = ex.join_device(Bd, Pd, fl)
             t = ex.last_timing()
-            if fl & H.HMJ_FIRST_WINS and nb > 1 << 16:  # (first-wins fetches payloads from the build relation: half the row limit)
-                assert not t["path"] & GT
-            else:
-                assert t["path"] & GT and t["radix_passes"] == 0, (nb, npb, fl, hex(t["path"]))
+            assert t["path"] & GT and t["radix_passes"] == 0, (nb, npb, fl, hex(t["path"]))
             assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, fl)
             if fl & H.HMJ_CHECKSUM:
                 assert r.checks() == ck, (nb, npb, fl)
@@ -1159,9 +1175,14 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
         ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE)
         assert not ex.last_timing()["path"] & GT
     # a build side beyond 2^17 rows (its table would leave the L2), a forced plan: partitioned as before
-    B, P = oracle.gen_build(200000), oracle.gen_probe(800000, 200000)
+    B, P = oracle.gen_build(200000), oracle.gen_probe(4000000, 200000)
     ex.join_device(to_dev(B), to_dev(P), 0)
     assert not ex.last_timing()["path"] & GT
+    # ... unless the whole join is small (<= 2^21 rows in all): then the launch count is what matters, up to 2^20 build rows
+    B, P = oracle.gen_build(700000), oracle.gen_probe(900000, 700000, miss_mod=3)
+    ck, _ = oracle.equijoin(B, P, cap=0)
+    r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
+    assert ex.last_timing()["path"] & GT and r.checks() == ck
     B, P = oracle.gen_build(20000), oracle.gen_probe(100000, 20000)
     ex.set_radix_bits(3)
     try:
@@ -1369,12 +1390,12 @@ def test_one_pass_ordered_write_gives_up_on_clustered_keys(ex_fresh, H, oracle):
     ex.release_result()
 
 
-def test_build_keys_in_part_of_the_key_range_get_a_denser_plan(ex_fresh, H, oracle):
+def test_build_keys_in_part_of_the_key_range_get_a_denser_plan(ex_part, H, oracle):
     # build keys below 2^62 (a quarter of the range the probe keys span), evenly spread: every build partition would
     # hold four times the planned rows and overflow the LDS table.  The key sample reports the build side's range
     # and how evenly it is filled; the plan then spends two more bits (HMJ_PATH_DENSE_BUILD) and the join stays on
     # the pipelined kernels.  Clustered build keys (three tags) do not qualify.
-    ex = ex_fresh
+    ex = ex_part
     n = 600000
     B, P = oracle.gen_build(n), oracle.gen_probe(n, n, miss_mod=3)
     B[:, 0] >>= np.uint64(2)
@@ -1597,7 +1618,11 @@ def test_randomized_partition_sort_prepare_host(ex, H, oracle):
 def test_prepare_then_reserve_then_join(H, oracle):
     # hmj_reserve may regrow the buffers a prepared build side lives in; the prepared state must be
     # dropped (hmj.h: "any other call discards the prepared state"), not read back from freed memory.
-    e = H.Executor(0)
+    os.environ["HMJ_GTABLE"] = "0"  # (a join this small would otherwise take the global table and partition nothing)
+    try:
+        e = H.Executor(0)
+    finally:
+        del os.environ["HMJ_GTABLE"]
     try:
         nb, npb = 300000, 200000
         B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=4)
