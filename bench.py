@@ -129,6 +129,11 @@ def extra_runs(ex, H, torch):
         ms, r = timed(lambda: ex.join_device(R, S, 0))
         assert int(r.n_matches) == n
         out["small_build_2p%d_x_2p26_count_ms" % lb] = ms
+        if lb == 16:
+            msm, rm = timed(lambda: ex.join_device(R, S, H.HMJ_MATERIALIZE))
+            assert int(rm.n_matches) == n
+            out["small_build_2p16_x_2p26_materialize_ms"] = msm
+            ex.join_device(R, S, 0)
         tp = ex.last_timing()
         out["small_build_2p%d_path" % lb] = ("global table, probe side unpartitioned" if tp["path"] & H.HMJ_PATH_GLOBAL_TABLE else
                                               "one %d-bit slab pass over the probe side, its slabs probed in place" % tp["radix_bits"]

@@ -1590,9 +1590,16 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
 // the probe side must be big enough for the saved partitioning pass to matter -- build rows <= c->gtable_max_rows,
 // probe rows >= c->gtable_min_fanout x build rows.
 int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
-                     hmj_result* out, bool* done) {
+                     hmj_result* out, bool to_host, bool* done) {
   *done = false;
-  if (!c->gtable_mode || (flags & (HMJ_MATERIALIZE | HMJ_ORDERED)) || c->prepare_only || c->force_bits >= 0 ||
+  // (materialising joins: the unordered form only -- an ordered result needs the probe rows in key order, which IS the
+  //  partitioning -- and only while no earlier attempt met duplicate build keys: gtable_write_cooldown)
+  const bool materialize = (flags & HMJ_MATERIALIZE) != 0;
+  if (materialize && c->gtable_write_cooldown > 0) {
+    c->gtable_write_cooldown--;
+    return HMJ_OK;
+  }
+  if (!c->gtable_mode || (flags & HMJ_ORDERED) || c->prepare_only || c->force_bits >= 0 ||
       !c->arrive_ev.empty() || n_build == 0 || n_probe > 0xFFFFFFFFull || n_probe < c->gtable_min_probe ||
       // big probe sides: the table must stay in an XCD's L2.  Small joins (a few hundred microseconds of dependent launches on
       // the partitioned paths: sample + read-back, histogram, scan, scatter, offsets, probe) take it up to 2^20 build rows:
@@ -1622,19 +1629,33 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   int sp = span_begin(c, K_PROBE_COUNT, -1);
   HIP_TRY(hipMemsetAsync(c->gtab.p, 0xFF, tab_bytes, c->stream));  // every slot empty (key of all ones)
   HIP_TRY(hmj::launch_gtable_build(R, (u32)n_build, c->gtab.p, log_cap, (u64*)c->accum.p, first, c->num_cus, c->stream));
-  HIP_TRY(hmj::launch_gtable_probe(S, (u32)n_probe, c->gtab.p, log_cap, R, (u64*)c->accum.p, first, extra, c->num_cus,
-                                   c->gtable_wg_per_cu, c->stream));
+  if (materialize) {
+    const size_t bytes = (size_t)(n_probe ? n_probe : 1) * 8;  // (at most one result row per probe row)
+    if ((rc = ensure_dev(c, c->out_key, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return rc;
+    span_end(c, sp);
+    sp = span_begin(c, K_PROBE_WRITE, -1);
+    HIP_TRY(hmj::launch_gtable_write(S, (u32)n_probe, c->gtab.p, log_cap, R, (u64*)c->accum.p, (u64*)c->out_key.p,
+                                     (u64*)c->out_rval.p, (u64*)c->out_sval.p, first, extra, c->num_cus, c->gtable_wg_per_cu,
+                                     c->stream));
+  } else {
+    HIP_TRY(hmj::launch_gtable_probe(S, (u32)n_probe, c->gtab.p, log_cap, R, (u64*)c->accum.p, first, extra, c->num_cus,
+                                     c->gtable_wg_per_cu, c->stream));
+  }
   span_end(c, sp);
   u64* hh = (u64*)c->h_accum.p;
   HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) {
-    c->gtable_cooldown = 8;
+  const bool dup_write = materialize && !first && hh[hmj::ACC_PAD] != 0;  // duplicate build keys: a probe row may expand to several rows
+  if (dup_write && !(hh[hmj::ACC_ERR] & hmj::ERR_GTABLE)) c->gtable_write_cooldown = 8;
+  if ((hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) || dup_write) {
+    if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) c->gtable_cooldown = 8;
     std::vector<Span> keep;  // forget the abandoned attempt's span
     for (const Span& s2 : c->spans)
       if (s2.kind == K_TOTAL || s2.kind == K_H2D) keep.push_back(s2);
     c->spans.swap(keep);
-    if (c->trace) std::fprintf(stderr, "[hmj] join nb=%llu np=%llu: global table gave up (long walk or reserved key) -> partitioned path\n",
+    if (c->trace) std::fprintf(stderr, "[hmj] join nb=%llu np=%llu: global table gave up (long walk, reserved key, or duplicate build keys under a materialising join) -> partitioned path\n",
                                (unsigned long long)n_build, (unsigned long long)n_probe);
     return HMJ_OK;
   }
@@ -1649,8 +1670,28 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   c->timing.radix_bits = 0;
   c->timing.radix_passes = 0;
   c->timing.n_probe_items = 1;
-  c->timing.bytes_probe_count = 16ull * (n_build + n_probe);
+  if (materialize)
+    c->timing.bytes_probe_write = 16ull * (n_build + n_probe) + 24ull * out->n_matches;
+  else
+    c->timing.bytes_probe_count = 16ull * (n_build + n_probe);
   c->prep.valid = false;
+  if (materialize && out->n_matches) {
+    const size_t bytes = (size_t)out->n_matches * 8;
+    if (to_host) {
+      if ((rc = ensure_host(c, c->h_key, bytes, false)) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_rval, bytes, false)) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_sval, bytes, false)) != HMJ_OK) return rc;
+      const int s2 = span_begin(c, K_D2H, -1);
+      HIP_TRY(hipMemcpyAsync(c->h_key.p, c->out_key.p, bytes, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_rval.p, c->out_rval.p, bytes, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_sval.p, c->out_sval.p, bytes, hipMemcpyDeviceToHost, c->stream));
+      span_end(c, s2);
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    out->key = (const uint64_t*)(to_host ? c->h_key.p : c->out_key.p);
+    out->rval = (const uint64_t*)(to_host ? c->h_rval.p : c->out_rval.p);
+    out->sval = (const uint64_t*)(to_host ? c->h_sval.p : c->out_sval.p);
+  }
   if (c->trace) std::fprintf(stderr, "[hmj] join nb=%llu np=%llu flags=%#x: global table of 2^%d slots\n",
                              (unsigned long long)n_build, (unsigned long long)n_probe, flags, log_cap);
   *done = true;
@@ -1661,7 +1702,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
                 uint32_t flags, hmj_result* out, bool to_host) {
   {
     bool done = false;
-    const int rc = try_global_table(c, R, n_build, S, n_probe, flags, out, &done);
+    const int rc = try_global_table(c, R, n_build, S, n_probe, flags, out, to_host, &done);
     if (rc != HMJ_OK || done) return rc;
   }
   bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true, prefix_unsafe = false, slab_probe = true;

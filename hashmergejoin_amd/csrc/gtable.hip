@@ -164,6 +164,113 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __r
   block_accumulate(red, accum, v, 1u << ACC_XOR);
 }
 
+// Materialising form (HMJ_MATERIALIZE without HMJ_ORDERED; unique build keys, or HMJ_FIRST_WINS): every probe row has at most
+// one result row.  No count pass: a wave compacts the hits of each of its row slots with a ballot, reserves its output
+// rows with ONE atomic add per tile on the result cursor (accum[ACC_N], which ends as n_matches) and writes them as runs
+// of consecutive rows -- an unordered result is a multiset, so any placement is a valid one.  Duplicate build keys
+// without first-wins (a probe row would expand to several rows) make the kernel return at once; the host sees the build
+// kernel's flag and takes the partitioned path.
+template <bool FIRST, bool EXTRA>
+__global__ __launch_bounds__(GT_THREADS) void gtable_write_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
+                                                                   int log_cap, const Tup* __restrict__ R, u64* __restrict__ accum,
+                                                                   u64* __restrict__ out_key, u64* __restrict__ out_rval,
+                                                                   u64* __restrict__ out_sval) {
+  __shared__ u64 red[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 8) red[tid] = 0;
+  const bool dups = accum[ACC_PAD] != 0;
+  if (dups && !FIRST) return;  // (uniform for the whole grid)
+  const u32 mask = (1u << log_cap) - 1;
+  const int shift = 64 - log_cap;
+  constexpr u32 TILE = GT_THREADS * GT_ROWS;
+  u64 acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
+  for (u64 base = (u64)blockIdx.x * TILE; base < np; base += (u64)gridDim.x * TILE) {
+    Tup t[GT_ROWS];
+    u32 slot[GT_ROWS];
+    bool live[GT_ROWS];
+    u64 hitv[GT_ROWS];  // the matching build row's payload (FIRST: its index, smallest so far)
+    u32 hit = 0;        // bit r: row slot r has a match
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      const u64 i = base + (u64)r * GT_THREADS + tid;
+      const bool valid = i < np;
+      t[r] = load_stream(&S[valid ? i : (u64)np - 1]);
+      live[r] = valid;
+    }
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      slot[r] = gt_hash(t[r].key, shift);
+      hitv[r] = ~0ull;
+      if (EXTRA && live[r]) acc_p += t[r].val;
+      if (t[r].key == GT_EMPTY) live[r] = false;
+    }
+    bool any_live = false;
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) any_live |= live[r];
+    while (any_live) {
+      Tup e[GT_ROWS];
+#pragma unroll
+      for (int r = 0; r < GT_ROWS; r++)
+        if (live[r]) e[r] = tab[slot[r]];
+      any_live = false;
+#pragma unroll
+      for (int r = 0; r < GT_ROWS; r++) {
+        if (live[r]) {
+          if (e[r].key == GT_EMPTY) {
+            live[r] = false;
+          } else {
+            const bool eq = e[r].key == t[r].key;
+            if (eq) {
+              hit |= 1u << r;
+              hitv[r] = (FIRST && e[r].val > hitv[r]) ? hitv[r] : e[r].val;
+            }
+            if (eq && !dups) {
+              live[r] = false;
+            } else {
+              slot[r] = (slot[r] + 1) & mask;
+              any_live = true;
+            }
+          }
+        }
+      }
+    }
+    // this wave's output rows: slot r's hits form a run, the runs follow each other
+    u32 pre[GT_ROWS], run = 0;
+    u64 m[GT_ROWS];
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      m[r] = __ballot((hit >> r) & 1u);
+      pre[r] = run;
+      run += (u32)__popcll(m[r]);
+    }
+    u64 ob = 0;
+    if (run) {
+      if (lane == 0) ob = atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_N]), (unsigned long long)run);
+      ob = __shfl(ob, 0, kWave);
+    }
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      if ((hit >> r) & 1u) {
+        const u64 rv = FIRST ? R[hitv[r]].val : hitv[r];
+        const u64 o = ob + pre[r] + popc_below(m[r]);
+        out_key[o] = t[r].key;
+        out_rval[o] = rv;
+        out_sval[o] = t[r].val;
+        acc_r += rv;
+        acc_s += t[r].val;
+        if (EXTRA) {
+          const u64 mx = tmix(t[r].key, rv, t[r].val);
+          acc_x ^= mx;
+          acc_m += mx;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const u64 v[6] = {0, acc_r, acc_s, acc_x, acc_m, acc_p};  // (ACC_N is the output cursor: already complete)
+  block_accumulate(red, accum, v, 1u << ACC_XOR);
+}
+
 hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u64* accum, bool first, int num_cus,
                                hipStream_t st) {
   if (log_cap < 4 || log_cap > 30 || ((u64)1 << log_cap) < (u64)nb + nb / 4 + 1) return hipErrorInvalidValue;  // (load factor <= 0.8: walks must end)
@@ -195,6 +302,25 @@ hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_c
     if (extra) HMJ_GT(false, true); else HMJ_GT(false, false);
   }
 #undef HMJ_GT
+  return hipGetLastError();
+}
+
+hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_cap, const void* R, u64* accum, u64* out_key,
+                               u64* out_rval, u64* out_sval, bool first, bool extra, int num_cus, int wg_per_cu, hipStream_t st) {
+  if (log_cap < 4 || log_cap > 30 || !out_key || !out_rval || !out_sval) return hipErrorInvalidValue;
+  const u64 tiles = ((u64)np + GT_THREADS * GT_ROWS - 1) / (GT_THREADS * GT_ROWS);
+  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8);
+  if (grid > tiles) grid = tiles;
+  if (grid < 1) grid = 1;
+#define HMJ_GTW(F, E)                                                                                                  \
+  hipLaunchKernelGGL((gtable_write_kernel<F, E>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np, \
+                     static_cast<const Tup*>(tab), log_cap, static_cast<const Tup*>(R), accum, out_key, out_rval, out_sval)
+  if (first) {
+    if (extra) HMJ_GTW(true, true); else HMJ_GTW(true, false);
+  } else {
+    if (extra) HMJ_GTW(false, true); else HMJ_GTW(false, false);
+  }
+#undef HMJ_GTW
   return hipGetLastError();
 }
 

@@ -138,6 +138,10 @@ hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u6
                                hipStream_t st);
 hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_cap, const void* R, u64* accum, bool first,
                                bool extra, int num_cus, int wg_per_cu, hipStream_t st);
+// materialising form: at most one result row per probe row (unique build keys or first-wins); out_*: room for np rows;
+// accum[ACC_N] is the output cursor (zeroed by the caller, n_matches afterwards)
+hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_cap, const void* R, u64* accum, u64* out_key,
+                               u64* out_rval, u64* out_sval, bool first, bool extra, int num_cus, int wg_per_cu, hipStream_t st);
 
 // gen.hip
 hipError_t launch_gen_build(void* out, u64 n, u64 start, u64 seed, hipStream_t st);

@@ -120,7 +120,7 @@ typedef struct {
 #define HMJ_PATH_LOOKBACK_TIMEOUT 0x10000u /* a chained partition gave up waiting for its predecessor (a bug if seen) */
 #define HMJ_PATH_PRESORTED 0x40000u /* a relation arrived already partitioned (sorted by key): its radix passes were skipped */
 #define HMJ_PATH_SLAB_ONE_PASS 0x80000u /* ... of a ONE-pass plan: the probe kernel reads the pass's worker-private slabs directly */
-#define HMJ_PATH_GLOBAL_TABLE 0x20000u /* small build side: one global hash table, the probe side streamed unpartitioned */
+#define HMJ_PATH_GLOBAL_TABLE 0x100000u /* small build side: one global hash table, the probe side streamed unpartitioned */
 #define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -193,7 +193,14 @@ const char* hmj_version(void);
  * hashjoin_bench.cc:126-133), and equally the partition_only + partitioned_hash_table + probe loop
  * of hashjoin_bench.cc:88-96 (partitioned_hash.h:82-124, :173-215).
  * Inputs are device-resident, borrowed, read-only, not retained after return.  Blocking: on
- * return `out` is filled and the result columns are complete on the stream.                      */
+ * return `out` is filled and the result columns are complete on the stream.
+ * Which formulation runs is the executor's choice (hmj_timing.path says which; results are the same):
+ *   - two radix passes + LDS build/probe per partition (the default from ~2^21 rows per side on; histogram-free slab
+ *     passes of up to 9 bits, so up to 2^30 rows per side stay at 32 B per row and pass);
+ *   - count modes, build side of <= 2^17 rows (or a join of <= 2^21 rows in all): ONE global hash table, the probe side
+ *     streamed unpartitioned -- the reference's BM_hash_join_raw formulation (hashjoin_bench.cc:29-63), HMJ_PATH_GLOBAL_TABLE;
+ *   - count modes, build side of 2^17 ... 2^21 rows under a probe side >= 8 x larger: one radix pass, the probe side left
+ *     in the worker-private slabs of its slab pass and probed there, HMJ_PATH_SLAB_ONE_PASS.                          */
 int hmj_join_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_build,
                         const void* probe_aos_dev, uint64_t n_probe, uint32_t flags,
                         hmj_result* out);

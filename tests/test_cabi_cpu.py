@@ -69,3 +69,19 @@ def test_product_never_imports_the_oracle():
                             and "// " + needle not in ln]
                     hits = [ln for ln in hits if not re.search(r"//.*" + re.escape(needle), ln)]
                     assert not hits, (f, needle, hits)
+
+
+def test_path_bits_are_distinct_and_mirrored_by_the_binding():
+    # hmj_timing.path is a bit set the tests assert on: two names on one bit (round 4 put HMJ_PATH_GLOBAL_TABLE on
+    # HMJ_PATH_SORTED_FK_WIDE's for a few hours) make those assertions mean something else
+    from hashmergejoin_amd import _lib
+
+    src = open(os.path.join(ROOT, "include", "hmj.h")).read()
+    seen = {}
+    for name, v in re.findall(r"#define (HMJ_PATH_\w+) (0x[0-9a-fA-F]+)u", src):
+        bit = int(v, 16)
+        assert bit and bit & (bit - 1) == 0, (name, v)
+        assert bit not in seen, (name, seen[bit])
+        seen[bit] = name
+        assert getattr(_lib, name) == bit, name
+    assert len(seen) >= 21

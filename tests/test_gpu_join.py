@@ -1171,9 +1171,30 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
                 assert r.checks() == ck, (nb, npb, fl)
             if fl & H.HMJ_SUM_PROBE:
                 assert int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
-        # materialising joins: partitioned as before
-        ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE)
+        # materialising joins, unordered: the same table, result rows written by ballot-compacted waves behind one output
+        # cursor (any placement is a valid unordered result) -- when no probe row can expand to several rows: unique build
+        # keys, or first-wins.  Duplicate build keys without first-wins: partitioned paths, and not asked again for 8 joins.
+        ck, rows = oracle.equijoin(B, P)
+        ckf, rowsf = oracle.equijoin(B, P, first_wins=True)
+        for fl, want_ck, want_rows, gt in ((H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, ck, rows, not dup),
+                                           (H.HMJ_MATERIALIZE | H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM, ckf, rowsf, True),
+                                           (H.HMJ_MATERIALIZE, ck, rows, not dup)):
+            if fl & H.HMJ_FIRST_WINS:  # (a cool-down left by the duplicate-key attempt before it must not hide this one)
+                for _ in range(8):
+                    ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE | H.HMJ_FIRST_WINS)
+            r = ex.join_device(Bd, Pd, fl)
+            assert bool(ex.last_timing()["path"] & GT) == gt, (nb, npb, dup, fl, hex(ex.last_timing()["path"]))
+            assert int(r.n_matches) == want_ck["n_matches"] and (int(r.sum_r), int(r.sum_s)) == (want_ck["sum_r"], want_ck["sum_s"])
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == want_ck
+            assert np.array_equal(sorted_rows(ex.columns_to_numpy(r, host=False)), want_rows), (nb, npb, dup, fl)
+        if dup:  # let the duplicate-key cool-down of the materialising form run out before the next case
+            for _ in range(8):
+                ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE)
+        # ordered results need the probe rows in key order, which is the partitioning
+        ex.join_device(Bd, Pd, H.HMJ_ORDERED)
         assert not ex.last_timing()["path"] & GT
+        ex.release_result()
     # a build side beyond 2^17 rows (its table would leave the L2), a forced plan: partitioned as before
     B, P = oracle.gen_build(200000), oracle.gen_probe(4000000, 200000)
     ex.join_device(to_dev(B), to_dev(P), 0)
