@@ -133,6 +133,12 @@ def extra_runs(ex, H, torch):
             msm, rm = timed(lambda: ex.join_device(R, S, H.HMJ_MATERIALIZE))
             assert int(rm.n_matches) == n
             out["small_build_2p16_x_2p26_materialize_ms"] = msm
+            mso, ro = timed(lambda: ex.join_device(R, S, H.HMJ_ORDERED), reps=2)  # the operator's mode: rows in (key, rval, sval) order
+            assert int(ro.n_matches) == n
+            out["small_build_2p16_x_2p26_ordered_ms"] = mso
+            out["small_build_2p16_ordered_path"] = ("sort on (key rank, payload) composites" if ex.last_timing()["path"] & H.HMJ_PATH_ORDER_BY_RANK_SORT
+                                                    else "partitioned (%d bits)" % ex.last_timing()["radix_bits"])
+            ex.release_result()
             ex.join_device(R, S, 0)
         tp = ex.last_timing()
         out["small_build_2p%d_path" % lb] = ("global table, probe side unpartitioned" if tp["path"] & H.HMJ_PATH_GLOBAL_TABLE else

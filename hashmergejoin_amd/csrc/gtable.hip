@@ -271,6 +271,150 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_write_kernel(const Tup* __r
   block_accumulate(red, accum, v, 1u << ACC_XOR);
 }
 
+// ---- ordered results for a small build side under a long probe side (fan-outs in the hundreds and thousands) ----------
+// The operator's order is (key, rval, sval).  With unique build keys that is: the probe rows sorted by (rank of their key
+// among the sorted build keys, sval).  rank < 2^17 and the payloads of one relation usually span far less than 64 bits
+// (row ids, timestamps of one epoch), so the pair fits ONE 64-bit sort key: composite = rank << range_bits | (sval - svmin).
+// Pipeline (api.hip, try_small_build_ordered): sort the build side (tiny) -> global table key -> rank -> this kernel emits
+// one composite per matching probe row -> LSD radix passes over the composite's rank_bits + range_bits low bits ->
+// gtable_expand_kernel turns every composite back into its result row.  The partitioned paths rank every probe row inside
+// its key's run, linear in the run: 2^16 x 2^26 rows ordered 14-22 ms, 2^10 x 2^22 6 ms (an 18-bit plan of 2^18 partitions).
+__global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__ S, u32 np, u64* __restrict__ out) {
+  u64 mn = ~0ull, mx = 0;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < np; i += (u64)gridDim.x * 256) {
+    const u64 v = S[i].val;
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    const u64 a2 = __shfl_xor(mn, o, kWave), b2 = __shfl_xor(mx, o, kWave);
+    mn = a2 < mn ? a2 : mn;
+    mx = b2 > mx ? b2 : mx;
+  }
+  if ((threadIdx.x & 63) == 0 && np) {
+    atomicMin(reinterpret_cast<unsigned long long*>(out), (unsigned long long)mn);
+    atomicMax(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)mx);
+  }
+}
+
+// table: key -> rank (built by gtable_build_kernel<true> over the SORTED build rows: the row index is the rank).
+// pairs[cursor++] = {rank << range_bits | (sval - svmin), 0}; accum[ACC_N] is the cursor.
+template <bool EXTRA>
+__global__ __launch_bounds__(GT_THREADS) void gtable_emit_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
+                                                                  int log_cap, u64 svmin, int range_bits, u64* __restrict__ accum,
+                                                                  Tup* __restrict__ pairs) {
+  __shared__ u64 red[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 8) red[tid] = 0;
+  if (accum[ACC_PAD] != 0) return;  // duplicate build keys: not this path's case (uniform for the grid)
+  const u32 mask = (1u << log_cap) - 1;
+  const int shift = 64 - log_cap;
+  constexpr u32 TILE = GT_THREADS * GT_ROWS;
+  u64 acc_s = 0, acc_p = 0;
+  for (u64 base = (u64)blockIdx.x * TILE; base < np; base += (u64)gridDim.x * TILE) {
+    Tup t[GT_ROWS];
+    u32 slot[GT_ROWS];
+    bool live[GT_ROWS];
+    u64 rank[GT_ROWS];
+    u32 hit = 0;
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      const u64 i = base + (u64)r * GT_THREADS + tid;
+      const bool valid = i < np;
+      t[r] = load_stream(&S[valid ? i : (u64)np - 1]);
+      live[r] = valid;
+    }
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      slot[r] = gt_hash(t[r].key, shift);
+      rank[r] = 0;
+      if (EXTRA && live[r]) acc_p += t[r].val;
+      if (t[r].key == GT_EMPTY) live[r] = false;
+    }
+    bool any_live = false;
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) any_live |= live[r];
+    while (any_live) {
+      Tup e[GT_ROWS];
+#pragma unroll
+      for (int r = 0; r < GT_ROWS; r++)
+        if (live[r]) e[r] = tab[slot[r]];
+      any_live = false;
+#pragma unroll
+      for (int r = 0; r < GT_ROWS; r++) {
+        if (live[r]) {
+          if (e[r].key == GT_EMPTY) {
+            live[r] = false;
+          } else if (e[r].key == t[r].key) {  // (unique build keys: the only hit)
+            hit |= 1u << r;
+            rank[r] = e[r].val;
+            live[r] = false;
+          } else {
+            slot[r] = (slot[r] + 1) & mask;
+            any_live = true;
+          }
+        }
+      }
+    }
+    u32 pre[GT_ROWS], run = 0;
+    u64 m[GT_ROWS];
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      m[r] = __ballot((hit >> r) & 1u);
+      pre[r] = run;
+      run += (u32)__popcll(m[r]);
+    }
+    u64 ob = 0;
+    if (run) {
+      if (lane == 0) ob = atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_N]), (unsigned long long)run);
+      ob = __shfl(ob, 0, kWave);
+    }
+#pragma unroll
+    for (int r = 0; r < GT_ROWS; r++) {
+      if ((hit >> r) & 1u) {
+        Tup o;
+        o.key = (range_bits >= 64 ? 0ull : rank[r] << range_bits) | (t[r].val - svmin);
+        o.val = 0;
+        store_stream(&pairs[ob + pre[r] + popc_below(m[r])], o);
+        acc_s += t[r].val;
+      }
+    }
+  }
+  __syncthreads();
+  const u64 v[6] = {0, 0, acc_s, 0, 0, acc_p};
+  block_accumulate(red, accum, v, 1u << ACC_XOR);
+}
+
+// sorted composites -> result rows.  sortedR: the build rows in key order (rank = index).
+template <bool EXTRA>
+__global__ __launch_bounds__(256) void gtable_expand_kernel(const Tup* __restrict__ pairs, u64 n, const Tup* __restrict__ sortedR,
+                                                            u64 svmin, int range_bits, u64* __restrict__ out_key,
+                                                            u64* __restrict__ out_rval, u64* __restrict__ out_sval,
+                                                            u64* __restrict__ accum) {
+  __shared__ u64 red[8];
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
+  const u64 lowmask = range_bits >= 64 ? ~0ull : ((1ull << range_bits) - 1);
+  u64 acc_r = 0, acc_x = 0, acc_m = 0;
+  for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n; j += (u64)gridDim.x * 256) {
+    const u64 c = load_stream(&pairs[j]).key;
+    const Tup b = sortedR[range_bits >= 64 ? 0ull : c >> range_bits];
+    const u64 sv = (c & lowmask) + svmin;
+    out_key[j] = b.key;
+    out_rval[j] = b.val;
+    out_sval[j] = sv;
+    acc_r += b.val;
+    if (EXTRA) {
+      const u64 mx = tmix(b.key, b.val, sv);
+      acc_x ^= mx;
+      acc_m += mx;
+    }
+  }
+  __syncthreads();
+  const u64 v[6] = {0, acc_r, 0, acc_x, acc_m, 0};
+  block_accumulate(red, accum, v, 1u << ACC_XOR);
+}
+
 hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u64* accum, bool first, int num_cus,
                                hipStream_t st) {
   if (log_cap < 4 || log_cap > 30 || ((u64)1 << log_cap) < (u64)nb + nb / 4 + 1) return hipErrorInvalidValue;  // (load factor <= 0.8: walks must end)
@@ -321,6 +465,42 @@ hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_c
     if (extra) HMJ_GTW(false, true); else HMJ_GTW(false, false);
   }
 #undef HMJ_GTW
+  return hipGetLastError();
+}
+
+hipError_t launch_sval_range(const void* S, u32 np, u64* out2, int num_cus, hipStream_t st) {
+  hipLaunchKernelGGL(sval_range_kernel, dim3(num_cus * 8), dim3(256), 0, st, static_cast<const Tup*>(S), np, out2);
+  return hipGetLastError();
+}
+
+hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,
+                              void* pairs, bool extra, int num_cus, int wg_per_cu, hipStream_t st) {
+  if (log_cap < 4 || log_cap > 30 || range_bits < 0 || range_bits > 64 || !pairs) return hipErrorInvalidValue;
+  const u64 tiles = ((u64)np + GT_THREADS * GT_ROWS - 1) / (GT_THREADS * GT_ROWS);
+  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8);
+  if (grid > tiles) grid = tiles;
+  if (grid < 1) grid = 1;
+  if (extra)
+    hipLaunchKernelGGL((gtable_emit_kernel<true>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np,
+                       static_cast<const Tup*>(tab), log_cap, svmin, range_bits, accum, static_cast<Tup*>(pairs));
+  else
+    hipLaunchKernelGGL((gtable_emit_kernel<false>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np,
+                       static_cast<const Tup*>(tab), log_cap, svmin, range_bits, accum, static_cast<Tup*>(pairs));
+  return hipGetLastError();
+}
+
+hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u64 svmin, int range_bits, u64* out_key,
+                                u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st) {
+  if (!pairs || !sortedR || !out_key || !out_rval || !out_sval || range_bits < 0 || range_bits > 64) return hipErrorInvalidValue;
+  u64 grid = (n + 255) / 256;
+  if (grid > (u64)num_cus * 16) grid = (u64)num_cus * 16;
+  if (grid < 1) grid = 1;
+  if (extra)
+    hipLaunchKernelGGL((gtable_expand_kernel<true>), dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(pairs), n,
+                       static_cast<const Tup*>(sortedR), svmin, range_bits, out_key, out_rval, out_sval, accum);
+  else
+    hipLaunchKernelGGL((gtable_expand_kernel<false>), dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(pairs), n,
+                       static_cast<const Tup*>(sortedR), svmin, range_bits, out_key, out_rval, out_sval, accum);
   return hipGetLastError();
 }
 

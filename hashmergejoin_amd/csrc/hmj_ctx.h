@@ -100,6 +100,9 @@ struct hmj_ctx {
   u32 gtable_slots_per_row = 16;   // table slots per build row (HMJ_GTABLE_SLOTS) ...
   int gtable_max_log_cap = 18;     // ... while the table has at most 2^this slots; beyond, down to 4 per row (HMJ_GTABLE_MAX_LOG_CAP)
   int gtable_cooldown = 0;         // joins to skip it for after it gave up
+  bool gtable_sort_mode = true;    // HMJ_GTABLE_SORT=0: ordered joins of a small build side under a long probe side stay partitioned
+  u32 gtable_sort_fanout = 128;    // ... from this many probe rows per build row on (HMJ_GTABLE_SORT_FANOUT)
+  int gtable_sort_cooldown = 0;
   int gtable_write_cooldown = 0;   // materialising joins to skip it for after one met duplicate build keys
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged

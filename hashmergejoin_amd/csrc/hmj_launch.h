@@ -143,6 +143,13 @@ hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_c
 hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_cap, const void* R, u64* accum, u64* out_key,
                                u64* out_rval, u64* out_sval, bool first, bool extra, int num_cus, int wg_per_cu, hipStream_t st);
 
+// ordered results of a small build side under a long probe side: composites rank << range_bits | (sval - svmin), sorted, expanded
+hipError_t launch_sval_range(const void* S, u32 np, u64* out2 /* {min, max}; caller: {~0, 0} */, int num_cus, hipStream_t st);
+hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,
+                              void* pairs, bool extra, int num_cus, int wg_per_cu, hipStream_t st);
+hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u64 svmin, int range_bits, u64* out_key,
+                                u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st);
+
 // gen.hip
 hipError_t launch_gen_build(void* out, u64 n, u64 start, u64 seed, hipStream_t st);
 hipError_t launch_gen_probe(void* out, u64 n, u64 start, u64 n_build, u64 seed, u64 miss_mod,

@@ -1093,6 +1093,55 @@ def test_nine_bit_slab_passes_against_the_oracle(ex_fresh, H, oracle, bits):
         ex.set_radix_bits(None)
 
 
+def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, oracle):
+    # The operator's own mode (HMJ_ORDERED) for a small dimension table under a long fact table -- hundreds or thousands of
+    # probe rows per build key.  With unique build keys the order (key, rval, sval) is the probe rows sorted by (rank of the
+    # key among the sorted build keys, sval); where rank and payload range fit 64 bits together the join sorts ONE composite
+    # per matching probe row (HMJ_PATH_ORDER_BY_RANK_SORT) instead of ranking every row inside its key's run.  Exact row
+    # sequences against the oracle: payloads that are row ids, payloads with a large common offset, unmatched probe rows,
+    # one build row, checksums / first-wins flags; payloads spanning all 64 bits, and duplicate build keys, fall back.
+    ex = ex_fresh
+    RS = H.HMJ_PATH_ORDER_BY_RANK_SORT
+    rng = np.random.default_rng(77)
+    for nb, npb, miss, pay in [(1, 5000, 0, "ids"), (7, 70000, 0, "ids"), (1000, 300001, 3, "offset"), (5000, 700000, 0, "ids"),
+                               (60000, 1 << 23, 4, "offset"), (1000, 200000, 0, "wide"), (3000, 400000, 2, "dupbuild")]:
+        B = oracle.gen_build(nb)
+        P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
+        if pay == "ids":
+            P[:, 1] = rng.permutation(npb).astype(np.uint64)
+        elif pay == "offset":
+            P[:, 1] = np.uint64(0xFEDCBA9800000000) + rng.integers(0, 1 << 30, size=npb, dtype=np.uint64)  # (ties among payloads too)
+        elif pay == "wide":
+            P[:, 1] = rng.integers(0, 1 << 63, size=npb, dtype=np.uint64) * np.uint64(2)
+        if pay == "dupbuild":
+            B[1::3, 0] = B[0::3, 0][: len(B[1::3])]
+        Bd, Pd = to_dev(B), to_dev(P)
+        ck, rows = oracle.equijoin(B, P)
+        for fl in (H.HMJ_ORDERED, H.HMJ_ORDERED | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE):
+            r = ex.join_device(Bd, Pd, fl)
+            t = ex.last_timing()
+            took = bool(t["path"] & RS)
+            assert took == (pay in ("ids", "offset")), (nb, npb, pay, fl, hex(t["path"]))
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, pay, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck and int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+            assert np.array_equal(ex.columns_to_numpy(r, host=False), rows), (nb, npb, pay, fl)
+            if not took:  # the give-up leaves 8 joins of cool-down: let it run out so the next case is asked again
+                for _ in range(8):
+                    ex.join_device(Bd, Pd, H.HMJ_ORDERED)
+        if pay == "ids":  # first-wins on unique build keys is the same join
+            r = ex.join_device(Bd, Pd, H.HMJ_ORDERED | H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM)
+            assert r.checks() == ck and ex.last_timing()["path"] & RS
+            assert np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+            rh = ex.join_host(B, P, H.HMJ_ORDERED)  # the C++ operator's entry: host relations in, ordered rows out
+            assert np.array_equal(ex.columns_to_numpy(rh, host=True), rows)
+        ex.release_result()
+    # a fan-out below the gate keeps the partitioned one-pass ordered write
+    B, P = oracle.gen_build(50000), oracle.gen_uniform_domain(600000, 50000)
+    ex.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED)
+    assert not ex.last_timing()["path"] & RS
+
+
 def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
     # A dimension table of 2^18 ... 2^20 rows under a fact table several times larger, count modes: ONE radix pass, and the
     # probe side's pass is the histogram-free slab pass A whose worker-private slabs the generic probe kernel walks piece
@@ -1443,8 +1492,10 @@ def test_build_keys_in_part_of_the_key_range_get_a_denser_plan(ex_part, H, oracl
     ex.set_profiling(False)
 
 
-def test_prepared_build_side(ex, H, oracle):
+def test_prepared_build_side(ex_part, H, oracle):
     # hmj_prepare_build_u64_device: partition R ahead of the join (one-shot), for both partitioning paths
+    # (on an executor whose small count joins partition too: with the global table there is nothing to prepare)
+    ex = ex_part
     for nb, npb in [(1 << 22, (1 << 22) + 999), (300000, 200000)]:
         B, P = oracle.gen_build(nb), oracle.gen_probe(npb, nb, miss_mod=4)
         ck, _ = oracle.equijoin(B, P, cap=0)
