@@ -965,7 +965,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // its threads per piece (1280 rows); a key's f probe rows spread over the four pieces (f = 8 at 4096-row partitions
     // overflowed a piece, the join started over with probe-side slabs only: 3.9 ms against 2.7 ms, tools/exp_cliffs_fk.py)
     if (!materialize)
-      while (Bp < 2 * hmj::SLAB_MAX_BITS && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
+      while (Bp < 16 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
     fk_wide_plan = wide_ok && wide_ok_override && !take_half && Bp < B_narrow;
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     // (count joins whose build-side plan is ONE pass keep it when the probe side can stay in that pass's slabs -- the
@@ -973,7 +973,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     const bool one_pass_count = !materialize && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
                                 c->slab_probe_cooldown == 0 && !c->prepare_only && np_plan >= (1u << 22) && (u64)np_plan >= 8ull * nb;
     if (Bp > B && !one_pass_count &&
-        ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 2 * hmj::SLAB_MAX_BITS && slab_ok)))
+        // (count joins: up to 16 bits only.  The 9-bit slab passes would allow 17 and 18, but a probe side that needs them
+        //  is >= 3 * 10^8 rows over a much smaller build side -- BASELINE configs[4] -- where partitioning BOTH sides that
+        //  finely costs more than the build-side plan with probe-side slabs (20 against 17.4 ms), skewed build keys overflow
+        //  the build slabs, and the cool-down of that failed attempt took the next eight joins of the context off the slab
+        //  path: a 5 * 10^8-row join after it ran 21.9 instead of 16.3 ms, tools/exp_after_configs4.py)
+        ((materialize && !c->prepare_only && Bp <= 18) || (!materialize && Bp <= 16 && slab_ok)))
       plan_bits(0, Bp, &B, &passes, pass_bits);  // the pass split of Bp bits
   }
   const u32 P = 1u << B;
