@@ -1762,7 +1762,14 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   const u64 key_diff = hh[0], svmin = np ? hh[3] : 0, svmax = np ? hh[4] : 0;
   const int range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
   const int rank_bits = nb > 1 ? 32 - __builtin_clz(nb - 1) : 0;
-  if (rank_bits + range_bits > 64) return give_up("probe payloads span too many bits");
+  // rank and payload in ONE word where they fit; else as two (payloads that are hashes, doubles, pointers): sorted by the
+  // payload's varying digits first, then stably by the rank -- up to 8 + 3 passes instead of 4-5, still well under the
+  // partitioned paths' run ranking at these fan-outs (a wide-payload join needs twice the fan-out to take this path)
+  const bool wide = rank_bits + range_bits > 64;
+  if (wide && n_probe < 2ull * c->gtable_sort_fanout * (n_build > 2 * c->gtable_max_rows ? 2 : 1) * n_build) {
+    c->gtable_sort_cooldown = 8;
+    return HMJ_OK;
+  }
   if (nb > 1 && key_diff == 0) return give_up("duplicate build keys");
   // ---- 2. the build side in key order: stable LSD passes over the digits in which keys differ
   const void* sortedR = R;
@@ -1789,8 +1796,8 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   int sp = span_begin(c, K_PROBE_COUNT, -1);
   HIP_TRY(hmj::launch_gtable_build(sortedR, nb, c->gtab.p, log_cap, (u64*)c->accum.p, true, c->num_cus, c->stream));
   // ---- 4. one composite per matching probe row
-  HIP_TRY(hmj::launch_gtable_emit(S, np, c->gtab.p, log_cap, svmin, range_bits, (u64*)c->accum.p, c->sbuf[0].p, extra, c->num_cus,
-                                  c->gtable_wg_per_cu, c->stream));
+  HIP_TRY(hmj::launch_gtable_emit(S, np, c->gtab.p, log_cap, svmin, range_bits, (u64*)c->accum.p, c->sbuf[0].p, extra, wide,
+                                  c->num_cus, c->gtable_wg_per_cu, c->stream));
   span_end(c, sp);
   HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1799,17 +1806,33 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   const u64 n = hh[hmj::ACC_N];
   // ---- 5. sort the composites: only their rank_bits + range_bits low bits differ
   const void* sorted = c->sbuf[0].p;
-  if (n > 1) {
-    const int total = rank_bits + range_bits;
+  int which = 0, n_passes = 0;  // `sorted` lies in sbuf[which]
+  auto lsd = [&](int total) -> int {  // stable LSD passes over the key word's bits [0, total), 9-bit digits at most
+    if (total <= 0 || n <= 1) return HMJ_OK;
     const int passes = (total + hmj::RP_MAX_BITS - 1) / hmj::RP_MAX_BITS;
     int shift = 0;
     for (int i = 0; i < passes; i++) {
       const int bits = total / passes + (i < total % passes ? 1 : 0);
-      void* dst = c->sbuf[(i + 1) & 1].p;
-      if ((rc = radix_pass(c, sorted, dst, (u32)n, shift, bits, 1, nullptr, i ? 1 : 0)) != HMJ_OK) return rc;
+      void* dst = c->sbuf[which ^ 1].p;
+      const int r2 = radix_pass(c, sorted, dst, (u32)n, shift, bits, 1, nullptr, n_passes ? 1 : 0);
+      if (r2 != HMJ_OK) return r2;
       sorted = dst;
+      which ^= 1;
       shift += bits;
+      n_passes++;
     }
+    return HMJ_OK;
+  };
+  if (!wide) {
+    if ((rc = lsd(rank_bits + range_bits)) != HMJ_OK) return rc;
+  } else {
+    if ((rc = lsd(range_bits)) != HMJ_OK) return rc;  // {payload, rank} by payload
+    if (n) {
+      HIP_TRY(hmj::launch_gtable_swap(sorted, c->sbuf[which ^ 1].p, n, c->num_cus, c->stream));  // -> {rank, payload}
+      sorted = c->sbuf[which ^ 1].p;
+      which ^= 1;
+    }
+    if ((rc = lsd(rank_bits)) != HMJ_OK) return rc;  // stably by rank
   }
   // ---- 6. composites -> result rows
   if (n) {
@@ -1819,7 +1842,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     if ((rc = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return rc;
     sp = span_begin(c, K_PROBE_WRITE, -1);
     HIP_TRY(hmj::launch_gtable_expand(sorted, n, sortedR, svmin, range_bits, (u64*)c->out_key.p, (u64*)c->out_rval.p,
-                                      (u64*)c->out_sval.p, (u64*)c->accum.p, extra, c->num_cus, c->stream));
+                                      (u64*)c->out_sval.p, (u64*)c->accum.p, extra, wide, c->num_cus, c->stream));
     span_end(c, sp);
     HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1833,7 +1856,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   out->sum_probe_all = hh[hmj::ACC_SUM_P];
   c->timing.path |= HMJ_PATH_GLOBAL_TABLE | HMJ_PATH_ORDER_BY_RANK_SORT;
   c->timing.radix_bits = rank_bits + range_bits;
-  c->timing.radix_passes = (rank_bits + range_bits + hmj::RP_MAX_BITS - 1) / hmj::RP_MAX_BITS;
+  c->timing.radix_passes = n_passes;
   c->timing.n_probe_items = 1;
   c->timing.bytes_probe_write = 16ull * (n_build + n_probe) + 24ull * n;
   if (n) {

@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__
 
 // table: key -> rank (built by gtable_build_kernel<true> over the SORTED build rows: the row index is the rank).
 // pairs[cursor++] = {rank << range_bits | (sval - svmin), 0}; accum[ACC_N] is the cursor.
-template <bool EXTRA>
+// WIDE (rank and payload do not fit one word together): pairs[..] = {sval - svmin, rank} -- sorted by the payload first, then
+// (after gtable_swap_kernel) stably by the rank.
+template <bool EXTRA, bool WIDE>
 __global__ __launch_bounds__(GT_THREADS) void gtable_emit_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
                                                                   int log_cap, u64 svmin, int range_bits, u64* __restrict__ accum,
                                                                   Tup* __restrict__ pairs) {
@@ -374,8 +376,13 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_emit_kernel(const Tup* __re
     for (int r = 0; r < GT_ROWS; r++) {
       if ((hit >> r) & 1u) {
         Tup o;
-        o.key = (range_bits >= 64 ? 0ull : rank[r] << range_bits) | (t[r].val - svmin);
-        o.val = 0;
+        if (WIDE) {
+          o.key = t[r].val - svmin;
+          o.val = rank[r];
+        } else {
+          o.key = (range_bits >= 64 ? 0ull : rank[r] << range_bits) | (t[r].val - svmin);
+          o.val = 0;
+        }
         store_stream(&pairs[ob + pre[r] + popc_below(m[r])], o);
         acc_s += t[r].val;
       }
@@ -386,8 +393,20 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_emit_kernel(const Tup* __re
   block_accumulate(red, accum, v, 1u << ACC_XOR);
 }
 
+// {a, b} -> {b, a}: the wide form's second sort is on the rank
+__global__ __launch_bounds__(256) void gtable_swap_kernel(const Tup* __restrict__ in, Tup* __restrict__ out, u64 n) {
+  for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n; j += (u64)gridDim.x * 256) {
+    const Tup t = load_stream(&in[j]);
+    Tup o;
+    o.key = t.val;
+    o.val = t.key;
+    store_stream(&out[j], o);
+  }
+}
+
 // sorted composites -> result rows.  sortedR: the build rows in key order (rank = index).
-template <bool EXTRA>
+// WIDE: pairs[j] = {rank, sval - svmin}.
+template <bool EXTRA, bool WIDE>
 __global__ __launch_bounds__(256) void gtable_expand_kernel(const Tup* __restrict__ pairs, u64 n, const Tup* __restrict__ sortedR,
                                                             u64 svmin, int range_bits, u64* __restrict__ out_key,
                                                             u64* __restrict__ out_rval, u64* __restrict__ out_sval,
@@ -397,9 +416,10 @@ __global__ __launch_bounds__(256) void gtable_expand_kernel(const Tup* __restric
   const u64 lowmask = range_bits >= 64 ? ~0ull : ((1ull << range_bits) - 1);
   u64 acc_r = 0, acc_x = 0, acc_m = 0;
   for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n; j += (u64)gridDim.x * 256) {
-    const u64 c = load_stream(&pairs[j]).key;
-    const Tup b = sortedR[range_bits >= 64 ? 0ull : c >> range_bits];
-    const u64 sv = (c & lowmask) + svmin;
+    const Tup pr = load_stream(&pairs[j]);
+    const u64 c = pr.key;
+    const Tup b = sortedR[WIDE ? c : (range_bits >= 64 ? 0ull : c >> range_bits)];
+    const u64 sv = (WIDE ? pr.val : (c & lowmask)) + svmin;
     out_key[j] = b.key;
     out_rval[j] = b.val;
     out_sval[j] = sv;
@@ -474,33 +494,47 @@ hipError_t launch_sval_range(const void* S, u32 np, u64* out2, int num_cus, hipS
 }
 
 hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,
-                              void* pairs, bool extra, int num_cus, int wg_per_cu, hipStream_t st) {
+                              void* pairs, bool extra, bool wide, int num_cus, int wg_per_cu, hipStream_t st) {
   if (log_cap < 4 || log_cap > 30 || range_bits < 0 || range_bits > 64 || !pairs) return hipErrorInvalidValue;
   const u64 tiles = ((u64)np + GT_THREADS * GT_ROWS - 1) / (GT_THREADS * GT_ROWS);
   u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8);
   if (grid > tiles) grid = tiles;
   if (grid < 1) grid = 1;
-  if (extra)
-    hipLaunchKernelGGL((gtable_emit_kernel<true>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np,
-                       static_cast<const Tup*>(tab), log_cap, svmin, range_bits, accum, static_cast<Tup*>(pairs));
-  else
-    hipLaunchKernelGGL((gtable_emit_kernel<false>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np,
-                       static_cast<const Tup*>(tab), log_cap, svmin, range_bits, accum, static_cast<Tup*>(pairs));
+#define HMJ_GTE(E, W)                                                                                                  \
+  hipLaunchKernelGGL((gtable_emit_kernel<E, W>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np, \
+                     static_cast<const Tup*>(tab), log_cap, svmin, range_bits, accum, static_cast<Tup*>(pairs))
+  if (extra) {
+    if (wide) HMJ_GTE(true, true); else HMJ_GTE(true, false);
+  } else {
+    if (wide) HMJ_GTE(false, true); else HMJ_GTE(false, false);
+  }
+#undef HMJ_GTE
+  return hipGetLastError();
+}
+
+hipError_t launch_gtable_swap(const void* in, void* out, u64 n, int num_cus, hipStream_t st) {
+  u64 grid = (n + 255) / 256;
+  if (grid > (u64)num_cus * 16) grid = (u64)num_cus * 16;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(gtable_swap_kernel, dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(in), static_cast<Tup*>(out), n);
   return hipGetLastError();
 }
 
 hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u64 svmin, int range_bits, u64* out_key,
-                                u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st) {
+                                u64* out_rval, u64* out_sval, u64* accum, bool extra, bool wide, int num_cus, hipStream_t st) {
   if (!pairs || !sortedR || !out_key || !out_rval || !out_sval || range_bits < 0 || range_bits > 64) return hipErrorInvalidValue;
   u64 grid = (n + 255) / 256;
   if (grid > (u64)num_cus * 16) grid = (u64)num_cus * 16;
   if (grid < 1) grid = 1;
-  if (extra)
-    hipLaunchKernelGGL((gtable_expand_kernel<true>), dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(pairs), n,
-                       static_cast<const Tup*>(sortedR), svmin, range_bits, out_key, out_rval, out_sval, accum);
-  else
-    hipLaunchKernelGGL((gtable_expand_kernel<false>), dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(pairs), n,
-                       static_cast<const Tup*>(sortedR), svmin, range_bits, out_key, out_rval, out_sval, accum);
+#define HMJ_GTX(E, W)                                                                                            \
+  hipLaunchKernelGGL((gtable_expand_kernel<E, W>), dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(pairs), n, \
+                     static_cast<const Tup*>(sortedR), svmin, range_bits, out_key, out_rval, out_sval, accum)
+  if (extra) {
+    if (wide) HMJ_GTX(true, true); else HMJ_GTX(true, false);
+  } else {
+    if (wide) HMJ_GTX(false, true); else HMJ_GTX(false, false);
+  }
+#undef HMJ_GTX
   return hipGetLastError();
 }
 

@@ -145,10 +145,12 @@ hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_c
 
 // ordered results of a small build side under a long probe side: composites rank << range_bits | (sval - svmin), sorted, expanded
 hipError_t launch_sval_range(const void* S, u32 np, u64* out2 /* {min, max}; caller: {~0, 0} */, int num_cus, hipStream_t st);
+// (wide: rank and payload as two words -- {payload, rank} emitted, sorted by payload, swapped, sorted by rank, expanded)
 hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,
-                              void* pairs, bool extra, int num_cus, int wg_per_cu, hipStream_t st);
+                              void* pairs, bool extra, bool wide, int num_cus, int wg_per_cu, hipStream_t st);
+hipError_t launch_gtable_swap(const void* in, void* out, u64 n, int num_cus, hipStream_t st);
 hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u64 svmin, int range_bits, u64* out_key,
-                                u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st);
+                                u64* out_rval, u64* out_sval, u64* accum, bool extra, bool wide, int num_cus, hipStream_t st);
 
 // gen.hip
 hipError_t launch_gen_build(void* out, u64 n, u64 start, u64 seed, hipStream_t st);

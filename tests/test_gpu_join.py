@@ -1099,12 +1099,13 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
     # key among the sorted build keys, sval); where rank and payload range fit 64 bits together the join sorts ONE composite
     # per matching probe row (HMJ_PATH_ORDER_BY_RANK_SORT) instead of ranking every row inside its key's run.  Exact row
     # sequences against the oracle: payloads that are row ids, payloads with a large common offset, unmatched probe rows,
-    # one build row, checksums / first-wins flags; payloads spanning all 64 bits, and duplicate build keys, fall back.
+    # one build row, checksums / first-wins flags, payloads spanning all 64 bits (two-word form); duplicate build keys fall back.
     ex = ex_fresh
     RS = H.HMJ_PATH_ORDER_BY_RANK_SORT
     rng = np.random.default_rng(77)
     for nb, npb, miss, pay in [(1, 5000, 0, "ids"), (7, 70000, 0, "ids"), (1000, 300001, 3, "offset"), (5000, 700000, 0, "ids"),
-                               (60000, 1 << 23, 4, "offset"), (1000, 200000, 0, "wide"), (3000, 400000, 2, "dupbuild")]:
+                               (60000, 1 << 23, 4, "offset"), (1000, 200000, 0, "wide"), (1000, 400001, 3, "wide"),
+                               (3000, 400000, 2, "dupbuild")]:
         B = oracle.gen_build(nb)
         P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
         if pay == "ids":
@@ -1121,7 +1122,8 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             r = ex.join_device(Bd, Pd, fl)
             t = ex.last_timing()
             took = bool(t["path"] & RS)
-            assert took == (pay in ("ids", "offset")), (nb, npb, pay, fl, hex(t["path"]))
+            # (payloads spanning all 64 bits go as two words -- sorted by payload, then stably by rank -- from twice the fan-out on)
+            assert took == (pay in ("ids", "offset") or (pay == "wide" and npb >= 256 * nb)), (nb, npb, pay, fl, hex(t["path"]))
             assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, pay, fl)
             if fl & H.HMJ_CHECKSUM:
                 assert r.checks() == ck and int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
