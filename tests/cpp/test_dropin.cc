@@ -140,6 +140,35 @@ static int run_iterator_kinds_case(uint64_t nb, uint64_t np, uint64_t miss) {
   return fails;
 }
 
+// ---- a dimension table under a fact table: few build rows, hundreds of probe rows per key.  The operator's rows must come in
+// (key, rval, sval) order -- the relational join's, which the oracle's orc_equijoin lists (the reference's own iterator is
+// only defined for unique probe keys).  On the GPU this shape takes the sort on (key rank, payload) composites.
+static int run_fk_case(uint64_t nb, uint64_t np) {
+  std::vector<uint64_t> ba(2 * nb), pa(2 * np);
+  orc_gen_build(ba.data(), nb, 0, ORC_SEED_B);
+  orc_gen_uniform_domain(pa.data(), np, 0, nb, ORC_SEED_B, 0x7654321ull);
+  const KeyValVec r = from_aos(ba), s = from_aos(pa);
+  orc_checks ck;
+  const uint64_t want_n = orc_equijoin(ba.data(), nb, pa.data(), np, 0, nullptr, 0, &ck);
+  std::vector<uint64_t> want(3 * (want_n + 1));
+  orc_equijoin(ba.data(), nb, pa.data(), np, 0, want.data(), want_n, &ck);
+  HashMergeJoin<KeyValVec::const_iterator, KeyValVec::const_iterator> hmj(r.cbegin(), r.cend(), s.cbegin(), s.cend(), 2);
+  uint64_t n = 0;
+  int bad = 0;
+  for (auto tuple : hmj) {
+    if (n < want_n && (*std::get<0>(tuple) != want[3 * n] || *std::get<1>(tuple) != want[3 * n + 1] ||
+                       *std::get<2>(tuple) != want[3 * n + 2]))
+      bad++;
+    n++;
+  }
+  if (n != want_n || bad) {
+    std::printf("FAIL foreign-key case nb=%llu np=%llu: n=%llu want %llu, %d rows differ\n", (unsigned long long)nb,
+                (unsigned long long)np, (unsigned long long)n, (unsigned long long)want_n, bad);
+    return 1;
+  }
+  return 0;
+}
+
 // ---- std::string keys: the reference's own benchmark type (KeyValVec, hashjoin.h:29).  The same
 // synthetic strgen-shaped relations as oracle/ref_driver.cc ref_hashmergejoin_str; the expected
 // count / sum / ordered FNV come from the compiled reference (tests/golden/golden.json) and are
@@ -348,6 +377,10 @@ int main(int argc, char** argv) {
   fails += run_iterator_kinds_case(1, 1, 0);
   fails += run_iterator_kinds_case(5000, 3000, 3);
   fails += run_iterator_kinds_case(300000, 200000, 2);
+  fails += run_fk_case(1, 3000);
+  fails += run_fk_case(1000, 300000);
+  fails += run_fk_case(5000, 1 << 21);
+  fails += run_fk_case(30000, 200000);  // (fan-out 6: the partitioned one-pass ordered write)
   fails += run_prehashed_case(0, 5, 0, 0);
   fails += run_prehashed_case(1000, 1000, 0, 0);
   fails += run_prehashed_case(5000, 3000, 3, 1);

@@ -47,6 +47,23 @@ def ex_part():
     e.close()
 
 
+@pytest.fixture
+def ex_part_fresh():
+    # ... and one of its own per test, for tests that depend on a context's memory of earlier joins (cool-downs, the form the
+    # last ordered join needed)
+    import hashmergejoin_amd as H
+
+    os.environ["HMJ_SLAB_MIN_LOG2"] = "22"
+    os.environ["HMJ_GTABLE"] = "0"
+    try:
+        e = H.Executor(0)
+    finally:
+        del os.environ["HMJ_SLAB_MIN_LOG2"]
+        del os.environ["HMJ_GTABLE"]
+    yield e
+    e.close()
+
+
 @pytest.fixture(scope="module")
 def H():
     import hashmergejoin_amd as H
@@ -326,7 +343,8 @@ def test_skewed_probe_side_is_split_into_virtual_partitions(ex, H, oracle):
     ex.release_result()
 
 
-def test_ordered_rows_of_very_few_keys(ex, H, oracle):
+def test_ordered_rows_of_very_few_keys(ex_part, H, oracle):
+    ex = ex_part  # (the PARTITIONED paths' handling of huge runs: with the global table on, these joins sort (rank, payload) composites)
     # Hundreds of thousands of result rows per key: no in-LDS path of the ordered epilogue applies, and a
     # bitonic network run by one workgroup took seconds.  Such segments are deferred to three stable LSD sorts
     # of the whole result on (sval, rval, key); exact rows in (key, rval, sval) order.
@@ -1244,7 +1262,8 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
                 ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE)
         # ordered results need the probe rows in key order, which is the partitioning
         ex.join_device(Bd, Pd, H.HMJ_ORDERED)
-        assert not ex.last_timing()["path"] & GT
+        tp = ex.last_timing()["path"]  # (... or, from 128 probe rows per key on, the sort on (key rank, payload) composites)
+        assert not tp & GT or tp & H.HMJ_PATH_ORDER_BY_RANK_SORT
         ex.release_result()
     # a build side beyond 2^17 rows (its table would leave the L2), a forced plan: partitioned as before
     B, P = oracle.gen_build(200000), oracle.gen_probe(4000000, 200000)
@@ -1337,7 +1356,8 @@ def test_ordered_unique_key_write_mode(ex, H, oracle):
     run_out_cooldown()
 
 
-def test_one_pass_ordered_write(ex_fresh, H, oracle):
+def test_one_pass_ordered_write(ex_part_fresh, H, oracle):
+    ex_fresh = ex_part_fresh  # (long runs included: with the global table on, fan-outs from 128 on sort (rank, payload) composites instead)
     # HMJ_ORDERED with unique keys on both sides: probe_write_sorted_kernel probes, sorts and writes in one pass
     # (HMJ_PATH_SORTED_WRITE).  Every probe row matched: rows go to the probe rows' own slots.  Unmatched rows: the
     # epilogue closes the gaps once, and the executor chains the output offsets from the next ordered join on
