@@ -1609,7 +1609,8 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       // big probe sides: the table must stay in an XCD's L2.  Small joins (a few hundred microseconds of dependent launches on
       // the partitioned paths: sample + read-back, histogram, scan, scatter, offsets, probe) take it up to 2^20 build rows:
       // 2^18 x 2^18 rows 0.124 -> 0.078 ms, tools/exp_gtable.py / profiles/r04h_sweep_build_x_probe_sizes.txt
-      (n_build > c->gtable_max_rows && !(n_build <= 8 * c->gtable_max_rows && n_build + n_probe <= 16 * c->gtable_max_rows)) ||
+      // (materialising joins: up to twice the rows -- what they replace costs more: 2^18 x 2^26 rows 2.66 ms partitioned)
+      (n_build > (materialize ? 2 : 1) * c->gtable_max_rows && !(n_build <= 8 * c->gtable_max_rows && n_build + n_probe <= 16 * c->gtable_max_rows)) ||
       n_probe < (uint64_t)c->gtable_min_fanout * n_build ||
       (c->prep.valid && c->prep.ptr == R && c->prep.n == (u32)n_build))
     return HMJ_OK;
