@@ -1717,11 +1717,20 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   *done = false;
   if (!c->gtable_mode || !c->gtable_sort_mode || !(flags & HMJ_ORDERED) || c->prepare_only || c->force_bits >= 0 ||
       !c->arrive_ev.empty() || n_build == 0 || n_build > 8 * c->gtable_max_rows || n_probe > 0xFFFFFFFFull ||
-      // from 128 probe rows per build row on up to 2^18 build rows, from 256 on up to 2^20 (measured crossovers: 2^15 x 2^22 rows
-      // 1.19 -> 1.10 ms, 2^19 x 2^27 14.6 -> 13.3, but 2^20 x 2^27 8.2 -> 13.8; 2^19 x 2^28: 140 -> 26 ms)
-      n_probe < (uint64_t)c->gtable_sort_fanout * (n_build > 2 * c->gtable_max_rows ? 2 : 1) * n_build ||
+      n_probe < (uint64_t)c->gtable_sort_fanout * n_build ||
       (c->prep.valid && c->prep.ptr == R && c->prep.n == (u32)n_build))
     return HMJ_OK;
+  {
+    // Which is faster is a matter of fan-out AND size (profiles/r04i_*, r04l_*: both paths over a grid of sizes).  This path:
+    // ~0.65 ms of dependent launches and read-backs + 0.084 ns per probe row (0.10 where the table leaves the L2).  The
+    // partitioned one-pass ordered write: ~0.15 ms + (0.030 + 0.00023 f) ns per row up to fan-out ~200, 0.00041 f ns beyond
+    // (the plan changes), and from ~700 rows per key on it declines (runs beyond its capacity) and the write + order
+    // epilogue takes over at 0.25 ns per row and more.  HMJ_GTABLE_SORT_FANOUT=1 (the experiments) skips the model.
+    const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
+    const double part_ns = f < 200.0 ? 0.030 + 0.00023 * f : f <= 700.0 ? 0.00041 * f : 0.25;
+    const double rank_ns = n_build > 2 * c->gtable_max_rows ? 0.10 : 0.084;
+    if (c->gtable_sort_fanout > 1 && 0.65 + rank_ns * rows >= 0.15 + part_ns * rows) return HMJ_OK;
+  }
   if (c->gtable_sort_cooldown > 0) {
     c->gtable_sort_cooldown--;
     return HMJ_OK;
@@ -1767,9 +1776,13 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   // payload's varying digits first, then stably by the rank -- up to 8 + 3 passes instead of 4-5, still well under the
   // partitioned paths' run ranking at these fan-outs (a wide-payload join needs twice the fan-out to take this path)
   const bool wide = rank_bits + range_bits > 64;
-  if (wide && n_probe < 2ull * c->gtable_sort_fanout * (n_build > 2 * c->gtable_max_rows ? 2 : 1) * n_build) {
-    c->gtable_sort_cooldown = 8;
-    return HMJ_OK;
+  if (wide && c->gtable_sort_fanout > 1) {  // (ten passes instead of four or five: about 1.6 x the time per row)
+    const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
+    const double part_ns = f < 200.0 ? 0.030 + 0.00023 * f : f <= 700.0 ? 0.00041 * f : 0.25;
+    if (0.65 + 0.145 * rows >= 0.15 + part_ns * rows) {
+      c->gtable_sort_cooldown = 8;
+      return HMJ_OK;
+    }
   }
   if (nb > 1 && key_diff == 0) return give_up("duplicate build keys");
   // ---- 2. the build side in key order: stable LSD passes over the digits in which keys differ
