@@ -820,6 +820,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   if (!c->prepare_only && c->prep.valid && !c->prep.slab && c->prep.ptr == R && c->prep.n == nb) allow_slab = false;
   if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;  // before the plan: one decision per join
   if (c->slab_probe_cooldown > 0 && allow_slab_probe) c->slab_probe_cooldown--;  // (likewise: the plan below asks about it)
+  if (c->one_pass_write_cooldown > 0 && materialize && allow_slab_probe) c->one_pass_write_cooldown--;
 
   int B, passes, pass_bits[4];
   bool fk_wide_plan = false;  // the plan relies on the wide shape of the one-pass ordered write (foreign-key form)
@@ -970,7 +971,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     // (count joins whose build-side plan is ONE pass keep it when the probe side can stay in that pass's slabs -- the
     //  one-pass slab path below: 2^21 x 2^28 rows, 18-bit probe-side plan 7.0 ms, 9-bit build-side plan 2.9 ms)
-    const bool one_pass_count = !materialize && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
+    const bool one_pass_count = !(flags & HMJ_ORDERED) && (!materialize || c->one_pass_write_cooldown == 0) && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
                                 c->slab_probe_cooldown == 0 && !c->prepare_only && np_plan >= (1u << 22) && (u64)np_plan >= 8ull * nb;
     if (Bp > B && !one_pass_count &&
         // (count joins: up to 16 bits only.  The 9-bit slab passes would allow 17 and 18, but a probe side that needs them
@@ -1316,7 +1317,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // probe side 16 (histogram) + 32 (scatter) + 16 (probe) bytes per row.  Here its one pass is the histogram-free slab
   // pass A (32 B), and the generic kernel reads a partition straight out of the pass's worker-private slabs: partition p =
   // the WA pieces [p][0 .. WA), an item = (partition, a run of pieces), a wave per piece.  48 instead of 64 B per row.
-  if (allow_slab_probe && c->slab_mode && c->one_pass_slab && c->slab_probe_cooldown == 0 && !materialize && passes == 1 &&
+  if (allow_slab_probe && c->slab_mode && c->one_pass_slab && c->slab_probe_cooldown == 0 && !(flags & HMJ_ORDERED) &&
+      (!materialize || c->one_pass_write_cooldown == 0) && passes == 1 &&
       B >= 5 && B <= hmj::SLAB_MAX_BITS && np >= (1u << 22) && (u64)np >= 8ull * nb && nb > 0) {
     hmj::SlabGeom g1;
     if (hmj::slab_geometry_one_pass(np, B, dense_scale * (double)nb / (double)P, 512, &g1)) {
@@ -1356,15 +1358,35 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
         a.matched = (u32*)c->matched.p;
         HIP_TRY(hipMemsetAsync(c->matched.p, 0, mb, c->stream));
       }
-      sp = span_begin(c, K_PROBE_COUNT, -1);
-      HIP_TRY(hmj::launch_probe(a, 0, first, extra, hmj::probe_default_grid(c->num_cus) * 2, c->stream));
+      if (materialize) {
+        // unordered rows: counted AND written in the same walk, behind one output cursor (probe_kernel<3>); the columns hold
+        // one row per probe row -- more (duplicate build keys: a probe row expands) raises ERR_FASTPATH, and the
+        // count / scan / write passes run instead
+        const size_t bytes = (size_t)np * 8;
+        if ((rc = ensure_dev(c, c->out_key, bytes)) != HMJ_OK) return rc;
+        if ((rc = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return rc;
+        if ((rc = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return rc;
+        a.out_key = (u64*)c->out_key.p;
+        a.out_rval = (u64*)c->out_rval.p;
+        a.out_sval = (u64*)c->out_sval.p;
+        a.out_cap = np;
+      }
+      sp = span_begin(c, materialize ? K_PROBE_WRITE : K_PROBE_COUNT, -1);
+      HIP_TRY(hmj::launch_probe(a, materialize ? 3 : 0, first, extra, hmj::probe_default_grid(c->num_cus) * 2, c->stream));
       span_end(c, sp);
-      c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
+      if (materialize)
+        c->timing.bytes_probe_write = 16ull * ((u64)nb + np);
+      else
+        c->timing.bytes_probe_count = 16ull * ((u64)nb + np);
       u64* hh = (u64*)c->h_accum.p;
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // a slab overflowed (skewed probe keys): the exact path, and not again for a while
         c->slab_probe_cooldown = 8;
+        return kRetryNoSlabProbe;
+      }
+      if (hh[hmj::ACC_ERR] & hmj::ERR_FASTPATH) {  // more result rows than probe rows: the general materialising passes
+        c->one_pass_write_cooldown = 8;
         return kRetryNoSlabProbe;
       }
       out->n_matches = hh[hmj::ACC_N];
@@ -1373,6 +1395,24 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       out->xor_fold = hh[hmj::ACC_XOR];
       out->mix_sum = hh[hmj::ACC_MIX];
       out->sum_probe_all = hh[hmj::ACC_SUM_P];
+      if (materialize && out->n_matches) {
+        c->timing.bytes_probe_write += 24ull * out->n_matches;
+        const size_t bytes = (size_t)out->n_matches * 8;
+        if (to_host) {
+          if ((rc = ensure_host(c, c->h_key, bytes, false)) != HMJ_OK) return rc;
+          if ((rc = ensure_host(c, c->h_rval, bytes, false)) != HMJ_OK) return rc;
+          if ((rc = ensure_host(c, c->h_sval, bytes, false)) != HMJ_OK) return rc;
+          const int s2 = span_begin(c, K_D2H, -1);
+          HIP_TRY(hipMemcpyAsync(c->h_key.p, c->out_key.p, bytes, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipMemcpyAsync(c->h_rval.p, c->out_rval.p, bytes, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipMemcpyAsync(c->h_sval.p, c->out_sval.p, bytes, hipMemcpyDeviceToHost, c->stream));
+          span_end(c, s2);
+          HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        out->key = (const uint64_t*)(to_host ? c->h_key.p : c->out_key.p);
+        out->rval = (const uint64_t*)(to_host ? c->h_rval.p : c->out_rval.p);
+        out->sval = (const uint64_t*)(to_host ? c->h_sval.p : c->out_sval.p);
+      }
       return HMJ_OK;
     }
   }
@@ -1609,8 +1649,8 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       // big probe sides: the table must stay in an XCD's L2.  Small joins (a few hundred microseconds of dependent launches on
       // the partitioned paths: sample + read-back, histogram, scan, scatter, offsets, probe) take it up to 2^20 build rows:
       // 2^18 x 2^18 rows 0.124 -> 0.078 ms, tools/exp_gtable.py / profiles/r04h_sweep_build_x_probe_sizes.txt
-      // (materialising joins: up to twice the rows -- what they replace costs more: 2^18 x 2^26 rows 2.66 ms partitioned)
-      (n_build > (materialize ? 2 : 1) * c->gtable_max_rows && !(n_build <= 8 * c->gtable_max_rows && n_build + n_probe <= 16 * c->gtable_max_rows)) ||
+      // (materialising joins that the one-pass slab walk does not take: up to twice the rows -- what they replace costs more)
+      (n_build > (materialize && !(c->one_pass_slab && c->slab_mode && n_probe >= (1ull << 22) && n_probe >= 8 * n_build) ? 2 : 1) * c->gtable_max_rows && !(n_build <= 8 * c->gtable_max_rows && n_build + n_probe <= 16 * c->gtable_max_rows)) ||
       n_probe < (uint64_t)c->gtable_min_fanout * n_build ||
       (c->prep.valid && c->prep.ptr == R && c->prep.n == (u32)n_build))
     return HMJ_OK;

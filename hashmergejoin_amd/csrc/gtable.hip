@@ -32,6 +32,28 @@ constexpr int GT_THREADS = 256;
 #define HMJ_GT_ROWS 8
 #endif
 constexpr int GT_ROWS = HMJ_GT_ROWS;  // probe rows per thread and tile
+#ifndef HMJ_GTW_THREADS
+#define HMJ_GTW_THREADS 256
+#endif
+constexpr int GTW_THREADS = HMJ_GTW_THREADS;  // the kernels that place rows behind the result cursor: threads per workgroup
+
+// A workgroup's rows of one tile behind the result cursor: ONE add per workgroup.  Adds on one address cost ~11 ns each
+// wherever they come from -- one per wave tile (512 rows) was 1.4 of gtable_write_kernel's 1.75 ms at 2^26 rows; one per
+// workgroup tile (2048 rows) leaves 0.63-0.80 ms for the whole join (512- and 1024-thread workgroups: no better).
+// Every thread of the workgroup calls this the same number of times (two barriers inside).
+template <int THREADS>
+__device__ __forceinline__ u64 wg_reserve(u32 wave_rows, u64* cursor, u64* s_base, u32* s_rows, int tid, int lane) {
+  constexpr int NW = THREADS / kWave;
+  const int wv = tid >> 6;
+  if (lane == 0) s_rows[wv] = wave_rows;
+  __syncthreads();
+  const u32 wr = lane < NW ? s_rows[lane] : 0u;
+  const u32 wincl = wave_incl_scan_u32(wr, lane);
+  const u32 all = (u32)__builtin_amdgcn_readlane((int)wincl, NW - 1);
+  if (tid == 0 && all) *s_base = atomicAdd(reinterpret_cast<unsigned long long*>(cursor), (unsigned long long)all);
+  __syncthreads();
+  return *s_base + (u32)__shfl((int)(wincl - wr), wv, kWave);
+}
 
 __device__ __forceinline__ u32 gt_hash(u64 key, int shift) {
   u64 h = key * 0x9E3779B97F4A7C15ull;
@@ -171,18 +193,20 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __r
 // without first-wins (a probe row would expand to several rows) make the kernel return at once; the host sees the build
 // kernel's flag and takes the partitioned path.
 template <bool FIRST, bool EXTRA>
-__global__ __launch_bounds__(GT_THREADS) void gtable_write_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
+__global__ __launch_bounds__(GTW_THREADS) void gtable_write_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
                                                                    int log_cap, const Tup* __restrict__ R, u64* __restrict__ accum,
                                                                    u64* __restrict__ out_key, u64* __restrict__ out_rval,
                                                                    u64* __restrict__ out_sval) {
   __shared__ u64 red[8];
+  __shared__ u64 obase;
+  __shared__ u32 wrows[GTW_THREADS / kWave];
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < 8) red[tid] = 0;
   const bool dups = accum[ACC_PAD] != 0;
   if (dups && !FIRST) return;  // (uniform for the whole grid)
   const u32 mask = (1u << log_cap) - 1;
   const int shift = 64 - log_cap;
-  constexpr u32 TILE = GT_THREADS * GT_ROWS;
+  constexpr u32 TILE = GTW_THREADS * GT_ROWS;
   u64 acc_r = 0, acc_s = 0, acc_x = 0, acc_m = 0, acc_p = 0;
   for (u64 base = (u64)blockIdx.x * TILE; base < np; base += (u64)gridDim.x * TILE) {
     Tup t[GT_ROWS];
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_write_kernel(const Tup* __r
     u32 hit = 0;        // bit r: row slot r has a match
 #pragma unroll
     for (int r = 0; r < GT_ROWS; r++) {
-      const u64 i = base + (u64)r * GT_THREADS + tid;
+      const u64 i = base + (u64)r * GTW_THREADS + tid;
       const bool valid = i < np;
       t[r] = load_stream(&S[valid ? i : (u64)np - 1]);
       live[r] = valid;
@@ -243,11 +267,7 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_write_kernel(const Tup* __r
       pre[r] = run;
       run += (u32)__popcll(m[r]);
     }
-    u64 ob = 0;
-    if (run) {
-      if (lane == 0) ob = atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_N]), (unsigned long long)run);
-      ob = __shfl(ob, 0, kWave);
-    }
+    const u64 ob = wg_reserve<GTW_THREADS>(run, &accum[ACC_N], &obase, wrows, tid, lane);
 #pragma unroll
     for (int r = 0; r < GT_ROWS; r++) {
       if ((hit >> r) & 1u) {
@@ -303,16 +323,18 @@ __global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__
 // WIDE (rank and payload do not fit one word together): pairs[..] = {sval - svmin, rank} -- sorted by the payload first, then
 // (after gtable_swap_kernel) stably by the rank.
 template <bool EXTRA, bool WIDE>
-__global__ __launch_bounds__(GT_THREADS) void gtable_emit_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
+__global__ __launch_bounds__(GTW_THREADS) void gtable_emit_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
                                                                   int log_cap, u64 svmin, int range_bits, u64* __restrict__ accum,
                                                                   Tup* __restrict__ pairs) {
   __shared__ u64 red[8];
+  __shared__ u64 obase;
+  __shared__ u32 wrows[GTW_THREADS / kWave];
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < 8) red[tid] = 0;
   if (accum[ACC_PAD] != 0) return;  // duplicate build keys: not this path's case (uniform for the grid)
   const u32 mask = (1u << log_cap) - 1;
   const int shift = 64 - log_cap;
-  constexpr u32 TILE = GT_THREADS * GT_ROWS;
+  constexpr u32 TILE = GTW_THREADS * GT_ROWS;
   u64 acc_s = 0, acc_p = 0;
   for (u64 base = (u64)blockIdx.x * TILE; base < np; base += (u64)gridDim.x * TILE) {
     Tup t[GT_ROWS];
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_emit_kernel(const Tup* __re
     u32 hit = 0;
 #pragma unroll
     for (int r = 0; r < GT_ROWS; r++) {
-      const u64 i = base + (u64)r * GT_THREADS + tid;
+      const u64 i = base + (u64)r * GTW_THREADS + tid;
       const bool valid = i < np;
       t[r] = load_stream(&S[valid ? i : (u64)np - 1]);
       live[r] = valid;
@@ -367,11 +389,7 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_emit_kernel(const Tup* __re
       pre[r] = run;
       run += (u32)__popcll(m[r]);
     }
-    u64 ob = 0;
-    if (run) {
-      if (lane == 0) ob = atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_N]), (unsigned long long)run);
-      ob = __shfl(ob, 0, kWave);
-    }
+    const u64 ob = wg_reserve<GTW_THREADS>(run, &accum[ACC_N], &obase, wrows, tid, lane);
 #pragma unroll
     for (int r = 0; r < GT_ROWS; r++) {
       if ((hit >> r) & 1u) {
@@ -472,12 +490,12 @@ hipError_t launch_gtable_probe(const void* S, u32 np, const void* tab, int log_c
 hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_cap, const void* R, u64* accum, u64* out_key,
                                u64* out_rval, u64* out_sval, bool first, bool extra, int num_cus, int wg_per_cu, hipStream_t st) {
   if (log_cap < 4 || log_cap > 30 || !out_key || !out_rval || !out_sval) return hipErrorInvalidValue;
-  const u64 tiles = ((u64)np + GT_THREADS * GT_ROWS - 1) / (GT_THREADS * GT_ROWS);
-  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8);
+  const u64 tiles = ((u64)np + GTW_THREADS * GT_ROWS - 1) / (GTW_THREADS * GT_ROWS);
+  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8) * GT_THREADS / GTW_THREADS;  // (wg_per_cu counts 256-thread workgroups)
   if (grid > tiles) grid = tiles;
   if (grid < 1) grid = 1;
 #define HMJ_GTW(F, E)                                                                                                  \
-  hipLaunchKernelGGL((gtable_write_kernel<F, E>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np, \
+  hipLaunchKernelGGL((gtable_write_kernel<F, E>), dim3((u32)grid), dim3(GTW_THREADS), 0, st, static_cast<const Tup*>(S), np, \
                      static_cast<const Tup*>(tab), log_cap, static_cast<const Tup*>(R), accum, out_key, out_rval, out_sval)
   if (first) {
     if (extra) HMJ_GTW(true, true); else HMJ_GTW(true, false);
@@ -496,12 +514,12 @@ hipError_t launch_sval_range(const void* S, u32 np, u64* out2, int num_cus, hipS
 hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,
                               void* pairs, bool extra, bool wide, int num_cus, int wg_per_cu, hipStream_t st) {
   if (log_cap < 4 || log_cap > 30 || range_bits < 0 || range_bits > 64 || !pairs) return hipErrorInvalidValue;
-  const u64 tiles = ((u64)np + GT_THREADS * GT_ROWS - 1) / (GT_THREADS * GT_ROWS);
-  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8);
+  const u64 tiles = ((u64)np + GTW_THREADS * GT_ROWS - 1) / (GTW_THREADS * GT_ROWS);
+  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8) * GT_THREADS / GTW_THREADS;  // (wg_per_cu counts 256-thread workgroups)
   if (grid > tiles) grid = tiles;
   if (grid < 1) grid = 1;
 #define HMJ_GTE(E, W)                                                                                                  \
-  hipLaunchKernelGGL((gtable_emit_kernel<E, W>), dim3((u32)grid), dim3(GT_THREADS), 0, st, static_cast<const Tup*>(S), np, \
+  hipLaunchKernelGGL((gtable_emit_kernel<E, W>), dim3((u32)grid), dim3(GTW_THREADS), 0, st, static_cast<const Tup*>(S), np, \
                      static_cast<const Tup*>(tab), log_cap, svmin, range_bits, accum, static_cast<Tup*>(pairs))
   if (extra) {
     if (wide) HMJ_GTE(true, true); else HMJ_GTE(true, false);

@@ -121,6 +121,7 @@ struct hmj_ctx {
                                // sample of an earlier join missed a few keys above an otherwise dense range
   u32 slab_probe_kb = 0;  // HMJ_SLAB_PROBE_KB: pieces per partition of the probe-side slabs (0 = 512 >> bits of pass A)
   bool one_pass_slab = true;  // HMJ_ONE_PASS_SLAB=0: count joins of a one-pass plan never leave the probe side in pass-A slabs
+  int one_pass_write_cooldown = 0;  // materialising joins to keep off the one-pass slab path after one met duplicate build keys there
   int slab_probe_cooldown = 0;  // the same for the probe-side-only slab partitioning of probe-heavy count joins
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;

@@ -87,6 +87,7 @@ struct ProbeArgs {
   u64* out_key;
   u64* out_rval;
   u64* out_sval;
+  u64 out_cap;             // mode 3 (count + write behind a cursor): rows the three columns hold
   u64* accum;              // 8 x u64, see hmj_dev.h ACC_*
   const u32* item_list;    // optional: process only these items (set aside by the fast kernel)
   const u32* n_item_list;  //           their count (device)
@@ -108,7 +109,7 @@ struct ProbeArgs {
   u32* matched;            // HMJ_FIRST_WINS + chunked build: one bit per probe row already paired
   u32 debug;               // developer builds (-DHMJ_DEV) only: ablation bits, 1 = loads only, 2 = no probe walk
 };
-// mode: 0 = count/sums only, 1 = count + per-partition counts, 2 = write
+// mode: 0 = count/sums only, 1 = count + per-partition counts, 2 = write, 3 = count + write behind the cursor accum[ACC_N] (piece walk only)
 hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extra, int grid,
                         hipStream_t st);
 int probe_default_grid(int num_cus);

@@ -28,6 +28,8 @@ struct ProbeSmem {
   u32 scratch[PB_THREADS / kWave + 1];
   u64 pcount;
   u64 red[8];
+  u64 obase;                       // MODE 3: where the workgroup's rows of this round start in the result
+  u32 wtot[PB_THREADS / kWave];    // MODE 3: rows each wave found in this round (bit 31: the wave had rows to look at)
   u32 nslot;
 };
 constexpr u32 PB_BATCH = 2 * PB_THREADS;  // build rows inserted per step
@@ -60,6 +62,8 @@ __device__ __forceinline__ bool first_claim(u32* matched, bool multi, u32 row) {
 }
 
 // MODE 0: count + sums.  MODE 1: also per-partition match counts.  MODE 2: write result columns.
+// MODE 3 (round 4; probe side in the slabs of one pass, piece walk): count AND write in one pass -- an unordered result may
+//         be placed anywhere, so a wave reserves its rows with one atomic add on the result cursor (accum[ACC_N]).
 // FIRST: HMJ_FIRST_WINS.  EXTRA: HMJ_CHECKSUM / HMJ_SUM_PROBE accumulators.
 // The table holds one chain entry per DISTINCT key (skewed build sides put hundreds of thousands of
 // equal keys into one partition; chaining them all would make every probe of that bucket walk them).
@@ -70,7 +74,7 @@ __device__ __forceinline__ bool first_claim(u32* matched, bool multi, u32 row) {
 //   else : aux threads a list through the rows with that key (enumerated per match: output-sized work).
 template <int MODE, bool FIRST, bool EXTRA>
 __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(ProbeArgs a) {
-  constexpr bool AGG = !FIRST && !EXTRA && MODE != 2;
+  constexpr bool AGG = !FIRST && !EXTRA && MODE != 2 && MODE != 3;
   constexpr bool PERSIST = AGG || FIRST;  // rows with a key already in the table take no slot
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ProbeSmem& sm = *reinterpret_cast<ProbeSmem*>(smem_raw);
@@ -264,11 +268,130 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
                 }
               }
         };
-        if (npieces) {
+        if (MODE == 3) {
+          // count + write: per group of 4 x 64 rows a wave finds every row's matches (m: how many, first: where their
+          // list starts) and scans the counts slot by slot; the WORKGROUP then reserves the rows of its sixteen groups on the
+          // cursor with ONE atomic add (same-address atomics cost 11 ns each: one per wave group was 3 of this kernel's
+          // 3.6 ms at 2^26 rows) and every wave writes its share -- slot k's rows form one contiguous block, a lane's m
+          // rows inside it are consecutive.  Waves walk their pieces as a state (pb, pi, j0) so that all sixteen reach the
+          // round's two barriers the same number of times.
+          constexpr u32 NW = PB_THREADS / kWave, PR = 4;  // (eight rows in flight spill here: 136-356 bytes of scratch per lane)
+          const u32 wv = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
+          u32 pb = 0, pi = wv, j0 = 0;
+          u32 cnt_l = (u32)lane < npieces ? a.s_cnt[piece0 + lane] : 0u;
+          for (;;) {
+            u32 cnt = 0;
+            bool have = false;
+            while (pb < npieces) {  // (uniform per wave)
+              const u32 pe = npieces - pb < (u32)kWave ? npieces - pb : (u32)kWave;
+              if (pi < pe) {
+                cnt = (u32)__builtin_amdgcn_readlane((int)cnt_l, (int)pi);
+                if (j0 < cnt) { have = true; break; }
+                pi += NW;
+                j0 = 0;
+              } else {
+                pb += kWave;
+                pi = wv;
+                j0 = 0;
+                if (pb < npieces) cnt_l = pb + (u32)lane < npieces ? a.s_cnt[piece0 + pb + lane] : 0u;
+              }
+            }
+            Tup t[PR];
+            u32 m[PR], first[PR], excl[PR], pre[PR];
+            u32 total = 0;
+            const u32 prow0 = (piece0 + pb + pi) * a.s_cap;  // (this piece's first slab slot; unused without a group)
+            if (have) {
+              const Tup* __restrict__ base = S + (u64)prow0;
+#pragma unroll
+              for (int k = 0; k < (int)PR; k++) {
+                const u32 j = j0 + k * kWave + lane;
+                t[k] = load_stream(&base[j < cnt ? j : cnt - 1]);
+              }
+#pragma unroll
+              for (int k = 0; k < (int)PR; k++) {
+                const u32 j = j0 + k * kWave + lane;
+                m[k] = 0;
+                first[k] = NIL;
+                if (j < cnt) {
+                  const u64 key = t[k].key;
+                  if (a.pfx_shift && (key >> a.pfx_shift) != a.pfx_val) pfx_bad = true;
+                  if (EXTRA && first_table) acc_p += t[k].val;
+                  u32 i = sm.head[tab_hash(key)];
+                  while (i != NIL && sm.key[i] != key) i = sm.next[i];
+                  if (i != NIL) {
+                    if (FIRST) {
+                      first[k] = sm.aux[i];
+                      m[k] = first_claim(a.matched, multi, prow0 + j) ? 1u : 0u;
+                    } else {
+                      first[k] = i;
+                      for (u32 n = i; n != NIL; n = sm.aux[n]) m[k]++;
+                    }
+                  }
+                }
+                const u32 incl = wave_incl_scan_u32(m[k], lane);
+                excl[k] = incl - m[k];
+                pre[k] = total;
+                total += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+              }
+              j0 += kWave * PR;
+            }
+            if (lane == 0) sm.wtot[wv] = total | (have ? 0x80000000u : 0u);
+            __syncthreads();
+            const u32 wt = (u32)lane < NW ? sm.wtot[lane] : 0u;
+            if (__ballot(wt & 0x80000000u) == 0) break;  // no wave had a group: the item is done (same answer in every wave)
+            const u32 wn = wt & 0x7FFFFFFFu;
+            const u32 wincl = wave_incl_scan_u32(wn, lane);
+            const u32 all = (u32)__builtin_amdgcn_readlane((int)wincl, (int)NW - 1);
+            const u32 mine = (u32)__shfl((int)(wincl - wn), (int)wv, kWave);
+            if (tid == 0 && all) sm.obase = atomicAdd(reinterpret_cast<unsigned long long*>(&a.accum[ACC_N]), (unsigned long long)all);
+            __syncthreads();
+            if (total == 0) continue;  // (uniform per wave; every wave still takes both barriers of every round)
+            const u64 ob = sm.obase + mine;
+            if (ob + total > a.out_cap) {  // more result rows than the caller's columns hold (duplicate build keys): not written
+              if (lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(&a.accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
+              continue;
+            }
+#pragma unroll
+            for (int k = 0; k < (int)PR; k++) {
+              if (m[k]) {
+                u64 o = ob + pre[k] + excl[k];
+                const u64 key = t[k].key, sval = t[k].val;
+                if (FIRST) {
+                  const u64 rval = R[(u64)rb + first[k]].val;
+                  a.out_key[o] = key;
+                  a.out_rval[o] = rval;
+                  a.out_sval[o] = sval;
+                  acc_r += rval;
+                  acc_s += sval;
+                  if (EXTRA) {
+                    const u64 mx = tmix(key, rval, sval);
+                    acc_x ^= mx;
+                    acc_m += mx;
+                  }
+                } else {
+                  for (u32 n = first[k]; n != NIL; n = sm.aux[n]) {
+                    const u64 rval = sm.val[n];
+                    a.out_key[o] = key;
+                    a.out_rval[o] = rval;
+                    a.out_sval[o] = sval;
+                    o++;
+                    acc_r += rval;
+                    acc_s += sval;
+                    if (EXTRA) {
+                      const u64 mx = tmix(key, rval, sval);
+                      acc_x ^= mx;
+                      acc_m += mx;
+                    }
+                  }
+                }
+              }
+            }
+          }
+        } else if (npieces) {
           // a wave per piece (pieces are a few hundred to a few thousand contiguous rows), eight rows per lane in flight.
           // The piece counts come in 64 at a time, one per lane (a count read per piece put a dependent global load --
           // a microsecond -- in front of every few hundred rows), and are handed out by readlane.
-          constexpr u32 NW = PB_THREADS / kWave, PR = 8;
+          constexpr u32 NW = PB_THREADS / kWave, PR = EXTRA ? 4 : 8;  // (with the checksum accumulators eight rows in flight spill: 96 bytes of scratch per lane)
           const u32 wv = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
           for (u32 pb = 0; pb < npieces; pb += kWave) {
             const u32 cnt_l = pb + (u32)lane < npieces ? a.s_cnt[piece0 + pb + lane] : 0u;
@@ -350,7 +473,7 @@ __global__ __launch_bounds__(PB_THREADS, PB_THREADS / 256) void probe_kernel(Pro
       first_table = false;
     }
 
-    acc_n += pc;
+    if (MODE != 3) acc_n += pc;  // (MODE 3: accum[ACC_N] is the output cursor, complete as it is)
     if (MODE == 1) {
       u64 ws = wave_sum_u64(pc);
       if (lane == 0 && ws) atomicAdd(&sm.pcount, ws);
@@ -2205,7 +2328,7 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
   if (grid < 1) grid = 1;
   // probe side in slabs (probe-heavy count joins): item w = p * Q + q is piece w -- count w, rows [w * cap, + count)
   if (a.s_ppi) {  // pieces of one slab pass: P * s_wa pieces, Q items of s_ppi pieces cover a partition's s_wa
-    if (!a.s_cnt || mode != 0 || (first_wins && !a.matched) || a.s_wa == 0 || (u64)a.P * a.s_wa * a.s_cap > 0xFFFFFFFFull || (u64)a.Q * a.s_ppi < a.s_wa || (u64)(a.Q - 1) * a.s_ppi >= a.s_wa ||
+    if (!a.s_cnt || (mode != 0 && mode != 3) || (mode == 3 && (!a.out_key || !a.out_rval || !a.out_sval || a.out_cap == 0)) || (first_wins && !a.matched) || a.s_wa == 0 || (u64)a.P * a.s_wa * a.s_cap > 0xFFFFFFFFull || (u64)a.Q * a.s_ppi < a.s_wa || (u64)(a.Q - 1) * a.s_ppi >= a.s_wa ||
         a.s_cnt_n < (u64)a.P * a.s_wa || a.s_rows < (u64)a.P * a.s_wa * a.s_cap)
       return hipErrorInvalidValue;
   } else if (a.s_cnt && (a.s_cnt_n < (u64)a.P * a.Q || a.s_rows < (u64)a.P * a.Q * a.s_cap || (u64)a.P * a.Q * a.s_cap > 0xFFFFFFFFull))
@@ -2217,8 +2340,11 @@ hipError_t launch_probe(const ProbeArgs& a, int mode, bool first_wins, bool extr
   else                                                                           \
     return extra ? launch_probe_t<M, false, true>(a, grid, st)                   \
                  : launch_probe_t<M, false, false>(a, grid, st);
+  if (mode == 3 && !a.s_ppi) return hipErrorInvalidValue;  // (count + write by cursor exists for the piece walk only)
   if (mode == 0) {
     HMJ_DISPATCH(0)
+  } else if (mode == 3) {
+    HMJ_DISPATCH(3)
   } else if (mode == 1) {
     HMJ_DISPATCH(1)
   } else {

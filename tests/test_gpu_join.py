@@ -1215,8 +1215,40 @@ def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
                 assert r.checks() == ckf and ex.last_timing()["radix_bits"] == 5
             finally:
                 ex.set_radix_bits(None)
-        ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE)
+        # unordered materialising joins: counted and written in the same walk, a workgroup's rows of a round behind one
+        # add on the output cursor -- as long as the result fits the columns reserved (one row per probe row)
+        ck, rows = oracle.equijoin(B, P)
+        _, rowsf = oracle.equijoin(B, P, first_wins=True)
+        for fl, want_ck, want_rows in ((H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, ck, rows), (H.HMJ_MATERIALIZE, ck, rows),
+                                       (H.HMJ_MATERIALIZE | H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE, ckf, rowsf)):
+            r = ex.join_device(Bd, Pd, fl)
+            assert ck["n_matches"] > npb or ex.last_timing()["path"] & ONE, (nb, npb, dup, fl, hex(ex.last_timing()["path"]))
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (want_ck["n_matches"], want_ck["sum_r"], want_ck["sum_s"]), (nb, npb, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == want_ck
+            assert np.array_equal(sorted_rows(ex.columns_to_numpy(r, host=False)), want_rows), (nb, npb, dup, fl)
+        ex.join_device(Bd, Pd, H.HMJ_ORDERED)
         assert not ex.last_timing()["path"] & ONE
+        ex.release_result()
+    # duplicate build keys under every probe row: twice as many result rows as the columns reserved hold -> nothing is lost,
+    # the general passes run instead (same rows) and the cursor form is left alone for the next 8 materialising joins
+    nb, npb = 300000, 1 << 22
+    B = oracle.gen_build(nb)
+    B[1::2, 0] = B[0::2, 0]
+    P = oracle.gen_uniform_domain(npb, nb)
+    P[:, 0] = B[0::2, 0][np.random.default_rng(5).integers(0, nb // 2, npb)]
+    ck, rows = oracle.equijoin(B, P)
+    assert ck["n_matches"] == 2 * npb
+    Bd, Pd = to_dev(B), to_dev(P)
+    for i in range(10):
+        r = ex.join_device(Bd, Pd, H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM)
+        assert r.checks() == ck and not ex.last_timing()["path"] & ONE, i
+        if i == 0:
+            assert np.array_equal(sorted_rows(ex.columns_to_numpy(r, host=False)), rows)
+    r = ex.join_device(Bd, Pd, H.HMJ_CHECKSUM)
+    assert r.checks() == ck and ex.last_timing()["path"] & ONE  # (count joins are not held back by it)
+    ex.release_result()
+    del Bd, Pd
     # a hot foreign key: half of the probe rows carry one key -> one digit's slabs overflow -> exact path, same answer
     nb, npb = 300000, 1 << 22
     B, P = oracle.gen_build(nb), oracle.gen_uniform_domain(npb, nb)
@@ -1450,6 +1482,11 @@ def test_dense_dimension_ids_with_foreign_keys(ex_fresh, H, oracle):
     # and an unordered result with unmatched rows is compacted, not sorted.  (Round 3 found this shape 18 x slower than
     # uniform keys: tools/exp_cliffs*.py.)
     ex = ex_fresh
+    os.environ["HMJ_ONE_PASS_SLAB"] = "0"
+    try:
+        ex_two_pass = H.Executor(0)
+    finally:
+        del os.environ["HMJ_ONE_PASS_SLAB"]
     nb, npb = (1 << 18) + 9, (1 << 22) + 5
     rng = np.random.default_rng(31)
     B = np.stack([rng.permutation(nb).astype(np.uint64), np.arange(nb, dtype=np.uint64) * np.uint64(3)], 1)
@@ -1463,16 +1500,21 @@ def test_dense_dimension_ids_with_foreign_keys(ex_fresh, H, oracle):
             ex.set_profiling(False)
             assert r.checks() == ck and np.array_equal(ex.columns_to_numpy(r, host=False), rows)
         assert t["path"] & H.HMJ_PATH_SORTED_FK and not (t["path"] & H.HMJ_PATH_SPLIT) and t["ms_order"] == 0.0, hex(t["path"])
-        ex.set_profiling(True)
-        r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM)
-        t = ex.last_timing()
-        ex.set_profiling(False)
-        got = ex.columns_to_numpy(r, host=False)
-        assert r.checks() == ck and t["path"] & H.HMJ_PATH_UNIQ_WRITE, hex(t["path"])
-        order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
-        assert np.array_equal(got[order], rows)
+        # unordered: rows behind a cursor in the walk over the probe side's one slab pass (round 4) -- and, where that form
+        # is off, the partitioned path's compacting write
+        for e, bit in ((ex, H.HMJ_PATH_SLAB_ONE_PASS), (ex_two_pass, H.HMJ_PATH_UNIQ_WRITE)):
+            e.set_profiling(True)
+            r = e.join_device(to_dev(B), to_dev(P), H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM)
+            t = e.last_timing()
+            e.set_profiling(False)
+            got = e.columns_to_numpy(r, host=False)
+            assert r.checks() == ck and t["path"] & bit, hex(t["path"])
+            order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
+            assert np.array_equal(got[order], rows)
+            e.release_result()
         assert ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM).checks() == ck
         ex.release_result()
+    ex_two_pass.close()
 
 
 def test_one_pass_ordered_write_gives_up_on_clustered_keys(ex_fresh, H, oracle):
