@@ -1213,6 +1213,13 @@ def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
             try:
                 r = ex.join_device(Bd, Pd, H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM)
                 assert r.checks() == ckf and ex.last_timing()["radix_bits"] == 5
+                # ... and rows written from several tables per partition (first-wins: a probe row pairs once, in the first
+                # table that holds its key; otherwise every table adds its matches)
+                for fl, want in ((H.HMJ_MATERIALIZE | H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM, ckf), (H.HMJ_MATERIALIZE | H.HMJ_CHECKSUM, oracle.equijoin(B, P, cap=0)[0])):
+                    r = ex.join_device(Bd, Pd, fl)
+                    assert r.checks() == want and ex.last_timing()["radix_bits"] == 5 and ex.last_timing()["path"] & ONE, hex(fl)
+                    got = ex.columns_to_numpy(r, host=False)
+                    assert len(got) == want["n_matches"] and int(got[:, 1].sum(dtype=np.uint64)) == want["sum_r"]
             finally:
                 ex.set_radix_bits(None)
         # unordered materialising joins: counted and written in the same walk, a workgroup's rows of a round behind one
