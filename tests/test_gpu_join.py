@@ -1481,6 +1481,45 @@ def test_one_pass_ordered_write(ex_part_fresh, H, oracle):
     assert not (t["path"] & H.HMJ_PATH_SORTED_WRITE)
 
 
+def test_long_foreign_key_runs(ex_part_fresh, H, oracle):
+    # Foreign-key joins with tens to a thousand probe rows per build key: the one-pass ordered write ranks a payload inside
+    # its key's run by reading the run.  Run lengths around the kernel's eight-at-a-time ranking loop and far above it,
+    # payloads with duplicates inside a run (identical result rows) and payloads in descending input order; with and
+    # without the composite sort that takes high fan-outs (HMJ_GTABLE_SORT); against the oracle's rows.
+    ex = ex_part_fresh
+    os.environ["HMJ_GTABLE_SORT"] = "0"
+    try:
+        e2 = H.Executor(0)
+    finally:
+        del os.environ["HMJ_GTABLE_SORT"]
+    rng = np.random.default_rng(99)
+    seen = 0
+    for nb, fan in [(3000, 60), (1 << 14, 70), (1 << 13, 130), (4096, 300), (1100, 1000), (5000, 97)]:
+        npb = nb * fan + 13
+        B = oracle.gen_build(nb)
+        P = oracle.gen_uniform_domain(npb, nb)
+        variants = [P.copy()]
+        Pd = P.copy()
+        Pd[:, 1] = rng.integers(0, 50, npb).astype(np.uint64)  # a handful of payload values: many ties in every run
+        variants.append(Pd)
+        Pr = P.copy()
+        Pr[:, 1] = np.arange(npb, 0, -1, dtype=np.uint64)  # descending in input order
+        variants.append(Pr)
+        for V in variants:
+            ck, rows = oracle.equijoin(B, V)
+            for e in (ex, e2):
+                e.set_profiling(True)
+                r = e.join_device(to_dev(B), to_dev(V), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+                t = e.last_timing()
+                e.set_profiling(False)
+                seen |= t["path"]
+                assert r.checks() == ck, (nb, fan)
+                assert np.array_equal(e.columns_to_numpy(r, host=False), rows), (nb, fan, hex(t["path"]))
+                e.release_result()
+    e2.close()
+    assert seen & H.HMJ_PATH_SORTED_FK, hex(seen)
+
+
 def test_dense_dimension_ids_with_foreign_keys(ex_fresh, H, oracle):
     # the everyday shape: a dimension table with ids 0 .. n - 1 (n a little above a power of two, shuffled) and a fact
     # table whose foreign keys are drawn from the ids -- or from a range a quarter wider (unmatched rows).  The ids fill

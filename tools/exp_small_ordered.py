@@ -28,9 +28,7 @@ def timed(e, R, S, fl, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3, r
 
 
-for k in range(8, 20, 1):
-    if (1 << k) * 2 > (1 << P):
-        break
+for k in range(8, min(P - 3, 25), 1):
     R, S = ex0.gen_build(1 << k), ex0.gen_uniform_domain(1 << P, 1 << k)
     fl = H.HMJ_ORDERED | H.HMJ_CHECKSUM
     m0, r0 = timed(ex0, R, S, fl)
