@@ -1762,13 +1762,16 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     return HMJ_OK;
   {
     // Which is faster is a matter of fan-out AND size (profiles/r04i_*, r04l_*: both paths over a grid of sizes).  This path:
-    // ~0.65 ms of dependent launches and read-backs + 0.084 ns per probe row (0.10 where the table leaves the L2).  The
+    // ~0.65 ms of dependent launches and read-backs + 0.06-0.09 ns per probe row (below).  The
     // partitioned one-pass ordered write: ~0.15 ms + (0.030 + 0.00023 f) ns per row up to fan-out ~200, 0.00041 f ns beyond
     // (the plan changes), and from ~700 rows per key on it declines (runs beyond its capacity) and the write + order
     // epilogue takes over at 0.25 ns per row and more.  HMJ_GTABLE_SORT_FANOUT=1 (the experiments) skips the model.
     const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
     const double part_ns = f < 200.0 ? 0.030 + 0.00023 * f : f <= 700.0 ? 0.00041 * f : 0.25;
-    const double rank_ns = n_build > 2 * c->gtable_max_rows ? 0.10 : 0.084;
+    // (round 4, later: 0.060 where the composites' passes are the chain of slab passes below, 0.072 on exact passes, + 0.02
+    //  where the table leaves the L2 -- profiles/r04p_side_rank_sort_slab_chain.txt)
+    const bool chain = c->gtable_sort_slab && c->slab_mode && c->gtable_sort_slab_cooldown == 0 && n_probe >= c->gtable_sort_slab_min;
+    const double rank_ns = (chain ? 0.060 : 0.072) + (n_build > c->gtable_max_rows ? 0.02 : 0.0);
     if (c->gtable_sort_fanout > 1 && 0.65 + rank_ns * rows >= 0.15 + part_ns * rows) return HMJ_OK;
   }
   if (c->gtable_sort_cooldown > 0) {
@@ -1877,7 +1880,106 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     }
     return HMJ_OK;
   };
-  if (!wide) {
+  // The narrow form's passes as a CHAIN of histogram-free slab passes (32 instead of 48 B per row and pass): pass 1 is slab
+  // pass A over the dense composites (<= 512 workers), every later pass is slab pass B -- whose input IS "the worker-private
+  // slabs [digit][worker] of the pass before" and whose output has the same shape, [digit][worker'] with worker' = (previous
+  // digit, k) -- so it chains into itself; the stable order of a pass's output is the order of its pieces in memory.  The
+  // last pass's pieces are expanded in place (gtable_expand_pieces_kernel).  Slab capacities assume evenly filled digits
+  // (row ids, dense ranks); the digits that hold the payload range's and the rank's top bits are sized for how much of their
+  // range is in use.  An overflow (skewed payload bits, a hot key) raises ERR_SLAB: the exact passes run from the dense
+  // composites, which the chain has not touched, and the chain is left alone for the next 8 such joins.
+  u32 pc_n = 0, pc_cap = 0;  // the sorted composites as pieces (pc_n != 0): c->slab_* / c->cnt_* [pc_which]
+  int pc_which = 0;
+  if (c->gtable_sort_slab_cooldown > 0 && !wide) c->gtable_sort_slab_cooldown--;
+  else if (!wide && c->slab_mode && c->gtable_sort_slab && n >= c->gtable_sort_slab_min && rank_bits + range_bits > 0) {
+    const int total = rank_bits + range_bits;
+    const int passes = (total + hmj::RP_MAX_BITS - 1) / hmj::RP_MAX_BITS;
+    const double dens_range = range_bits ? std::ldexp(1.0, range_bits) / ((double)(svmax - svmin) + 1.0) : 1.0;
+    const double dens_rank = rank_bits ? std::ldexp(1.0, rank_bits) / (double)nb : 1.0;
+    DevBuf* sl[2] = {&c->slab_a, &c->slab_bs};
+    DevBuf* cn[2] = {&c->cnt_a, &c->cnt_bs};
+    u64* acc = (u64*)c->accum.p;
+    u32 W = 0, C = 0;
+    int bprev = 0, shift = 0;
+    double dens_prev = 1.0;
+    bool ok = true;
+    for (int i = 0; i < passes && ok; i++) {
+      const int bits = total / passes + (i < total % passes ? 1 : 0);
+      double dens = 1.0;
+      if (range_bits && shift <= range_bits - 1 && range_bits - 1 < shift + bits) dens *= dens_range;
+      if (rank_bits && i == passes - 1) dens *= dens_rank;
+      const int sp2 = span_begin(c, K_SCATTER, 1, i);
+      if (i == 0) {
+        hmj::SlabGeom g;
+        if (!hmj::slab_geometry_one_pass((u32)n, bits, 1e18, 512, &g, dens)) {
+          ok = false;
+        } else {
+          if ((rc = ensure_dev(c, *sl[0], g.rows_a * 16)) != HMJ_OK) return rc;
+          if ((rc = ensure_dev(c, *cn[0], ((size_t)g.WA << bits) * 4)) != HMJ_OK) return rc;
+          HIP_TRY(hmj::launch_slab_a(c->sbuf[0].p, (u32)n, 0, bits, g, sl[0]->p, sl[0]->cap / 16, (u32*)cn[0]->p, cn[0]->cap / 4, acc, c->stream));
+          W = g.WA;
+          C = g.CA;
+        }
+      } else {
+        hmj::SlabGeom g;
+        std::memset(&g, 0, sizeof(g));
+        g.WA = W;
+        g.CA = C;
+        g.KB = 512u >> bprev;  // 512 workers again, whatever the last digit's width
+        if (g.KB < 1) g.KB = 1;
+        if (g.KB > W) g.KB = W;
+        const u32 Wn = g.KB << bprev;
+        // (a pass-B worker belongs to ONE value of the previous digit: where that digit fills only part of its range, the
+        //  workers of the values in use carry dens_prev x the mean, and so do their slabs)
+        g.CB = hmj::slab_capacity(dens * dens_prev * (double)n / ((double)Wn * (double)(1u << bits)), 1.0);
+        const u64 pieces = (u64)Wn << bits;
+        if (pieces * g.CB >= 0xFFFFFFF0ull) {
+          ok = false;
+        } else {
+          DevBuf& so = *sl[i & 1];
+          DevBuf& co = *cn[i & 1];
+          if ((rc = ensure_dev(c, so, pieces * g.CB * 16)) != HMJ_OK) return rc;
+          if ((rc = ensure_dev(c, co, pieces * 4)) != HMJ_OK) return rc;
+          HIP_TRY(hmj::launch_slab_b(sl[(i - 1) & 1]->p, (const u32*)cn[(i - 1) & 1]->p, bprev, shift, bits, g, so.p, so.cap / 16,
+                                     (u32*)co.p, co.cap / 4, acc, c->stream));
+          W = Wn;
+          C = g.CB;
+        }
+      }
+      span_end(c, sp2);
+      if (ok) {
+        c->timing.bytes_scatter += 32ull * n;
+        bprev = bits;
+        dens_prev = dens;
+        shift += bits;
+        n_passes++;
+        pc_which = i & 1;
+      }
+    }
+    if (ok) {
+      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) ok = false;
+    }
+    if (ok) {
+      pc_n = W << bprev;
+      pc_cap = C;
+      c->timing.path |= HMJ_PATH_SLAB;
+    } else {  // back to the exact passes (the composites in sbuf[0] are untouched)
+      c->gtable_sort_slab_cooldown = 8;
+      HIP_TRY(hipMemsetAsync((u64*)c->accum.p + hmj::ACC_ERR, 0, sizeof(u64), c->stream));
+      std::vector<Span> keep;
+      for (const Span& s2 : c->spans)
+        if (s2.kind != K_SCATTER) keep.push_back(s2);
+      c->spans.swap(keep);
+      c->timing.bytes_scatter = 0;
+      n_passes = 0;
+      if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: a slab of the composite sort's chain overflowed -> exact passes\n", nb, np);
+    }
+  }
+  if (pc_n) {
+    // (sorted: the pieces of the chain's last pass)
+  } else if (!wide) {
     if ((rc = lsd(rank_bits + range_bits)) != HMJ_OK) return rc;
   } else {
     if ((rc = lsd(range_bits)) != HMJ_OK) return rc;  // {payload, rank} by payload
@@ -1895,8 +1997,18 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     if ((rc = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return rc;
     sp = span_begin(c, K_PROBE_WRITE, -1);
-    HIP_TRY(hmj::launch_gtable_expand(sorted, n, sortedR, svmin, range_bits, (u64*)c->out_key.p, (u64*)c->out_rval.p,
-                                      (u64*)c->out_sval.p, (u64*)c->accum.p, extra, wide, c->num_cus, c->stream));
+    if (pc_n) {
+      DevBuf& so = pc_which ? c->slab_bs : c->slab_a;
+      DevBuf& co = pc_which ? c->cnt_bs : c->cnt_a;
+      if ((rc = ensure_dev(c, c->piece_off, (size_t)pc_n * 8)) != HMJ_OK) return rc;
+      HIP_TRY(hmj::launch_piece_offsets((const u32*)co.p, pc_n, (u64*)c->piece_off.p, c->stream));
+      HIP_TRY(hmj::launch_gtable_expand_pieces(so.p, (const u32*)co.p, (const u64*)c->piece_off.p, pc_n, pc_cap, sortedR, svmin, range_bits,
+                                               (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, (u64*)c->accum.p, extra,
+                                               c->num_cus, c->stream));
+    } else {
+      HIP_TRY(hmj::launch_gtable_expand(sorted, n, sortedR, svmin, range_bits, (u64*)c->out_key.p, (u64*)c->out_rval.p,
+                                        (u64*)c->out_sval.p, (u64*)c->accum.p, extra, wide, c->num_cus, c->stream));
+    }
     span_end(c, sp);
     HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2023,6 +2135,11 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_GTABLE_FANOUT")) c->gtable_min_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;
   if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
+  if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB")) c->gtable_sort_slab = atoi(e) != 0;  // 0: the composites' LSD passes are exact passes (hist + scan + scatter)
+  if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB_MIN_LOG2")) {
+    const int l = atoi(e);
+    if (l >= 12 && l <= 32) c->gtable_sort_slab_min = 1ull << l;
+  }
   if (const char* e = getenv("HMJ_GTABLE_SORT_FANOUT")) c->gtable_sort_fanout = atoi(e) > 0 ? (u32)atoi(e) : 1u;
   if (const char* e = getenv("HMJ_GTABLE_SLOTS")) c->gtable_slots_per_row = atoi(e) >= 2 ? (u32)atoi(e) : 2u;
   if (const char* e = getenv("HMJ_GTABLE_MAX_LOG_CAP")) c->gtable_max_log_cap = atoi(e);
@@ -2094,7 +2211,7 @@ void hmj_destroy(hmj_ctx* c) {
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
                     &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched, &c->vparts,
-                    &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs, &c->lookback, &c->gtab};
+                    &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs, &c->lookback, &c->gtab, &c->piece_off};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);

@@ -453,6 +453,100 @@ __global__ __launch_bounds__(256) void gtable_expand_kernel(const Tup* __restric
   block_accumulate(red, accum, v, 1u << ACC_XOR);
 }
 
+// ---- the same, from the worker-private slabs of a chain of histogram-free slab passes (api.hip, try_small_build_ordered) ------
+// off[i] = cnt[0] + ... + cnt[i - 1]: one workgroup, a contiguous share of the counts per thread (a few hundred thousand counts).
+__global__ __launch_bounds__(1024) void piece_offsets_kernel(const u32* __restrict__ cnt, u32 n, u64* __restrict__ off) {
+  __shared__ u64 wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const u32 per = (n + 1023u) / 1024u, b = (u32)tid * per, e = b + per < n ? b + per : n;
+  u64 s = 0;
+  for (u32 i = b; i < e; i++) s += cnt[i];
+  u64 incl = s;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const u64 up = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += up;
+  }
+  if (lane == kWave - 1) wtot[wv] = incl;
+  __syncthreads();
+  u64 before = 0;
+  for (int w2 = 0; w2 < wv; w2++) before += wtot[w2];
+  u64 run = before + incl - s;
+  for (u32 i = b; i < e; i++) {
+    off[i] = run;
+    run += cnt[i];
+  }
+}
+
+// a wave walks a contiguous range of pieces (counts and offsets fetched 64 at a time, one per lane, handed out by readlane)
+template <bool EXTRA>
+__global__ __launch_bounds__(256) void gtable_expand_pieces_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt,
+                                                                   const u64* __restrict__ off, u32 n_pieces, u32 cap, u32 ppw,
+                                                                   const Tup* __restrict__ sortedR, u64 svmin, int range_bits,
+                                                                   u64* __restrict__ out_key, u64* __restrict__ out_rval,
+                                                                   u64* __restrict__ out_sval, u64* __restrict__ accum) {
+  __shared__ u64 red[8];
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
+  const int lane = threadIdx.x & 63;
+  const u64 lowmask = range_bits >= 64 ? ~0ull : ((1ull << range_bits) - 1);
+  u64 acc_r = 0, acc_x = 0, acc_m = 0;
+  const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const u64 p0 = (u64)wave * ppw;
+  const u32 p1 = p0 + ppw < n_pieces ? (u32)(p0 + ppw) : n_pieces;
+  for (u64 pb = p0; pb < p1; pb += kWave) {
+    const u32 c_l = pb + lane < p1 ? cnt[pb + lane] : 0u;
+    const u64 o_l = pb + lane < p1 ? off[pb + lane] : 0ull;
+    const u32 pe = p1 - pb < (u64)kWave ? (u32)(p1 - pb) : (u32)kWave;
+    for (u32 pi = 0; pi < pe; pi++) {
+      const u32 c = (u32)__builtin_amdgcn_readlane((int)c_l, (int)pi);
+      const u64 o = ((u64)(u32)__builtin_amdgcn_readlane((int)(o_l >> 32), (int)pi) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)o_l, (int)pi);
+      const Tup* __restrict__ base = slabs + (pb + pi) * cap;
+      for (u32 r = (u32)lane; r < c; r += kWave) {
+        const u64 comp = load_stream(&base[r]).key;
+        const Tup b = sortedR[range_bits >= 64 ? 0ull : comp >> range_bits];
+        const u64 sv = (comp & lowmask) + svmin;
+        out_key[o + r] = b.key;
+        out_rval[o + r] = b.val;
+        out_sval[o + r] = sv;
+        acc_r += b.val;
+        if (EXTRA) {
+          const u64 mx = tmix(b.key, b.val, sv);
+          acc_x ^= mx;
+          acc_m += mx;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const u64 v[6] = {0, acc_r, 0, acc_x, acc_m, 0};
+  block_accumulate(red, accum, v, 1u << ACC_XOR);
+}
+
+hipError_t launch_piece_offsets(const u32* cnt, u32 n_pieces, u64* off, hipStream_t st) {
+  if (!cnt || !off || n_pieces == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(piece_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, n_pieces, off);
+  return hipGetLastError();
+}
+
+hipError_t launch_gtable_expand_pieces(const void* slabs, const u32* cnt, const u64* off, u32 n_pieces, u32 cap, const void* sortedR,
+                                       u64 svmin, int range_bits, u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra,
+                                       int num_cus, hipStream_t st) {
+  if (!slabs || !cnt || !off || !sortedR || !out_key || !out_rval || !out_sval || n_pieces == 0 || cap == 0 || range_bits < 0 ||
+      range_bits > 64)
+    return hipErrorInvalidValue;
+  u32 waves = (u32)num_cus * 32u;  // eight workgroups of four waves per CU
+  if (waves > n_pieces) waves = n_pieces;
+  const u32 ppw = (n_pieces + waves - 1) / waves;
+  const u32 grid = ((n_pieces + ppw - 1) / ppw + 3) / 4;
+  if (extra)
+    hipLaunchKernelGGL((gtable_expand_pieces_kernel<true>), dim3(grid), dim3(256), 0, st, static_cast<const Tup*>(slabs), cnt, off, n_pieces,
+                       cap, ppw, static_cast<const Tup*>(sortedR), svmin, range_bits, out_key, out_rval, out_sval, accum);
+  else
+    hipLaunchKernelGGL((gtable_expand_pieces_kernel<false>), dim3(grid), dim3(256), 0, st, static_cast<const Tup*>(slabs), cnt, off, n_pieces,
+                       cap, ppw, static_cast<const Tup*>(sortedR), svmin, range_bits, out_key, out_rval, out_sval, accum);
+  return hipGetLastError();
+}
+
 hipError_t launch_gtable_build(const void* R, u32 nb, void* tab, int log_cap, u64* accum, bool first, int num_cus,
                                hipStream_t st) {
   if (log_cap < 4 || log_cap > 30 || ((u64)1 << log_cap) < (u64)nb + nb / 4 + 1) return hipErrorInvalidValue;  // (load factor <= 0.8: walks must end)

@@ -45,7 +45,7 @@ struct hmj_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
       out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
-      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback, gtab;
+      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback, gtab, piece_off;
   HostBuf h_accum, h_key, h_rval, h_sval;
   int host_threads = 0;  // staging threads for pageable input (0 = default)
   std::vector<hipStream_t> up_streams;
@@ -103,6 +103,9 @@ struct hmj_ctx {
   bool gtable_sort_mode = true;    // HMJ_GTABLE_SORT=0: ordered joins of a small build side under a long probe side stay partitioned
   u32 gtable_sort_fanout = 128;    // ... from this many probe rows per build row on (HMJ_GTABLE_SORT_FANOUT)
   int gtable_sort_cooldown = 0;
+  bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
+  u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
+  int gtable_sort_slab_cooldown = 0;  // joins to keep on the exact passes after a slab of the chain overflowed (skewed digits)
   int gtable_write_cooldown = 0;   // materialising joins to skip it for after one met duplicate build keys
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged

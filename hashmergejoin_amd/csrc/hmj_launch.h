@@ -59,7 +59,9 @@ struct SlabGeom {
 bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb = 0, double fan = 1.0, double density = 1.0);
 // one slab pass only (its worker-private slabs are what the probe kernel reads): workers, rows per worker, slab capacity.
 // keys_per_digit: distinct keys a digit holds on average (the digit's share of a worker's rows varies with it)
-bool slab_geometry_one_pass(u32 n, int bits, double keys_per_digit, u32 max_workers, SlabGeom* g);
+bool slab_geometry_one_pass(u32 n, int bits, double keys_per_digit, u32 max_workers, SlabGeom* g, double density = 1.0);
+// rows a slab holds for `mean` expected rows whose count varies like fan * (a Poisson count): mean + 8 sigma + slack
+u32 slab_capacity(double mean, double fan);
 // slab_*_rows / cnt_*_n: what the caller ALLOCATED (rows of 16 bytes, u32 entries).  The launchers compare them with
 // what the kernel and its grid will touch for this geometry and refuse (hipErrorInvalidValue) instead of launching
 // a kernel that would write past a buffer.
@@ -152,6 +154,13 @@ hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_ca
 hipError_t launch_gtable_swap(const void* in, void* out, u64 n, int num_cus, hipStream_t st);
 hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u64 svmin, int range_bits, u64* out_key,
                                 u64* out_rval, u64* out_sval, u64* accum, bool extra, bool wide, int num_cus, hipStream_t st);
+// Sorted composites that lie in the worker-private slabs of a chain of slab passes (piece i = rows [i * cap, + cnt[i]); the
+// sorted order is the order of the pieces): launch_piece_offsets gives every piece its first result row (exclusive scan of
+// the counts), launch_gtable_expand_pieces turns the pieces into result rows.
+hipError_t launch_piece_offsets(const u32* cnt, u32 n_pieces, u64* off, hipStream_t st);
+hipError_t launch_gtable_expand_pieces(const void* slabs, const u32* cnt, const u64* off, u32 n_pieces, u32 cap, const void* sortedR,
+                                       u64 svmin, int range_bits, u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra,
+                                       int num_cus, hipStream_t st);
 
 // gen.hip
 hipError_t launch_gen_build(void* out, u64 n, u64 start, u64 seed, hipStream_t st);

@@ -1275,6 +1275,7 @@ static u32 slab_cap(double mean, double fan) {
   double c = mean + 8.0 * __builtin_sqrt(fan * mean) + 24.0;
   return ((u32)c + 8) & ~7u;
 }
+u32 slab_capacity(double mean, double fan) { return slab_cap(mean, fan < 1.0 ? 1.0 : fan); }
 bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fan, double density) {
   if (bits_a < 1 || bits_a > SLAB_MAX_BITS || bits_b < 1 || bits_b > SLAB_MAX_BITS) return false;
   const u32 tile = bits_a > 8 ? 4096 : 2048;  // pass A's tile: a worker owns whole tiles (its last one may be ragged)
@@ -1305,7 +1306,7 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fa
 // fall into digit d with probability p_d = (keys of d) / (all keys); p_d varies over the digits like a Poisson count of
 // keys_per_digit, so a slab's row count has variance mean + mean^2 / keys_per_digit (sampling noise + key-count noise) --
 // NOT fan-out x mean, which is the spread of a digit's rows over the WHOLE relation.
-bool slab_geometry_one_pass(u32 n, int bits, double keys_per_digit, u32 max_workers, SlabGeom* g) {
+bool slab_geometry_one_pass(u32 n, int bits, double keys_per_digit, u32 max_workers, SlabGeom* g, double density) {
   if (bits < 1 || bits > SLAB_MAX_BITS || max_workers == 0) return false;
   const u32 tile = bits > 8 ? 4096 : 2048;
   const u64 tiles = ((u64)n + tile - 1) / tile;
@@ -1316,7 +1317,8 @@ bool slab_geometry_one_pass(u32 n, int bits, double keys_per_digit, u32 max_work
   g->KB = 0;
   g->CB = 0;
   g->rows_b = 0;
-  const double mean = (double)g->rpw / (double)(1u << bits);
+  if (density < 1.0) density = 1.0;  // digits that fill 1 / density of their range: the filled ones hold density x the mean
+  const double mean = density * (double)g->rpw / (double)(1u << bits);
   if (keys_per_digit < 1.0) keys_per_digit = 1.0;
   g->CA = slab_cap(mean, 1.0 + mean / keys_per_digit);
   g->rows_a = (u64)(1u << bits) * g->WA * g->CA;

@@ -1176,6 +1176,56 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
         ex.release_result()
 
 
+def test_rank_payload_composites_sorted_by_a_chain_of_slab_passes(H, oracle):
+    # The composite sort's LSD passes as histogram-free slab passes: slab pass A over the dense composites, then slab pass B
+    # chained into itself (its input is "the worker-private slabs of the pass before", its output has the same shape), the last
+    # pass's pieces expanded in place (HMJ_PATH_SLAB beside HMJ_PATH_ORDER_BY_RANK_SORT).  Row sequences against the oracle:
+    # build sides that fill half of their top rank digit, payload ranges that fill part of their top digit, unmatched rows,
+    # four and five passes; payloads whose low bits never vary (every row in one digit of the first pass) and a hot key
+    # (one rank) overflow a slab -> the exact passes run from the untouched composites, the chain is left alone for 8 joins.
+    RS, SL = H.HMJ_PATH_ORDER_BY_RANK_SORT, H.HMJ_PATH_SLAB
+    os.environ["HMJ_GTABLE_SORT_FANOUT"] = "1"
+    os.environ["HMJ_GTABLE_SORT_SLAB_MIN_LOG2"] = "20"  # (default 2^25 composites: more than the oracle checks in seconds)
+    try:
+        ex = H.Executor(0)
+    finally:
+        del os.environ["HMJ_GTABLE_SORT_FANOUT"], os.environ["HMJ_GTABLE_SORT_SLAB_MIN_LOG2"]
+    rng = np.random.default_rng(78)
+    for nb, npb, miss, pay, chain in [(1000, (1 << 22) + 5, 0, "ids", True), (33000, 1 << 23, 4, "offset", True), (5, 3000000, 0, "ids", True),
+                                      (70000, 5000001, 0, "partial", True), (4097, 1 << 22, 0, "stride", False), (3000, 1 << 22, 0, "hot", False)]:
+        B = oracle.gen_build(nb)
+        P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
+        if pay == "ids":
+            P[:, 1] = rng.permutation(npb).astype(np.uint64)
+        elif pay == "offset":
+            P[:, 1] = np.uint64(0xFEDCBA9800000000) + rng.integers(0, 1 << 30, size=npb, dtype=np.uint64)
+        elif pay == "partial":  # the range's top digit is a third full
+            P[:, 1] = np.uint64(12345) + rng.integers(0, (1 << 25) + (1 << 23), size=npb, dtype=np.uint64)
+        elif pay == "stride":  # timestamps in steps of 1024: the first pass's digit is the same for every row
+            P[:, 1] = rng.permutation(npb).astype(np.uint64) * np.uint64(1024)
+        elif pay == "hot":
+            P[:, 1] = rng.permutation(npb).astype(np.uint64)
+            P[::2, 0] = B[77, 0]
+        Bd, Pd = to_dev(B), to_dev(P)
+        ck, rows = oracle.equijoin(B, P)
+        for i, fl in enumerate((H.HMJ_ORDERED, H.HMJ_ORDERED | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE)):
+            r = ex.join_device(Bd, Pd, fl)
+            t = ex.last_timing()
+            assert t["path"] & RS, (nb, npb, pay, hex(t["path"]))
+            assert bool(t["path"] & SL) == chain, (nb, npb, pay, i, hex(t["path"]))
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, pay, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck and int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
+            assert np.array_equal(ex.columns_to_numpy(r, host=False), rows), (nb, npb, pay, fl)
+        if not chain:  # the overflow leaves 8 joins on the exact passes: let them run out so the next case is asked again
+            for _ in range(8):
+                ex.join_device(Bd, Pd, H.HMJ_ORDERED)
+                assert not ex.last_timing()["path"] & SL
+        ex.release_result()
+        del Bd, Pd
+    ex.close()
+
+
 def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
     # A dimension table of 2^18 ... 2^20 rows under a fact table several times larger, count modes: ONE radix pass, and the
     # probe side's pass is the histogram-free slab pass A whose worker-private slabs the generic probe kernel walks piece
