@@ -1744,6 +1744,111 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   return HMJ_OK;
 }
 
+// Stable LSD passes over n dense 16-byte rows as a CHAIN of histogram-free slab passes (32 instead of 48 B per row and pass).
+// Pass 1 is slab pass A over the dense rows (<= 512 workers); every later pass is slab pass B launched with the geometry of the
+// pass before: B reads "the worker-private slabs [digit][worker] of the previous pass" -- worker (dA, k) gathers a run of the
+// pieces of previous digit dA -- and writes [digit'][worker'] with worker' = dA * KB + k: the same shape, so the kernel chains
+// into itself unchanged, and a pass's stable output order IS the order of its pieces in memory.  Result (*ok): *pc_n pieces of
+// *pc_cap rows each in c->slab_a / c->cnt_a (*pc_which == 0) or c->slab_bs / c->cnt_bs (1), in sorted order; the caller walks
+// or compacts them.  Slab capacities assume evenly filled digits; dg[i].dens >= 1 says how much fuller than the mean the
+// values in use of digit i are (a digit that holds the top bits of a range filled in part) -- it widens pass i's slabs AND pass
+// i + 1's, because a pass-B worker belongs to one value of the previous digit and the values in use carry all its rows.  Skew
+// the sizes do not cover overflows a slab: *ok = false, the input is untouched, the error word is cleared, the chain's spans
+// are dropped.  One read-back.
+struct ChainDigit {
+  int shift, bits;
+  double dens;
+};
+static int slab_chain(hmj_ctx* c, const void* dense_in, u32 n, const ChainDigit* dg, int nd, int rel, bool* ok_out, u32* pc_n,
+                      u32* pc_cap, int* pc_which) {
+  *ok_out = false;
+  *pc_n = 0;
+  int rc;
+  if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  DevBuf* sl[2] = {&c->slab_a, &c->slab_bs};
+  DevBuf* cn[2] = {&c->cnt_a, &c->cnt_bs};
+  u64* acc = (u64*)c->accum.p;
+  u64* hh = (u64*)c->h_accum.p;
+  u32 W = 0, C = 0;
+  int bprev = 0;
+  double dens_prev = 1.0;
+  bool ok = nd >= 1 && n > 0;
+  const u64 bytes_before = c->timing.bytes_scatter;
+  for (int i = 0; i < nd && ok; i++) {
+    const int bits = dg[i].bits, shift = dg[i].shift;
+    const double dens = dg[i].dens < 1.0 ? 1.0 : dg[i].dens;
+    const int sp2 = span_begin(c, K_SCATTER, rel, i);
+    if (i == 0) {
+      hmj::SlabGeom g;
+      if (!hmj::slab_geometry_one_pass(n, bits, 1e18, 512, &g, dens)) {
+        ok = false;
+      } else {
+        if ((rc = ensure_dev(c, *sl[0], g.rows_a * 16)) != HMJ_OK) return rc;
+        if ((rc = ensure_dev(c, *cn[0], ((size_t)g.WA << bits) * 4)) != HMJ_OK) return rc;
+        HIP_TRY(hmj::launch_slab_a(dense_in, n, shift, bits, g, sl[0]->p, sl[0]->cap / 16, (u32*)cn[0]->p, cn[0]->cap / 4, acc, c->stream));
+        W = g.WA;
+        C = g.CA;
+      }
+    } else {
+      hmj::SlabGeom g;
+      std::memset(&g, 0, sizeof(g));
+      g.WA = W;
+      g.CA = C;
+      g.KB = 512u >> bprev;  // 512 workers again, whatever the last digit's width
+      if (g.KB < 1) g.KB = 1;
+      if (g.KB > W) g.KB = W;
+      const u32 Wn = g.KB << bprev;
+      g.CB = hmj::slab_capacity(dens * dens_prev * (double)n / ((double)Wn * (double)(1u << bits)), 1.0);
+      const u64 pieces = (u64)Wn << bits;
+      if (pieces * g.CB >= 0xFFFFFFF0ull) {
+        ok = false;
+      } else {
+        DevBuf& so = *sl[i & 1];
+        DevBuf& co = *cn[i & 1];
+        if ((rc = ensure_dev(c, so, pieces * g.CB * 16)) != HMJ_OK) return rc;
+        if ((rc = ensure_dev(c, co, pieces * 4)) != HMJ_OK) return rc;
+        HIP_TRY(hmj::launch_slab_b(sl[(i - 1) & 1]->p, (const u32*)cn[(i - 1) & 1]->p, bprev, shift, bits, g, so.p, so.cap / 16,
+                                   (u32*)co.p, co.cap / 4, acc, c->stream));
+        W = Wn;
+        C = g.CB;
+      }
+    }
+    span_end(c, sp2);
+    if (ok) {
+      c->timing.bytes_scatter += 32ull * n;
+      bprev = bits;
+      dens_prev = dens;
+      *pc_which = i & 1;
+    }
+    // keys with many duplicates (a digit's row count then varies like rows-per-key x its key count) or digits that follow
+    // from one another show in the first two passes: look at the error word there instead of running a long chain to its end
+    if (ok && i == 1 && nd > 3) {
+      HIP_TRY(hipMemcpyAsync(hh, (u64*)c->accum.p + hmj::ACC_ERR, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hh[0] & hmj::ERR_SLAB) ok = false;
+    }
+  }
+  if (ok) {
+    HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) ok = false;
+  }
+  if (ok) {
+    *pc_n = W << bprev;
+    *pc_cap = C;
+  } else {
+    HIP_TRY(hipMemsetAsync((u64*)c->accum.p + hmj::ACC_ERR, 0, sizeof(u64), c->stream));
+    std::vector<Span> keep;
+    for (const Span& s2 : c->spans)
+      if (!(s2.kind == K_SCATTER && s2.rel == rel)) keep.push_back(s2);
+    c->spans.swap(keep);
+    c->timing.bytes_scatter = bytes_before;
+  }
+  *ok_out = ok;
+  return HMJ_OK;
+}
+
 // Ordered result of a SMALL build side under a LONG probe side (fan-outs in the hundreds and thousands: a dimension table of a
 // few thousand rows under a fact table), unique build keys.  The operator's order (key, rval, sval) is then the probe rows
 // sorted by (rank of their key among the sorted build keys, sval), and both fit one 64-bit sort key when the probe payloads
@@ -1880,14 +1985,10 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     }
     return HMJ_OK;
   };
-  // The narrow form's passes as a CHAIN of histogram-free slab passes (32 instead of 48 B per row and pass): pass 1 is slab
-  // pass A over the dense composites (<= 512 workers), every later pass is slab pass B -- whose input IS "the worker-private
-  // slabs [digit][worker] of the pass before" and whose output has the same shape, [digit][worker'] with worker' = (previous
-  // digit, k) -- so it chains into itself; the stable order of a pass's output is the order of its pieces in memory.  The
-  // last pass's pieces are expanded in place (gtable_expand_pieces_kernel).  Slab capacities assume evenly filled digits
-  // (row ids, dense ranks); the digits that hold the payload range's and the rank's top bits are sized for how much of their
-  // range is in use.  An overflow (skewed payload bits, a hot key) raises ERR_SLAB: the exact passes run from the dense
-  // composites, which the chain has not touched, and the chain is left alone for the next 8 such joins.
+  // The narrow form's passes as a chain of histogram-free slab passes (slab_chain above): 32 instead of 48 B per row and pass,
+  // the last pass's pieces expanded in place (gtable_expand_pieces_kernel).  The digits that hold the payload range's and the
+  // rank's top bits are sized for how much of their range is in use.  An overflow (skewed payload bits, a hot key): the exact
+  // passes run from the dense composites, which the chain has not touched, and the chain is left alone for the next 8 such joins.
   u32 pc_n = 0, pc_cap = 0;  // the sorted composites as pieces (pc_n != 0): c->slab_* / c->cnt_* [pc_which]
   int pc_which = 0;
   if (c->gtable_sort_slab_cooldown > 0 && !wide) c->gtable_sort_slab_cooldown--;
@@ -1896,84 +1997,23 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     const int passes = (total + hmj::RP_MAX_BITS - 1) / hmj::RP_MAX_BITS;
     const double dens_range = range_bits ? std::ldexp(1.0, range_bits) / ((double)(svmax - svmin) + 1.0) : 1.0;
     const double dens_rank = rank_bits ? std::ldexp(1.0, rank_bits) / (double)nb : 1.0;
-    DevBuf* sl[2] = {&c->slab_a, &c->slab_bs};
-    DevBuf* cn[2] = {&c->cnt_a, &c->cnt_bs};
-    u64* acc = (u64*)c->accum.p;
-    u32 W = 0, C = 0;
-    int bprev = 0, shift = 0;
-    double dens_prev = 1.0;
-    bool ok = true;
-    for (int i = 0; i < passes && ok; i++) {
-      const int bits = total / passes + (i < total % passes ? 1 : 0);
-      double dens = 1.0;
-      if (range_bits && shift <= range_bits - 1 && range_bits - 1 < shift + bits) dens *= dens_range;
-      if (rank_bits && i == passes - 1) dens *= dens_rank;
-      const int sp2 = span_begin(c, K_SCATTER, 1, i);
-      if (i == 0) {
-        hmj::SlabGeom g;
-        if (!hmj::slab_geometry_one_pass((u32)n, bits, 1e18, 512, &g, dens)) {
-          ok = false;
-        } else {
-          if ((rc = ensure_dev(c, *sl[0], g.rows_a * 16)) != HMJ_OK) return rc;
-          if ((rc = ensure_dev(c, *cn[0], ((size_t)g.WA << bits) * 4)) != HMJ_OK) return rc;
-          HIP_TRY(hmj::launch_slab_a(c->sbuf[0].p, (u32)n, 0, bits, g, sl[0]->p, sl[0]->cap / 16, (u32*)cn[0]->p, cn[0]->cap / 4, acc, c->stream));
-          W = g.WA;
-          C = g.CA;
-        }
-      } else {
-        hmj::SlabGeom g;
-        std::memset(&g, 0, sizeof(g));
-        g.WA = W;
-        g.CA = C;
-        g.KB = 512u >> bprev;  // 512 workers again, whatever the last digit's width
-        if (g.KB < 1) g.KB = 1;
-        if (g.KB > W) g.KB = W;
-        const u32 Wn = g.KB << bprev;
-        // (a pass-B worker belongs to ONE value of the previous digit: where that digit fills only part of its range, the
-        //  workers of the values in use carry dens_prev x the mean, and so do their slabs)
-        g.CB = hmj::slab_capacity(dens * dens_prev * (double)n / ((double)Wn * (double)(1u << bits)), 1.0);
-        const u64 pieces = (u64)Wn << bits;
-        if (pieces * g.CB >= 0xFFFFFFF0ull) {
-          ok = false;
-        } else {
-          DevBuf& so = *sl[i & 1];
-          DevBuf& co = *cn[i & 1];
-          if ((rc = ensure_dev(c, so, pieces * g.CB * 16)) != HMJ_OK) return rc;
-          if ((rc = ensure_dev(c, co, pieces * 4)) != HMJ_OK) return rc;
-          HIP_TRY(hmj::launch_slab_b(sl[(i - 1) & 1]->p, (const u32*)cn[(i - 1) & 1]->p, bprev, shift, bits, g, so.p, so.cap / 16,
-                                     (u32*)co.p, co.cap / 4, acc, c->stream));
-          W = Wn;
-          C = g.CB;
-        }
-      }
-      span_end(c, sp2);
-      if (ok) {
-        c->timing.bytes_scatter += 32ull * n;
-        bprev = bits;
-        dens_prev = dens;
-        shift += bits;
-        n_passes++;
-        pc_which = i & 1;
-      }
+    ChainDigit dg[8];
+    int shift = 0;
+    for (int i = 0; i < passes; i++) {
+      dg[i].shift = shift;
+      dg[i].bits = total / passes + (i < total % passes ? 1 : 0);
+      dg[i].dens = 1.0;
+      if (range_bits && shift <= range_bits - 1 && range_bits - 1 < shift + dg[i].bits) dg[i].dens *= dens_range;
+      if (rank_bits && i == passes - 1) dg[i].dens *= dens_rank;
+      shift += dg[i].bits;
     }
+    bool ok = false;
+    if ((rc = slab_chain(c, c->sbuf[0].p, (u32)n, dg, passes, 1, &ok, &pc_n, &pc_cap, &pc_which)) != HMJ_OK) return rc;
     if (ok) {
-      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) ok = false;
-    }
-    if (ok) {
-      pc_n = W << bprev;
-      pc_cap = C;
+      n_passes = passes;
       c->timing.path |= HMJ_PATH_SLAB;
-    } else {  // back to the exact passes (the composites in sbuf[0] are untouched)
+    } else {
       c->gtable_sort_slab_cooldown = 8;
-      HIP_TRY(hipMemsetAsync((u64*)c->accum.p + hmj::ACC_ERR, 0, sizeof(u64), c->stream));
-      std::vector<Span> keep;
-      for (const Span& s2 : c->spans)
-        if (s2.kind != K_SCATTER) keep.push_back(s2);
-      c->spans.swap(keep);
-      c->timing.bytes_scatter = 0;
-      n_passes = 0;
       if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: a slab of the composite sort's chain overflowed -> exact passes\n", nb, np);
     }
   }
@@ -2136,6 +2176,11 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB")) c->gtable_sort_slab = atoi(e) != 0;  // 0: the composites' LSD passes are exact passes (hist + scan + scatter)
+  if (const char* e = getenv("HMJ_SORT_SLAB")) c->sort_slab = atoi(e) != 0;  // 0: hmj_sort_u64_device runs exact passes (hist + scan + scatter)
+  if (const char* e = getenv("HMJ_SORT_SLAB_MIN_LOG2")) {
+    const int l = atoi(e);
+    if (l >= 12 && l <= 32) c->sort_slab_min = 1ull << l;
+  }
   if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB_MIN_LOG2")) {
     const int l = atoi(e);
     if (l >= 12 && l <= 32) c->gtable_sort_slab_min = 1ull << l;
@@ -2629,6 +2674,8 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
   // says whether that can be the case at all -- uniform 64-bit keys then pay nothing --, one pass over all keys (16 of a
   // radix pass's 48 bytes per row) makes it exact.
   u32 digits = 0xFFu;  // bit d: the 8-bit digit d varies
+  u64 diff = ~0ull, kmin = 0, kmax = ~0ull;  // the bits in which keys differ; exact (with the extremes) when != ~0
+  u64 sdiff = ~0ull;                          // the bits in which the SAMPLED keys differ
   if (n >= (1u << 22)) {
     if ((rc = ensure_dev(c, c->offs64, 8 * sizeof(u64))) != HMJ_OK) return rc;
     if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
@@ -2641,18 +2688,72 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
       for (int i = 0; i < 8; i++) d |= ((mask >> (8 * i)) & 0xFFu) ? (1u << i) : 0u;
       return d;
     };
+    sdiff = h[0];
     if (varying(h[0]) != 0xFFu) {
       const u64 init[3] = {0, ~0ull, 0};
       HIP_TRY(hipMemcpyAsync(c->offs64.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
       HIP_TRY(hmj::launch_key_exact(in_aos_dev, (u32)n, nullptr, 0u, 0, (u64*)c->offs64.p, c->num_cus, c->stream, true));
-      HIP_TRY(hipMemcpyAsync(h, c->offs64.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(h, c->offs64.p, 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       digits = varying(h[0]);
+      diff = h[0];
+      kmin = h[1];
+      kmax = h[2];
     }
   }
   const int k = __builtin_popcount(digits);
   void* const tmp = c->rbuf[0].p;
-  if (k == 0) {  // one distinct key: the input order is the sorted order
+  // From 2^25 rows on the passes are a CHAIN of histogram-free slab passes (slab_chain: 32 instead of 48 B per row and pass)
+  // and one compaction of the last pass's pieces into the output (32 B per row): uniform 64-bit keys 9 x 32 instead of 8 x 48
+  // B per row.  A digit is trimmed to the bits that vary inside it (ids below 2^28: 8 + 8 + 8 + 4 bits), the top digit's slabs
+  // are sized for the share of its values in use; digits that are not evenly filled overflow a slab -> the exact passes below
+  // (the input is untouched: the chain writes only its own buffers), and the chain is left alone for the next 8 sorts.
+  bool chained = false;
+  if (c->sort_slab_cooldown > 0) c->sort_slab_cooldown--;
+  else if (k >= 2 && c->slab_mode && c->sort_slab && n >= c->sort_slab_min && n < 0xFFFFFFF0ull) {
+    // exact: `diff` holds every bit in which keys differ (digits are trimmed to them).  Otherwise the sample saw all eight
+    // digits vary and `sdiff` holds the bits IT saw varying: every digit keeps its eight bits (a bit the sample missed must
+    // still be sorted on), but a bit of a digit that (as far as the sample tells) never varies halves the values in use, so
+    // the rows crowd into the others -- 63-bit keys fill half of the top digit -- and the slabs are sized for that.
+    const bool exact = diff != ~0ull || sdiff == ~0ull;
+    hmj_host::ChainDigit dg[8];
+    int nd = 0;
+    for (int d = 0; d < 8; d++) {
+      const u32 sub = (u32)((exact ? diff : sdiff) >> (8 * d)) & 0xFFu;
+      if (exact && !sub) continue;
+      const int lo = exact ? __builtin_ctz(sub) : 0, hi = exact ? 31 - __builtin_clz(sub) : 7;
+      dg[nd].shift = 8 * d + lo;
+      dg[nd].bits = hi - lo + 1;
+      dg[nd].dens = std::ldexp(1.0, dg[nd].bits - __builtin_popcount(sub));
+      nd++;
+    }
+    if (exact && diff != ~0ull && nd) {  // (kmin / kmax are the keys' extremes, all bits above the top digit agree)
+      const hmj_host::ChainDigit& t = dg[nd - 1];
+      const u64 in_use = (kmax >> t.shift) - (kmin >> t.shift) + 1;
+      const double dt = std::ldexp(1.0, t.bits) / (double)in_use;
+      if (dt > dg[nd - 1].dens) dg[nd - 1].dens = dt;
+    }
+    bool ok = false;
+    u32 pc_n = 0, pc_cap = 0;
+    int pc_which = 0;
+    if ((rc = hmj_host::slab_chain(c, in_aos_dev, (u32)n, dg, nd, -1, &ok, &pc_n, &pc_cap, &pc_which)) != HMJ_OK) return rc;
+    if (ok) {
+      DevBuf& so = pc_which ? c->slab_bs : c->slab_a;
+      DevBuf& co = pc_which ? c->cnt_bs : c->cnt_a;
+      if ((rc = ensure_dev(c, c->piece_off, (size_t)pc_n * 8)) != HMJ_OK) return rc;
+      HIP_TRY(hmj::launch_piece_offsets((const u32*)co.p, pc_n, (u64*)c->piece_off.p, c->stream));
+      const int sp = span_begin(c, K_SCATTER, -1, nd);
+      HIP_TRY(hmj::launch_pieces_compact(so.p, (const u32*)co.p, (const u64*)c->piece_off.p, pc_n, pc_cap, out_aos_dev, c->num_cus, c->stream));
+      span_end(c, sp);
+      c->timing.bytes_scatter += 32ull * n;
+      c->timing.path |= HMJ_PATH_SLAB;
+      chained = true;
+    } else {
+      c->sort_slab_cooldown = 8;
+    }
+  }
+  if (chained) {
+  } else if (k == 0) {  // one distinct key: the input order is the sorted order
     if (out_aos_dev != in_aos_dev) HIP_TRY(hipMemcpyAsync(out_aos_dev, in_aos_dev, (size_t)n * 16, hipMemcpyDeviceToDevice, c->stream));
   } else {
     // the passes alternate between the caller's output and the scratch buffer and end in the output -- except in place

@@ -522,6 +522,39 @@ __global__ __launch_bounds__(256) void gtable_expand_pieces_kernel(const Tup* __
   block_accumulate(red, accum, v, 1u << ACC_XOR);
 }
 
+// pieces -> dense rows (the sort API's last step: hmj_sort_u64_device over a chain of slab passes)
+__global__ __launch_bounds__(256) void pieces_compact_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt,
+                                                             const u64* __restrict__ off, u32 n_pieces, u32 cap, u32 ppw,
+                                                             Tup* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const u64 p0 = (u64)wave * ppw;
+  const u32 p1 = p0 + ppw < n_pieces ? (u32)(p0 + ppw) : n_pieces;
+  for (u64 pb = p0; pb < p1; pb += kWave) {
+    const u32 c_l = pb + lane < p1 ? cnt[pb + lane] : 0u;
+    const u64 o_l = pb + lane < p1 ? off[pb + lane] : 0ull;
+    const u32 pe = p1 - pb < (u64)kWave ? (u32)(p1 - pb) : (u32)kWave;
+    for (u32 pi = 0; pi < pe; pi++) {
+      const u32 c = (u32)__builtin_amdgcn_readlane((int)c_l, (int)pi);
+      const u64 o = ((u64)(u32)__builtin_amdgcn_readlane((int)(o_l >> 32), (int)pi) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)o_l, (int)pi);
+      const Tup* __restrict__ base = slabs + (pb + pi) * cap;
+      for (u32 r = (u32)lane; r < c; r += kWave) store_stream(&out[o + r], load_stream(&base[r]));
+    }
+  }
+}
+
+hipError_t launch_pieces_compact(const void* slabs, const u32* cnt, const u64* off, u32 n_pieces, u32 cap, void* out, int num_cus,
+                                 hipStream_t st) {
+  if (!slabs || !cnt || !off || !out || n_pieces == 0 || cap == 0) return hipErrorInvalidValue;
+  u32 waves = (u32)num_cus * 32u;
+  if (waves > n_pieces) waves = n_pieces;
+  const u32 ppw = (n_pieces + waves - 1) / waves;
+  const u32 grid = ((n_pieces + ppw - 1) / ppw + 3) / 4;
+  hipLaunchKernelGGL(pieces_compact_kernel, dim3(grid), dim3(256), 0, st, static_cast<const Tup*>(slabs), cnt, off, n_pieces, cap, ppw,
+                     static_cast<Tup*>(out));
+  return hipGetLastError();
+}
+
 hipError_t launch_piece_offsets(const u32* cnt, u32 n_pieces, u64* off, hipStream_t st) {
   if (!cnt || !off || n_pieces == 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(piece_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, n_pieces, off);

@@ -105,7 +105,10 @@ struct hmj_ctx {
   int gtable_sort_cooldown = 0;
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
-  int gtable_sort_slab_cooldown = 0;  // joins to keep on the exact passes after a slab of the chain overflowed (skewed digits)
+  int gtable_sort_slab_cooldown = 0;
+  bool sort_slab = true;           // hmj_sort_u64_device: LSD passes as a chain of slab passes + one compaction (HMJ_SORT_SLAB=0: exact passes)
+  u64 sort_slab_min = 1ull << 25;  // ... from this many rows on (HMJ_SORT_SLAB_MIN_LOG2)
+  int sort_slab_cooldown = 0;      // sorts to keep on the exact passes after a slab of the chain overflowed (skewed digits)  // joins to keep on the exact passes after a slab of the chain overflowed (skewed digits)
   int gtable_write_cooldown = 0;   // materialising joins to skip it for after one met duplicate build keys
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged

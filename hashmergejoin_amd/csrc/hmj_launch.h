@@ -158,6 +158,8 @@ hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u
 // sorted order is the order of the pieces): launch_piece_offsets gives every piece its first result row (exclusive scan of
 // the counts), launch_gtable_expand_pieces turns the pieces into result rows.
 hipError_t launch_piece_offsets(const u32* cnt, u32 n_pieces, u64* off, hipStream_t st);
+hipError_t launch_pieces_compact(const void* slabs, const u32* cnt, const u64* off, u32 n_pieces, u32 cap, void* out, int num_cus,
+                                 hipStream_t st);  // pieces -> dense 16-byte rows, in piece order
 hipError_t launch_gtable_expand_pieces(const void* slabs, const u32* cnt, const u64* off, u32 n_pieces, u32 cap, const void* sortedR,
                                        u64 svmin, int range_bits, u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra,
                                        int num_cus, hipStream_t st);

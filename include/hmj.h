@@ -394,7 +394,8 @@ int hmj_partition_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, i
 /* ---- full radix sort ------------------------------------------------------------ */
 /* Replaces radix_int_non_inplace<uint64_t,uint64_t>(begin, end, dst, num_threads)
  * (radix_sort.h:452-522) -- the call radix_bench_par.cc:126-127 times: rows sorted by key, ascending,
- * out of place.  Eight stable 8-bit LSD passes of the write-combining scatter; equal keys keep their
+ * out of place.  Stable LSD passes over the 8-bit digits in which keys differ (write-combining scatter; from
+ * 2^25 rows on histogram-free slab passes chained one into the next + one compaction); equal keys keep their
  * input order (the reference is stable in pass 1 only, so on duplicate keys its payload order may
  * differ; the key column and the multiset of rows are identical).  in/out: n x {key,val}, device.
  * out == in sorts in place -- the replacement of radix_int_inplace<uint64_t,uint64_t>(begin, n,

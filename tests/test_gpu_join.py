@@ -882,6 +882,62 @@ def test_sort_skips_the_digits_no_key_differs_in(ex, shape):
     assert np.array_equal(to_np(ex.sort_device(d, inplace=True)), want)
 
 
+def test_sort_as_a_chain_of_slab_passes(H):
+    # hmj_sort_u64_device from 2^25 rows on (here: from 2^20, HMJ_SORT_SLAB_MIN_LOG2): its LSD passes are histogram-free
+    # slab passes chained one into the next, the last pass's pieces compacted into the output.  Uniform 64-bit keys (eight
+    # digits), a permutation of 0 .. n - 1 (digits trimmed to the bits that vary, the top one filled in part), digits that are
+    # not adjacent, keys with duplicates (stable: equal keys keep their input order), out of place and in place; keys drawn from
+    # a handful of values or with sixteen copies each overflow a slab (keys whose digits follow from one another may) -> exact
+    # passes, same order, and the
+    # chain is left alone for 8 sorts.
+    os.environ["HMJ_SORT_SLAB_MIN_LOG2"] = "20"
+    try:
+        ex = H.Executor(0)
+    finally:
+        del os.environ["HMJ_SORT_SLAB_MIN_LOG2"]
+    SL = H.HMJ_PATH_SLAB
+    rng = np.random.default_rng(13)
+    n = (1 << 22) + 4099
+    shapes = {
+        "uniform": rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64),
+        "dense": rng.permutation(n).astype(np.uint64),
+        "dense_offset": rng.permutation(n).astype(np.uint64) + np.uint64(0x123456789A000000),
+        "digits_0_2_5": (rng.integers(0, 256, n).astype(np.uint64) | (rng.integers(0, 256, n).astype(np.uint64) << np.uint64(16))
+                         | (rng.integers(0, 200, n).astype(np.uint64) << np.uint64(40)) | (np.uint64(0xAB) << np.uint64(56))),
+        "duplicates": rng.integers(0, 1 << 63, 1 << 21, dtype=np.uint64)[rng.integers(0, 1 << 21, n)],  # ~2 rows per key
+        "many_duplicates": rng.integers(0, 1 << 63, 1 << 18, dtype=np.uint64)[rng.integers(0, 1 << 18, n)],  # ~16 rows per key: a digit's
+        # share of a worker's rows varies 16 x as much as the slabs allow for at this size (at 2^28 rows it does not)
+        "correlated_digits": rng.integers(0, 1 << 18, n).astype(np.uint64) * np.uint64(0x0000400001000401),  # (a digit follows from the one before)
+        "few_values": rng.integers(0, 5, n).astype(np.uint64) * np.uint64(0x0101010101010101),
+        "two_low_bytes": (rng.integers(0, 1 << 40, n).astype(np.uint64) << np.uint64(8)) | (rng.integers(0, 2, n).astype(np.uint64) * np.uint64(0x80)),
+    }
+    def drain():  # an overflow leaves the chain alone for 8 sorts: let them pass so that the next case is asked again
+        small = to_dev(np.stack([np.arange(5000, dtype=np.uint64)] * 2, 1))
+        for _ in range(8):
+            ex.sort_device(small)
+
+    for name, keys in shapes.items():
+        a = np.stack([keys, np.arange(n, dtype=np.uint64)], 1)
+        want = a[np.argsort(keys, kind="stable")]
+        # True: the chain sorts it; False: a slab overflows; None: either (the digits are correlated, not skewed)
+        # (two_low_bytes: with the exact digit mask the first digit shrinks to its one varying bit)
+        chain = {"many_duplicates": False, "few_values": False, "two_low_bytes": None, "correlated_digits": None}.get(name, True)
+        got = to_np(ex.sort_device(to_dev(a)))
+        took = bool(ex.last_timing()["path"] & SL)
+        assert chain is None or took == chain, (name, hex(ex.last_timing()["path"]))
+        assert np.array_equal(got, want), name
+        if not took:
+            ex.sort_device(to_dev(a))
+            assert not ex.last_timing()["path"] & SL, name  # (not asked again right away)
+            drain()
+        d = to_dev(a)
+        out = ex.sort_device(d, inplace=True)
+        assert out.data_ptr() == d.data_ptr() and np.array_equal(to_np(d), want), name
+        if not ex.last_timing()["path"] & SL:
+            drain()
+    ex.close()
+
+
 def test_sort_in_place_replaces_radix_int_inplace(ex, oracle):
     # hmj_sort_u64_device with out == in vs the restated radix_int_inplace (radix_sort.h:333-398; the call
     # radix_bench_par.cc:96 times).  The reference's in-place sort is unstable: same rows, same key column.
