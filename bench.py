@@ -183,6 +183,19 @@ def extra_runs(ex, H, torch):
     ex.release_result()
     del R, Rf, Sf
     torch.cuda.empty_cache()
+    # the full sort (hmj_sort_u64_device = radix_int_non_inplace<u64,u64>, radix_bench_par.cc:126-127): 2^28 rows of
+    # uniform 64-bit keys, and ids 0 .. 2^28 - 1 in random order; sortedness and the payload sum are checked
+    for name, mkrel in (("uniform", lambda: ex.gen_build(1 << 28)),
+                        ("dense", lambda: torch.stack([torch.randperm(1 << 28, device="cuda"), torch.arange(1 << 28, device="cuda")], 1).contiguous())):
+        a = mkrel()
+        ms, o = timed(lambda: ex.sort_device(a), reps=2)
+        k = o[:, 0]
+        top = torch.iinfo(torch.int64).min  # (flips the sign bit: signed compare of the flipped keys = unsigned order)
+        assert bool(((k[1:] ^ top) >= (k[:-1] ^ top)).all()) and int(o[:, 1].sum()) == int(a[:, 1].sum()), name
+        out["sort_2p28_%s_keys_ms" % name] = ms
+        out["sort_2p28_%s_path" % name] = "chain of slab passes + compaction" if ex.last_timing()["path"] & H.HMJ_PATH_SLAB else "exact passes"
+        del a, o, k
+        torch.cuda.empty_cache()
     # duplicate keys on BOTH sides (outside the reference's domain: its iterator drops matches there): 2^24 rows per side
     # drawn from 2^21 keys, ~1.3 * 10^8 result rows in (key, rval, sval) order
     g = torch.Generator(device="cuda")

@@ -126,6 +126,8 @@ hipError_t launch_slab_np(const u32* cnt, u32 P, u64* out, hipStream_t st);
 hipError_t launch_probe_count_fast(const ProbeArgs& a, u32* irregular, u32* n_irregular, bool big,
                                    bool per_partition_counts, int num_cus, hipStream_t st);
 hipError_t launch_scan_u64(const u64* in, u64* out_excl, u32 n, hipStream_t st);  // out: n+1
+// ordered result of a join with duplicate build keys, written in order partition by partition (probe_expand_ordered_kernel)
+hipError_t launch_probe_expand_ordered(const ProbeArgs& a, int key_low, int num_cus, hipStream_t st);
 hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
                         int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
                         u64* bsval, u64* accum, u32 defer_rows, bool many_per_key, int grid, hipStream_t st);

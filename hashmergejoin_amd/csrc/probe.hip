@@ -2374,6 +2374,216 @@ static hipError_t launch_order_t(const u64* part_out_off, const u32* vstart, con
   return hipGetLastError();
 }
 // many_per_key: the result has clearly more rows than the build side has keys (fan-out)
+// ---------------------------------------------------------------------------------------------
+// Ordered result of a join with duplicate keys on the build side (and usually on both): written IN ORDER, partition by
+// partition, instead of written in probe order and sorted afterwards (order_kernel: 16 of the 19 ms of a join of 8 x 8 rows per
+// key with 1.3 * 10^8 result rows).  The operator's order is (key, rval, sval).  Per partition (a key range; one workgroup):
+//   1. both sides are SORTED in LDS -- build rows by (key, rval), probe rows by (key, sval): a row goes to its bucket (the key
+//      bits under the partition bits, in arrival order), then ranks itself among the rows of its bucket (a handful: one or two
+//      keys' rows) and moves to its place once everybody has read;
+//   2. every build row finds its key's run of probe rows (the probe side's bucket of that key, a handful of rows): that many
+//      result rows, the build row's own payload against the run's payloads in order -- an exclusive scan over the build rows
+//      gives each its first result row;
+//   3. the result rows are written by OUTPUT index: lane <-> result row, so the stores coalesce; a row finds its build row by
+//      a binary search over the scan (13 LDS reads) and its probe row by the offset inside the run.
+// The partition's first result row comes from the count pass's scan (part_out_off), which also made the sums.  A partition
+// that does not fit (XE_CAP rows a side) raises ERR_FASTPATH: the caller writes and sorts as before.
+constexpr int XE_THREADS = 1024, XE_ROWS = 5, XE_CAP = 4608, XE_LOGB = 11;
+struct ExpandSmem {
+  u64 bkey[XE_CAP];  // build keys, sorted; from step 2 on: off[XE_CAP] (u32) and s0[XE_CAP] (u16) in their place
+  u64 bval[XE_CAP];
+  u64 skey[XE_CAP];
+  u64 sval[XE_CAP];
+  u32 cnt[1 << XE_LOGB];
+  u16 bstart[(1 << XE_LOGB) + 2];  // the probe side's buckets once both sides are sorted
+  u32 scratch[XE_THREADS / kWave + 1];
+  u32 flag;
+};
+static_assert(sizeof(ExpandSmem) <= 160 * 1024, "one workgroup per CU");
+static_assert(XE_THREADS * XE_ROWS >= XE_CAP, "every row has a thread slot");
+
+// rows t[0 .. XE_ROWS) of this thread (row j = k * XE_THREADS + tid, valid while j < n) -> K[], V[] sorted by (key, val)
+__device__ __forceinline__ void xe_sort_side(ExpandSmem& sm, Tup (&t)[XE_ROWS], u32 n, u64* K, u64* V, int bsh, int tid) {
+  constexpr u32 NB = 1u << XE_LOGB, BPT = NB / XE_THREADS;
+  const u32 mask = NB - 1;
+#pragma unroll
+  for (u32 q = 0; q < BPT; q++) sm.cnt[tid * BPT + q] = 0;
+  lds_barrier();
+  u32 arr[XE_ROWS], bk[XE_ROWS];
+#pragma unroll
+  for (int k = 0; k < XE_ROWS; k++) {
+    const u32 j = (u32)k * XE_THREADS + tid;
+    bk[k] = key_bucket(t[k].key, bsh, mask);
+    arr[k] = j < n ? atomicAdd(&sm.cnt[bk[k]], 1u) : 0u;
+  }
+  lds_barrier();
+  {  // exclusive scan of the bucket counts -> bstart
+    u32 c[BPT], sum = 0;
+#pragma unroll
+    for (u32 q = 0; q < BPT; q++) {
+      c[q] = sm.cnt[tid * BPT + q];
+      sum += c[q];
+    }
+    u32 tot;
+    u32 ex = block_excl_scan_u32<XE_THREADS>(sum, sm.scratch, &tot, tid);
+#pragma unroll
+    for (u32 q = 0; q < BPT; q++) {
+      sm.bstart[tid * BPT + q] = (u16)ex;
+      ex += c[q];
+    }
+    if (tid == 0) sm.bstart[NB] = (u16)tot;
+  }
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < XE_ROWS; k++) {
+    const u32 j = (u32)k * XE_THREADS + tid;
+    if (j < n) {
+      const u32 slot = sm.bstart[bk[k]] + arr[k];
+      K[slot] = t[k].key;
+      V[slot] = t[k].val;
+    }
+  }
+  lds_barrier();
+  // slot j's row ranks itself inside its bucket: rows with a smaller (key, val), and equal ones in earlier slots
+  u32 pos[XE_ROWS];
+#pragma unroll
+  for (int k = 0; k < XE_ROWS; k++) {
+    const u32 j = (u32)k * XE_THREADS + tid;
+    pos[k] = 0xFFFFFFFFu;
+    if (j < n) {
+      const u64 key = K[j], val = V[j];
+      t[k].key = key;
+      t[k].val = val;
+      const u32 b = key_bucket(key, bsh, mask), b0 = sm.bstart[b], b1 = sm.bstart[b + 1];
+      u32 r = 0;
+      for (u32 i = b0; i < b1; i++) {
+        const u64 k2 = K[i], v2 = V[i];
+        r += (k2 < key || (k2 == key && (v2 < val || (v2 == val && i < j)))) ? 1u : 0u;
+      }
+      pos[k] = b0 + r;
+    }
+  }
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < XE_ROWS; k++) {
+    if (pos[k] != 0xFFFFFFFFu) {
+      K[pos[k]] = t[k].key;
+      V[pos[k]] = t[k].val;
+    }
+  }
+  lds_barrier();
+}
+
+__global__ __launch_bounds__(XE_THREADS) void probe_expand_ordered_kernel(ProbeArgs a, int key_low) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ExpandSmem& sm = *reinterpret_cast<ExpandSmem*>(smem_raw);
+  const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
+  const Tup* __restrict__ S = static_cast<const Tup*>(a.S);
+  const int tid = threadIdx.x;
+  const int bsh = key_low - XE_LOGB;
+  constexpr u32 NB = 1u << XE_LOGB;
+  u32* off = reinterpret_cast<u32*>(sm.bkey);      // [XE_CAP]: first result row of build row i (sorted order)
+  u16* s0 = reinterpret_cast<u16*>(off + XE_CAP);  // [XE_CAP]: where build row i's run of probe rows starts; bit 15: the row equals its predecessor
+  static_assert(XE_CAP * 4 + XE_CAP * 2 <= XE_CAP * 8 && XE_CAP < 0x8000, "off[] and s0[] fit the build keys' place");
+  bool toobig = false;
+  if (tid == 0) sm.flag = 0;
+  __syncthreads();
+  for (u32 p = blockIdx.x; p < a.P; p += gridDim.x) {
+    const u32 rb = a.r_off[p], nb = a.r_off[p + 1] - rb, sb = a.s_off[p], np = a.s_off[p + 1] - sb;
+    const u64 ob = a.part_out_off[p], total64 = a.part_out_off[p + 1] - ob;
+    if (total64 == 0) continue;  // (uniform)
+    if (nb > (u32)XE_CAP || np > (u32)XE_CAP || total64 > 0xFFFFFFFFull) {
+      toobig = true;
+      continue;
+    }
+    const u32 total = (u32)total64;
+    Tup br[XE_ROWS], pr[XE_ROWS];
+#pragma unroll
+    for (int k = 0; k < XE_ROWS; k++) {
+      const u32 j = (u32)k * XE_THREADS + tid;
+      br[k] = load_stream(&R[(u64)rb + (j < nb ? j : nb - 1)]);
+      pr[k] = load_stream(&S[(u64)sb + (j < np ? j : np - 1)]);
+    }
+    xe_sort_side(sm, br, nb, sm.bkey, sm.bval, bsh, tid);
+    xe_sort_side(sm, pr, np, sm.skey, sm.sval, bsh, tid);  // (leaves the probe side's buckets in bstart)
+    // every build row: its key's probe rows = the equal keys inside the probe side's bucket of that key
+    u32 c[XE_ROWS], st[XE_ROWS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < XE_ROWS; k++) {
+      const u32 i = (u32)tid * XE_ROWS + k;  // (consecutive build rows per thread: the scan below is over them)
+      c[k] = 0;
+      st[k] = 0;
+      if (i < nb) {
+        const u64 key = sm.bkey[i];
+        // (a build row that equals its predecessor in key AND payload: the two rows' result rows are the same rows, and
+        //  the order by sval runs across both -- see the copy-out)
+        if (i > 0 && sm.bkey[i - 1] == key && sm.bval[i - 1] == sm.bval[i]) st[k] = 0x8000u;
+        const u32 b = key_bucket(key, bsh, NB - 1), b0 = sm.bstart[b], b1 = sm.bstart[b + 1];
+        u32 first = b1, n = 0;
+        for (u32 j = b0; j < b1; j++) {
+          const u64 k2 = sm.skey[j];
+          if (k2 == key) {
+            first = j < first ? j : first;
+            n++;
+          }
+        }
+        c[k] = n;
+        st[k] |= first;  // (first <= XE_CAP < 2^15)
+      }
+      sum += c[k];
+    }
+    u32 tot;
+    u32 ex = block_excl_scan_u32<XE_THREADS>(sum, sm.scratch, &tot, tid);  // (its barriers: everybody has read bkey)
+#pragma unroll
+    for (int k = 0; k < XE_ROWS; k++) {
+      const u32 i = (u32)tid * XE_ROWS + k;
+      if (i < nb) {
+        off[i] = ex;
+        s0[i] = (u16)st[k];
+      }
+      ex += c[k];
+    }
+    if (tid == 0 && tot != total) sm.flag = 1;  // (the count pass and this kernel disagree: never expected; the caller falls back)
+    lds_barrier();
+    // result rows by output index.  Build row lo's rows are (its payload) x (its key's run of probe rows, by sval); g build
+    // rows that agree in key and payload share ONE block of g * cs rows in which every probe row appears g times in a row.
+    for (u32 o = (u32)tid; o < tot && tot == total; o += XE_THREADS) {
+      u32 lo = 0, hi = nb;  // off[lo] <= o < off[hi] (off[nb] = tot, not stored)
+#pragma unroll 1
+      while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (off[mid] <= o) lo = mid; else hi = mid;
+      }
+      const u32 cs = (lo + 1 < nb ? off[lo + 1] : tot) - off[lo];
+      u32 q = 0, g = 1;  // lo is the q-th of g equal build rows
+#pragma unroll 1
+      while (s0[lo - q] & 0x8000u) q++;
+#pragma unroll 1
+      while (lo + g - q < nb && (s0[lo + g - q] & 0x8000u)) g++;
+      const u32 x = (o - off[lo]) + q * cs;
+      const u32 s = ((u32)s0[lo] & 0x7FFFu) + (g == 1 ? x : x / g);
+      a.out_key[ob + o] = sm.skey[s];
+      a.out_rval[ob + o] = sm.bval[lo];
+      a.out_sval[ob + o] = sm.sval[s];
+    }
+    lds_barrier();  // (the next partition overwrites the arrays)
+  }
+  if (tid == 0 && sm.flag) toobig = true;
+  if (__any(toobig) && (tid & 63) == 0) atomicOr(reinterpret_cast<unsigned long long*>(&a.accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
+}
+
+// a: R / r_off, S / s_off (contiguous partitions, P of them), part_out_off (P + 1, from the count pass), out_*, accum
+hipError_t launch_probe_expand_ordered(const ProbeArgs& a, int key_low, int num_cus, hipStream_t st) {
+  if (!a.R || !a.S || !a.r_off || !a.s_off || !a.part_out_off || !a.out_key || !a.out_rval || !a.out_sval || !a.accum || a.P == 0)
+    return hipErrorInvalidValue;
+  static SmemAttrOnce attr_once;
+  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_expand_ordered_kernel), sizeof(ExpandSmem)); e != hipSuccess) return e;
+  u32 grid = (u32)num_cus;
+  if (grid > a.P) grid = a.P;
+  hipLaunchKernelGGL(probe_expand_ordered_kernel, dim3(grid), dim3(XE_THREADS), sizeof(ExpandSmem), st, a, key_low);
+  return hipGetLastError();
+}
+
 hipError_t launch_order(const u64* part_out_off, const u32* vstart, const u32* in_base32, const u64* in_base64, u32 P, u32 Q,
                         int low, const u64* akey, const u64* arval, const u64* asval, u64* bkey, u64* brval,
                         u64* bsval, u64* accum, u32 defer_rows, bool many_per_key, int grid, hipStream_t st) {

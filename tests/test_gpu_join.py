@@ -1587,6 +1587,45 @@ def test_one_pass_ordered_write(ex_part_fresh, H, oracle):
     assert not (t["path"] & H.HMJ_PATH_SORTED_WRITE)
 
 
+def test_ordered_rows_of_duplicate_build_keys_are_written_in_order(ex_part_fresh, H, oracle):
+    # HMJ_ORDERED with duplicate keys on the build side (and on both): the unique-key forms give up, and the general passes
+    # write the result IN ORDER partition by partition (HMJ_PATH_ORDERED_EXPANSION: both sides sorted in LDS, every build row
+    # against its key's run of probe rows) instead of writing in probe order and sorting 10^8 rows afterwards.  Row sequences
+    # against the oracle: a few copies per key on both sides, ties among the payloads of a key (rows that differ only in
+    # the other side's payload), unmatched rows on both sides, one side unique; a key with thousands of build rows makes a
+    # partition that does not fit the kernel -> write + sort as before, same rows, and the form is left alone for 8 joins.
+    ex = ex_part_fresh
+    XE = H.HMJ_PATH_ORDERED_EXPANSION
+    rng = np.random.default_rng(41)
+    for nb, npb, keys_n, ties, hot in [(200000, 300000, 30000, False, False), (150001, 90000, 40000, True, False),
+                                       (300000, 300000, 250000, False, False), (120000, 500000, 120000 // 3, True, False),
+                                       (200000, 100000, 30000, False, True)]:
+        pool = rng.integers(0, 1 << 62, keys_n + keys_n // 4, dtype=np.uint64)
+        B = np.stack([pool[rng.integers(0, keys_n, nb)], rng.permutation(nb).astype(np.uint64)], 1)
+        P = np.stack([pool[rng.integers(keys_n // 8, len(pool), npb)], rng.permutation(npb).astype(np.uint64) + np.uint64(1 << 40)], 1)
+        if ties:
+            B[:, 1] = rng.integers(0, 4, nb).astype(np.uint64)
+            P[:, 1] = rng.integers(0, 3, npb).astype(np.uint64)
+        if hot:
+            B[:9000, 0] = pool[5]
+            P[:3, 0] = pool[5]
+        ck, rows = oracle.equijoin(B, P)
+        assert ck["n_matches"] > max(nb, npb) // 2
+        Bd, Pd = to_dev(B), to_dev(P)
+        for fl in (H.HMJ_ORDERED, H.HMJ_ORDERED | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE):
+            r = ex.join_device(Bd, Pd, fl)
+            t = ex.last_timing()
+            assert bool(t["path"] & XE) == (not hot), (nb, npb, hex(t["path"]))
+            assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, fl)
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck
+            assert np.array_equal(ex.columns_to_numpy(r, host=False), rows), (nb, npb, ties, hot, fl)
+            if hot:  # (the cool-down the oversized partition leaves: let it run out)
+                for _ in range(8):
+                    ex.join_device(Bd, Pd, H.HMJ_ORDERED)
+        ex.release_result()
+
+
 def test_long_foreign_key_runs(ex_part_fresh, H, oracle):
     # Foreign-key joins with tens to a thousand probe rows per build key: the one-pass ordered write ranks a payload inside
     # its key's run by reading the run.  Run lengths around the kernel's eight-at-a-time ranking loop and far above it,
