@@ -1602,7 +1602,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // (An unordered result takes it too -- rows in order are rows: 1.15 against 1.9 ms for the general write pass, whose
     //  workgroups re-probe their partition; there the partitions need not be key ranges.)
     if (c->expand_cooldown > 0) c->expand_cooldown--;
-    else if (c->expand_mode && (!(flags & HMJ_ORDERED) || !win_ordered) && !split && Q == 1 && !first && P >= 2) {
+    //  Only where the result is several times the input: the kernel runs one workgroup per CU through a dozen barriers per
+    //  partition -- at about one result row per input row the general write pass is as fast: 2^28 x 2^28, every 4th build key
+    //  doubled: 6.4 against 6.9 ms.)
+    else if (c->expand_mode && ((flags & HMJ_ORDERED) ? !win_ordered : out->n_matches >= 2 * ((u64)nb + np)) && !split && Q == 1 &&
+             !first && P >= 2) {
       s = span_begin(c, K_PROBE_WRITE, -1);
       HIP_TRY(hmj::launch_probe_expand_ordered(a, low, c->num_cus, c->stream));
       span_end(c, s);
