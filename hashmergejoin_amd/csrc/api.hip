@@ -517,6 +517,7 @@ constexpr int kRetryNoWinOrdered = 1003;  // internal: window + sort ordered pat
 constexpr int kRetryNoFastWrite = 1002;  // internal: unique-key write mode gave up -> general materialise
 constexpr int kRetryNoSlab = 1001;    // internal: the slab path gave up (skew) -> exact path
 constexpr int kRetryNoSlabProbe = 1004;  // internal: the probe-side slab partitioning overflowed -> exact path
+constexpr int kRetryMoreBits = 1005;  // internal: a partition did not fit the ordered expansion but would with one more radix bit -> re-plan
 constexpr int kRetryNoPrefix = 1000;  // internal: ordered join must be re-planned without the sampled prefix
 
 // The ordered epilogue.  order_kernel sorts every partition's rows from the unsorted columns (c->out_*) into
@@ -1610,9 +1611,17 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       s = span_begin(c, K_PROBE_WRITE, -1);
       HIP_TRY(hmj::launch_probe_expand_ordered(a, low, c->num_cus, c->stream));
       span_end(c, s);
-      HIP_TRY(hipMemcpyAsync(&h[hmj::ACC_ERR], (u64*)c->accum.p + hmj::ACC_ERR, 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(&h[hmj::ACC_ERR], (u64*)c->accum.p + hmj::ACC_ERR, 16, hipMemcpyDeviceToHost, c->stream));  // (+ ACC_PAD)
       HIP_TRY(hipStreamSynchronize(c->stream));
-      if (h[hmj::ACC_ERR] & hmj::ERR_FASTPATH) {  // a partition beyond the kernel's capacity (skew): write + sort, as before
+      if (h[hmj::ACC_ERR] & hmj::ERR_FASTPATH) {  // a partition beyond the kernel's capacity: write + sort, as before ...
+        // ... unless ONE more radix bit would make every partition fit (the biggest is under twice the capacity: keys with
+        // many copies make partition sizes vary like copies x keys, not a hot key) and sorting the result rows would cost more
+        // than partitioning again (0.12 ns per result row against ~0.06 per input row): the join starts over with B + 1
+        if (c->expand_allow_rebits && (flags & HMJ_ORDERED) && c->force_bits < 0 && h[hmj::ACC_PAD] <= 7800 && B + 1 <= 18 &&
+            2 * out->n_matches >= (u64)nb + np) {
+          c->expand_rebits = B + 1;
+          return kRetryMoreBits;
+        }
         c->expand_cooldown = 8;
         HIP_TRY(hipMemsetAsync((u64*)c->accum.p + hmj::ACC_ERR, 0, sizeof(u64), c->stream));
         std::vector<Span> keep;
@@ -2135,7 +2144,16 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
     c->exact_prefix_joins--;
     prefix_unsafe = true;
   }
-  for (int attempt = 0; attempt < 7; attempt++) {
+  bool forced_here = false;  // (kRetryMoreBits pins the plan's bits for the rest of THIS join)
+  struct Unforce {
+    hmj_ctx* c;
+    bool* on;
+    ~Unforce() {
+      if (*on) c->force_bits = -1;
+      c->expand_allow_rebits = true;
+    }
+  } unforce{c, &forced_here};
+  for (int attempt = 0; attempt < 8; attempt++) {
     int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab, fast_write,
                               win_ordered, prefix_unsafe, slab_probe);
     if (c->trace)
@@ -2147,8 +2165,10 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
                    : rc == kRetryNoPrefix ? " -> retry: a row outside the sampled key prefix"
                    : rc == kRetryNoFastWrite ? " -> retry without the unique-key write mode"
                    : rc == kRetryNoWinOrdered ? " -> retry without the key window"
-                   : rc == kRetryNoSlabProbe ? " -> retry without probe-side slabs (one overflowed)" : "");
-    if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite || rc == kRetryNoWinOrdered || rc == kRetryNoSlabProbe) {
+                   : rc == kRetryNoSlabProbe ? " -> retry without probe-side slabs (one overflowed)"
+                   : rc == kRetryMoreBits ? " -> retry with one more radix bit (a partition did not fit the ordered expansion)" : "");
+    if (rc == kRetryNoSlab || rc == kRetryNoPrefix || rc == kRetryNoFastWrite || rc == kRetryNoWinOrdered || rc == kRetryNoSlabProbe ||
+        rc == kRetryMoreBits) {
       // forget the abandoned attempt's phase spans (the enclosing total / h2d spans stay)
       std::vector<Span> keep;
       for (const Span& sp : c->spans)
@@ -2156,6 +2176,11 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
       c->spans.swap(keep);
       std::memset(&c->timing, 0, sizeof(c->timing));
       if (rc == kRetryNoSlab) slab = false;
+      else if (rc == kRetryMoreBits) {  // once per join: the next attempt plans the bits asked for
+        c->force_bits = c->expand_rebits;
+        c->expand_allow_rebits = false;
+        forced_here = true;
+      }
       else if (rc == kRetryNoSlabProbe) slab_probe = false;
       else if (rc == kRetryNoFastWrite) fast_write = false;
       else if (rc == kRetryNoWinOrdered) win_ordered = false;

@@ -107,7 +107,9 @@ struct hmj_ctx {
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
   int gtable_sort_slab_cooldown = 0;
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)
-  int expand_cooldown = 0;         // ordered joins to keep on write + sort after a partition did not fit the expansion kernel
+  int expand_cooldown = 0;
+  bool expand_allow_rebits = true;  // (false during the retry that already took one more bit)
+  int expand_rebits = 0;            // the bits that retry plans         // ordered joins to keep on write + sort after a partition did not fit the expansion kernel
   bool sort_slab = true;           // hmj_sort_u64_device: LSD passes as a chain of slab passes + one compaction (HMJ_SORT_SLAB=0: exact passes)
   u64 sort_slab_min = 1ull << 25;  // ... from this many rows on (HMJ_SORT_SLAB_MIN_LOG2)
   int sort_slab_cooldown = 0;      // sorts to keep on the exact passes after a slab of the chain overflowed (skewed digits)  // joins to keep on the exact passes after a slab of the chain overflowed (skewed digits)

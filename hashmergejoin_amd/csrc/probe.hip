@@ -2494,6 +2494,8 @@ __global__ __launch_bounds__(XE_THREADS) void probe_expand_ordered_kernel(ProbeA
     if (total64 == 0) continue;  // (uniform)
     if (nb > (u32)XE_CAP || np > (u32)XE_CAP || total64 > 0xFFFFFFFFull) {
       toobig = true;
+      // (the caller decides from the biggest partition whether one more radix bit would make them all fit)
+      if (tid == 0) atomicMax(reinterpret_cast<unsigned long long*>(&a.accum[ACC_PAD]), (unsigned long long)(total64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : (nb > np ? nb : np)));
       continue;
     }
     const u32 total = (u32)total64;

@@ -1624,6 +1624,25 @@ def test_ordered_rows_of_duplicate_build_keys_are_written_in_order(ex_part_fresh
                 for _ in range(8):
                     ex.join_device(Bd, Pd, H.HMJ_ORDERED)
         ex.release_result()
+    # exactly 16 copies of every key on both sides: partition sizes then vary like 16 x (a partition's key count) -- a dozen of
+    # the planned 4096-row partitions exceed the kernel's 4608 rows, none by much: the join starts over with one more radix
+    # bit instead of sorting 3 * 10^7 result rows
+    nk = 1 << 17
+    pool = rng.integers(0, 1 << 62, nk, dtype=np.uint64)
+    B = np.stack([np.repeat(pool, 16)[rng.permutation(nk * 16)], rng.permutation(nk * 16).astype(np.uint64)], 1)
+    P = np.stack([np.repeat(pool, 16)[rng.permutation(nk * 16)], rng.permutation(nk * 16).astype(np.uint64) + np.uint64(7)], 1)
+    ck, rows = oracle.equijoin(B, P)
+    Bd, Pd = to_dev(B), to_dev(P)
+    ex.join_device(Bd, Pd, 0)
+    bits_count = ex.last_timing()["radix_bits"]
+    r = ex.join_device(Bd, Pd, H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    assert t["path"] & XE and t["radix_bits"] == bits_count + 1, (hex(t["path"]), t["radix_bits"], bits_count)
+    assert r.checks() == ck and np.array_equal(ex.columns_to_numpy(r, host=False), rows)
+    ex.set_radix_bits(None)  # (the executor's plan is its own again: the retry's bits were for that join only)
+    ex.join_device(Bd, Pd, 0)
+    assert ex.last_timing()["radix_bits"] == bits_count
+    ex.release_result()
 
 
 def test_long_foreign_key_runs(ex_part_fresh, H, oracle):
