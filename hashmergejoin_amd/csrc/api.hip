@@ -1086,7 +1086,12 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // (HMJ_FIRST_WINS included: with unique build keys "the first row of a key" is the only one, and the unique-key
   //  kernels give up the moment a probe row meets a key twice -- the general first-wins passes then run as before.
   //  Until round 3 first-wins joins never tried: first + ordered 3.2 ms against 1.4 ms at 2^25 unique keys.)
-  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !win_ordered &&
+  // (ordered foreign-key joins with LONG runs -- expand_fk_fanout probe rows per build row and more -- skip the one-pass
+  //  ordered write, whose in-run ranking is linear in the run, for count + scan + the ordered expansion, whose sort buckets
+  //  cut the runs by payload: probe_expand_ordered_kernel)
+  const bool long_runs = (flags & HMJ_ORDERED) && c->expand_mode && c->expand_cooldown == 0 && c->expand_fk_fanout > 0 && nb > 0 &&
+                         (double)np >= (double)c->expand_fk_fanout * (double)nb && !(flags & HMJ_FIRST_WINS);
+  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !win_ordered && !long_runs &&
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
   if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
       probe_fits &&
@@ -2234,6 +2239,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB")) c->gtable_sort_slab = atoi(e) != 0;  // 0: the composites' LSD passes are exact passes (hist + scan + scatter)
+  if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
   if (const char* e = getenv("HMJ_ORDERED_EXPANSION")) c->expand_mode = atoi(e) != 0;  // 0: ordered joins with duplicate build keys write in probe order and sort the rows
   if (const char* e = getenv("HMJ_SORT_SLAB")) c->sort_slab = atoi(e) != 0;  // 0: hmj_sort_u64_device runs exact passes (hist + scan + scatter)
   if (const char* e = getenv("HMJ_SORT_SLAB_MIN_LOG2")) {

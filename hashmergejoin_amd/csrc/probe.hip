@@ -2375,35 +2375,65 @@ static hipError_t launch_order_t(const u64* part_out_off, const u32* vstart, con
 }
 // many_per_key: the result has clearly more rows than the build side has keys (fan-out)
 // ---------------------------------------------------------------------------------------------
-// Ordered result of a join with duplicate keys on the build side (and usually on both): written IN ORDER, partition by
-// partition, instead of written in probe order and sorted afterwards (order_kernel: 16 of the 19 ms of a join of 8 x 8 rows per
-// key with 1.3 * 10^8 result rows).  The operator's order is (key, rval, sval).  Per partition (a key range; one workgroup):
-//   1. both sides are SORTED in LDS -- build rows by (key, rval), probe rows by (key, sval): a row goes to its bucket (the key
-//      bits under the partition bits, in arrival order), then ranks itself among the rows of its bucket (a handful: one or two
-//      keys' rows) and moves to its place once everybody has read;
-//   2. every build row finds its key's run of probe rows (the probe side's bucket of that key, a handful of rows): that many
-//      result rows, the build row's own payload against the run's payloads in order -- an exclusive scan over the build rows
-//      gives each its first result row;
-//   3. the result rows are written by OUTPUT index: lane <-> result row, so the stores coalesce; a row finds its build row by
-//      a binary search over the scan (13 LDS reads) and its probe row by the offset inside the run.
+// Ordered result written IN ORDER, partition by partition, instead of written in probe order and sorted afterwards
+// (order_kernel: 16 of the 19 ms of a join of 8 x 8 rows per key with 1.3 * 10^8 result rows), for what the one-pass unique-key
+// forms do not take: duplicate build keys, and foreign-key joins whose runs are long (their in-run ranking is linear in the
+// run).  The operator's order is (key, rval, sval).  Per partition (a key range; one workgroup):
+//   1. the build rows are SORTED in LDS by (key, rval): a row goes to its bucket (the key bits under the partition bits, in
+//      arrival order), then ranks itself among the handful of rows of its bucket and moves to its place once everybody has read;
+//   2. every probe row looks its key up in the sorted build keys (binary search): its KEY ID is the index of the key's first
+//      build row; rows without a match are dropped here;
+//   3. the matched probe rows are sorted by (key id, sval) the same way, with buckets over BOTH: a partition with few keys
+//      (2^b >= build rows) spends its 11 bucket bits as b bits of key id and 11 - b bits of the payload's position in the
+//      partition's payload range -- a foreign-key partition of 16 keys x 256 rows ranks inside buckets of a few rows instead of
+//      inside runs of 256; a partition with thousands of keys buckets by key id alone;
+//   4. every build row takes its key's run of sorted probe rows (bucket boundaries where a key owns whole buckets): that many
+//      result rows; an exclusive scan over the build rows gives each its first result row;
+//   5. the result rows are written by OUTPUT index: lane <-> result row, so the stores coalesce; a row finds its build row by a
+//      binary search over the scan (13 LDS reads) and its probe row by the offset inside the run.  Build rows that agree in key
+//      AND payload share one block in which every probe row appears g times in a row (the order by sval runs across them).
 // The partition's first result row comes from the count pass's scan (part_out_off), which also made the sums.  A partition
-// that does not fit (XE_CAP rows a side) raises ERR_FASTPATH: the caller writes and sorts as before.
+// that does not fit (XE_CAP rows a side) raises ERR_FASTPATH and reports its size: the caller plans one more bit or writes
+// and sorts as before.
 constexpr int XE_THREADS = 1024, XE_ROWS = 5, XE_CAP = 4608, XE_LOGB = 11;
 struct ExpandSmem {
-  u64 bkey[XE_CAP];  // build keys, sorted; from step 2 on: off[XE_CAP] (u32) and s0[XE_CAP] (u16) in their place
-  u64 bval[XE_CAP];
-  u64 skey[XE_CAP];
-  u64 sval[XE_CAP];
+  u64 bkey[XE_CAP];  // build keys, sorted
+  u64 bval[XE_CAP];  // build payloads, same order
+  u64 sval[XE_CAP];  // payloads of the matched probe rows, sorted by (key id, payload)
+  u32 off[XE_CAP];   // first result row of build row i
+  u16 sid[XE_CAP];   // key id of every sorted probe row
+  u16 s0[XE_CAP];    // where build row i's run of probe rows starts; bit 15: the row equals its predecessor (key and payload)
   u32 cnt[1 << XE_LOGB];
-  u16 bstart[(1 << XE_LOGB) + 2];  // the probe side's buckets once both sides are sorted
+  u16 bstart[(1 << XE_LOGB) + 2];
   u32 scratch[XE_THREADS / kWave + 1];
   u32 flag;
+  unsigned long long vmin, vmax;
 };
 static_assert(sizeof(ExpandSmem) <= 160 * 1024, "one workgroup per CU");
-static_assert(XE_THREADS * XE_ROWS >= XE_CAP, "every row has a thread slot");
+static_assert(XE_THREADS * XE_ROWS >= XE_CAP && XE_CAP < 0x8000, "every row has a thread slot; row indices fit 15 bits");
 
-// rows t[0 .. XE_ROWS) of this thread (row j = k * XE_THREADS + tid, valid while j < n) -> K[], V[] sorted by (key, val)
-__device__ __forceinline__ void xe_sort_side(ExpandSmem& sm, Tup (&t)[XE_ROWS], u32 n, u64* K, u64* V, int bsh, int tid) {
+// exclusive scan of sm.cnt[] -> sm.bstart[] (+ the total behind it); barriers before and after are the caller's
+__device__ __forceinline__ u32 xe_scan_buckets(ExpandSmem& sm, int tid) {
+  constexpr u32 NB = 1u << XE_LOGB, BPT = NB / XE_THREADS;
+  u32 c[BPT], sum = 0;
+#pragma unroll
+  for (u32 q = 0; q < BPT; q++) {
+    c[q] = sm.cnt[tid * BPT + q];
+    sum += c[q];
+  }
+  u32 tot;
+  u32 ex = block_excl_scan_u32<XE_THREADS>(sum, sm.scratch, &tot, tid);
+#pragma unroll
+  for (u32 q = 0; q < BPT; q++) {
+    sm.bstart[tid * BPT + q] = (u16)ex;
+    ex += c[q];
+  }
+  if (tid == 0) sm.bstart[NB] = (u16)tot;
+  return tot;
+}
+
+// build rows t[0 .. XE_ROWS) of this thread (row j = k * XE_THREADS + tid, valid while j < n) -> bkey[], bval[] sorted by (key, val)
+__device__ __forceinline__ void xe_sort_build(ExpandSmem& sm, Tup (&t)[XE_ROWS], u32 n, int bsh, int tid) {
   constexpr u32 NB = 1u << XE_LOGB, BPT = NB / XE_THREADS;
   const u32 mask = NB - 1;
 #pragma unroll
@@ -2417,30 +2447,15 @@ __device__ __forceinline__ void xe_sort_side(ExpandSmem& sm, Tup (&t)[XE_ROWS], 
     arr[k] = j < n ? atomicAdd(&sm.cnt[bk[k]], 1u) : 0u;
   }
   lds_barrier();
-  {  // exclusive scan of the bucket counts -> bstart
-    u32 c[BPT], sum = 0;
-#pragma unroll
-    for (u32 q = 0; q < BPT; q++) {
-      c[q] = sm.cnt[tid * BPT + q];
-      sum += c[q];
-    }
-    u32 tot;
-    u32 ex = block_excl_scan_u32<XE_THREADS>(sum, sm.scratch, &tot, tid);
-#pragma unroll
-    for (u32 q = 0; q < BPT; q++) {
-      sm.bstart[tid * BPT + q] = (u16)ex;
-      ex += c[q];
-    }
-    if (tid == 0) sm.bstart[NB] = (u16)tot;
-  }
+  xe_scan_buckets(sm, tid);
   lds_barrier();
 #pragma unroll
   for (int k = 0; k < XE_ROWS; k++) {
     const u32 j = (u32)k * XE_THREADS + tid;
     if (j < n) {
       const u32 slot = sm.bstart[bk[k]] + arr[k];
-      K[slot] = t[k].key;
-      V[slot] = t[k].val;
+      sm.bkey[slot] = t[k].key;
+      sm.bval[slot] = t[k].val;
     }
   }
   lds_barrier();
@@ -2451,13 +2466,13 @@ __device__ __forceinline__ void xe_sort_side(ExpandSmem& sm, Tup (&t)[XE_ROWS], 
     const u32 j = (u32)k * XE_THREADS + tid;
     pos[k] = 0xFFFFFFFFu;
     if (j < n) {
-      const u64 key = K[j], val = V[j];
+      const u64 key = sm.bkey[j], val = sm.bval[j];
       t[k].key = key;
       t[k].val = val;
       const u32 b = key_bucket(key, bsh, mask), b0 = sm.bstart[b], b1 = sm.bstart[b + 1];
       u32 r = 0;
       for (u32 i = b0; i < b1; i++) {
-        const u64 k2 = K[i], v2 = V[i];
+        const u64 k2 = sm.bkey[i], v2 = sm.bval[i];
         r += (k2 < key || (k2 == key && (v2 < val || (v2 == val && i < j)))) ? 1u : 0u;
       }
       pos[k] = b0 + r;
@@ -2467,8 +2482,8 @@ __device__ __forceinline__ void xe_sort_side(ExpandSmem& sm, Tup (&t)[XE_ROWS], 
 #pragma unroll
   for (int k = 0; k < XE_ROWS; k++) {
     if (pos[k] != 0xFFFFFFFFu) {
-      K[pos[k]] = t[k].key;
-      V[pos[k]] = t[k].val;
+      sm.bkey[pos[k]] = t[k].key;
+      sm.bval[pos[k]] = t[k].val;
     }
   }
   lds_barrier();
@@ -2479,12 +2494,9 @@ __global__ __launch_bounds__(XE_THREADS) void probe_expand_ordered_kernel(ProbeA
   ExpandSmem& sm = *reinterpret_cast<ExpandSmem*>(smem_raw);
   const Tup* __restrict__ R = static_cast<const Tup*>(a.R);
   const Tup* __restrict__ S = static_cast<const Tup*>(a.S);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int bsh = key_low - XE_LOGB;
-  constexpr u32 NB = 1u << XE_LOGB;
-  u32* off = reinterpret_cast<u32*>(sm.bkey);      // [XE_CAP]: first result row of build row i (sorted order)
-  u16* s0 = reinterpret_cast<u16*>(off + XE_CAP);  // [XE_CAP]: where build row i's run of probe rows starts; bit 15: the row equals its predecessor
-  static_assert(XE_CAP * 4 + XE_CAP * 2 <= XE_CAP * 8 && XE_CAP < 0x8000, "off[] and s0[] fit the build keys' place");
+  constexpr u32 NB = 1u << XE_LOGB, BPT = NB / XE_THREADS, NONE = 0xFFFFu;
   bool toobig = false;
   if (tid == 0) sm.flag = 0;
   __syncthreads();
@@ -2506,9 +2518,118 @@ __global__ __launch_bounds__(XE_THREADS) void probe_expand_ordered_kernel(ProbeA
       br[k] = load_stream(&R[(u64)rb + (j < nb ? j : nb - 1)]);
       pr[k] = load_stream(&S[(u64)sb + (j < np ? j : np - 1)]);
     }
-    xe_sort_side(sm, br, nb, sm.bkey, sm.bval, bsh, tid);
-    xe_sort_side(sm, pr, np, sm.skey, sm.sval, bsh, tid);  // (leaves the probe side's buckets in bstart)
-    // every build row: its key's probe rows = the equal keys inside the probe side's bucket of that key
+    if (tid == 0) {
+      sm.vmin = ~0ull;
+      sm.vmax = 0;
+    }
+    xe_sort_build(sm, br, nb, bsh, tid);
+    // ---- 2. key ids: lower bound of every probe key in the sorted build keys (the five searches of a thread in lockstep)
+    u32 id[XE_ROWS];
+    {
+      u32 lo[XE_ROWS], hi[XE_ROWS];  // first index with bkey >= key lies in [lo, hi]
+#pragma unroll
+      for (int k = 0; k < XE_ROWS; k++) {
+        lo[k] = 0;
+        hi[k] = nb;
+      }
+#pragma unroll 1
+      for (u32 span = nb; span > 0; span >>= 1) {  // (13 rounds at most: every round halves hi - lo)
+#pragma unroll
+        for (int k = 0; k < XE_ROWS; k++) {
+          if (lo[k] < hi[k]) {
+            const u32 mid = (lo[k] + hi[k]) >> 1;
+            if (sm.bkey[mid] < pr[k].key) lo[k] = mid + 1; else hi[k] = mid;
+          }
+        }
+      }
+      u64 mn = ~0ull, mx = 0;
+#pragma unroll
+      for (int k = 0; k < XE_ROWS; k++) {
+        const u32 j = (u32)k * XE_THREADS + tid;
+        id[k] = NONE;
+        if (j < np && lo[k] < nb && sm.bkey[lo[k]] == pr[k].key) {
+          id[k] = lo[k];
+          mn = pr[k].val < mn ? pr[k].val : mn;
+          mx = pr[k].val > mx ? pr[k].val : mx;
+        }
+      }
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) {
+        const u64 a2 = __shfl_xor(mn, o, kWave), b2 = __shfl_xor(mx, o, kWave);
+        mn = a2 < mn ? a2 : mn;
+        mx = b2 > mx ? b2 : mx;
+      }
+      if (lane == 0 && mn <= mx) {
+        atomicMin(&sm.vmin, (unsigned long long)mn);
+        atomicMax(&sm.vmax, (unsigned long long)mx);
+      }
+    }
+#pragma unroll
+    for (u32 q = 0; q < BPT; q++) sm.cnt[tid * BPT + q] = 0;
+    lds_barrier();
+    // ---- 3. the matched probe rows sorted by (key id, payload): bucket = key id bits, then payload-position bits
+    const u64 vmin = sm.vmin, vmax = sm.vmax;
+    const int nbits = nb > 1 ? 32 - __builtin_clz(nb - 1) : 0;             // key ids < 2^nbits
+    const int svb = nbits < XE_LOGB ? XE_LOGB - nbits : 0;                 // bucket bits left for the payload
+    const int idsh = nbits > XE_LOGB ? nbits - XE_LOGB : 0;                // ... or several key ids per bucket
+    const int rbits = vmax > vmin ? 64 - __builtin_clzll(vmax - vmin) : 0;
+    const int vsh = rbits > svb ? rbits - svb : 0;
+    auto bucket_of = [&](u32 kid, u64 v) -> u32 { return svb ? ((kid << svb) | (u32)((v - vmin) >> vsh)) : (kid >> idsh); };
+    u32 arr[XE_ROWS], bk[XE_ROWS];
+#pragma unroll
+    for (int k = 0; k < XE_ROWS; k++) {
+      bk[k] = 0;
+      arr[k] = 0;
+      if (id[k] != NONE) {
+        bk[k] = bucket_of(id[k], pr[k].val);
+        arr[k] = atomicAdd(&sm.cnt[bk[k]], 1u);
+      }
+    }
+    lds_barrier();
+    const u32 nm = xe_scan_buckets(sm, tid);  // matched probe rows
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < XE_ROWS; k++) {
+      if (id[k] != NONE) {
+        const u32 slot = sm.bstart[bk[k]] + arr[k];
+        sm.sid[slot] = (u16)id[k];
+        sm.sval[slot] = pr[k].val;
+      }
+    }
+    lds_barrier();
+    {
+      u32 pos[XE_ROWS], kid[XE_ROWS];
+      u64 val[XE_ROWS];
+#pragma unroll
+      for (int k = 0; k < XE_ROWS; k++) {
+        const u32 j = (u32)k * XE_THREADS + tid;
+        pos[k] = 0xFFFFFFFFu;
+        kid[k] = 0;
+        val[k] = 0;
+        if (j < nm) {
+          kid[k] = sm.sid[j];
+          val[k] = sm.sval[j];
+          const u32 b = bucket_of(kid[k], val[k]), b0 = sm.bstart[b], b1 = sm.bstart[b + 1];
+          u32 r = 0;
+          for (u32 i = b0; i < b1; i++) {
+            const u32 k2 = sm.sid[i];
+            const u64 v2 = sm.sval[i];
+            r += (k2 < kid[k] || (k2 == kid[k] && (v2 < val[k] || (v2 == val[k] && i < j)))) ? 1u : 0u;
+          }
+          pos[k] = b0 + r;
+        }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int k = 0; k < XE_ROWS; k++) {
+        if (pos[k] != 0xFFFFFFFFu) {
+          sm.sid[pos[k]] = (u16)kid[k];
+          sm.sval[pos[k]] = val[k];
+        }
+      }
+      lds_barrier();
+    }
+    // ---- 4. every build row: its key's run of sorted probe rows
     u32 c[XE_ROWS], st[XE_ROWS], sum = 0;
 #pragma unroll
     for (int k = 0; k < XE_ROWS; k++) {
@@ -2517,54 +2638,62 @@ __global__ __launch_bounds__(XE_THREADS) void probe_expand_ordered_kernel(ProbeA
       st[k] = 0;
       if (i < nb) {
         const u64 key = sm.bkey[i];
+        u32 kid = i;  // the key's first build row
+        while (kid > 0 && sm.bkey[kid - 1] == key) kid--;
         // (a build row that equals its predecessor in key AND payload: the two rows' result rows are the same rows, and
         //  the order by sval runs across both -- see the copy-out)
-        if (i > 0 && sm.bkey[i - 1] == key && sm.bval[i - 1] == sm.bval[i]) st[k] = 0x8000u;
-        const u32 b = key_bucket(key, bsh, NB - 1), b0 = sm.bstart[b], b1 = sm.bstart[b + 1];
-        u32 first = b1, n = 0;
-        for (u32 j = b0; j < b1; j++) {
-          const u64 k2 = sm.skey[j];
-          if (k2 == key) {
-            first = j < first ? j : first;
-            n++;
+        const u32 tie = (i > 0 && sm.bkey[i - 1] == key && sm.bval[i - 1] == sm.bval[i]) ? 0x8000u : 0u;
+        u32 first, n;
+        if (idsh == 0) {  // the key id owns whole buckets: its run is what lies between their boundaries
+          first = sm.bstart[kid << svb];
+          n = sm.bstart[(kid + 1) << svb] - first;
+        } else {
+          const u32 b = kid >> idsh, b0 = sm.bstart[b], b1 = sm.bstart[b + 1];
+          first = b1;
+          n = 0;
+          for (u32 j = b0; j < b1; j++) {
+            if (sm.sid[j] == kid) {
+              first = j < first ? j : first;
+              n++;
+            }
           }
         }
         c[k] = n;
-        st[k] |= first;  // (first <= XE_CAP < 2^15)
+        st[k] = tie | first;
       }
       sum += c[k];
     }
     u32 tot;
-    u32 ex = block_excl_scan_u32<XE_THREADS>(sum, sm.scratch, &tot, tid);  // (its barriers: everybody has read bkey)
+    u32 ex = block_excl_scan_u32<XE_THREADS>(sum, sm.scratch, &tot, tid);
 #pragma unroll
     for (int k = 0; k < XE_ROWS; k++) {
       const u32 i = (u32)tid * XE_ROWS + k;
       if (i < nb) {
-        off[i] = ex;
-        s0[i] = (u16)st[k];
+        sm.off[i] = ex;
+        sm.s0[i] = (u16)st[k];
       }
       ex += c[k];
     }
     if (tid == 0 && tot != total) sm.flag = 1;  // (the count pass and this kernel disagree: never expected; the caller falls back)
     lds_barrier();
-    // result rows by output index.  Build row lo's rows are (its payload) x (its key's run of probe rows, by sval); g build
-    // rows that agree in key and payload share ONE block of g * cs rows in which every probe row appears g times in a row.
+    // ---- 5. result rows by output index.  Build row lo's rows are (its payload) x (its key's run of probe rows, by sval); g
+    // build rows that agree in key and payload share ONE block of g * cs rows in which every probe row appears g times in a row.
     for (u32 o = (u32)tid; o < tot && tot == total; o += XE_THREADS) {
       u32 lo = 0, hi = nb;  // off[lo] <= o < off[hi] (off[nb] = tot, not stored)
 #pragma unroll 1
       while (hi - lo > 1) {
         const u32 mid = (lo + hi) >> 1;
-        if (off[mid] <= o) lo = mid; else hi = mid;
+        if (sm.off[mid] <= o) lo = mid; else hi = mid;
       }
-      const u32 cs = (lo + 1 < nb ? off[lo + 1] : tot) - off[lo];
+      const u32 cs = (lo + 1 < nb ? sm.off[lo + 1] : tot) - sm.off[lo];
       u32 q = 0, g = 1;  // lo is the q-th of g equal build rows
 #pragma unroll 1
-      while (s0[lo - q] & 0x8000u) q++;
+      while (sm.s0[lo - q] & 0x8000u) q++;
 #pragma unroll 1
-      while (lo + g - q < nb && (s0[lo + g - q] & 0x8000u)) g++;
-      const u32 x = (o - off[lo]) + q * cs;
-      const u32 s = ((u32)s0[lo] & 0x7FFFu) + (g == 1 ? x : x / g);
-      a.out_key[ob + o] = sm.skey[s];
+      while (lo + g - q < nb && (sm.s0[lo + g - q] & 0x8000u)) g++;
+      const u32 x = (o - sm.off[lo]) + q * cs;
+      const u32 s = ((u32)sm.s0[lo] & 0x7FFFu) + (g == 1 ? x : x / g);
+      a.out_key[ob + o] = sm.bkey[lo];
       a.out_rval[ob + o] = sm.bval[lo];
       a.out_sval[ob + o] = sm.sval[s];
     }

@@ -1624,6 +1624,33 @@ def test_ordered_rows_of_duplicate_build_keys_are_written_in_order(ex_part_fresh
                 for _ in range(8):
                     ex.join_device(Bd, Pd, H.HMJ_ORDERED)
         ex.release_result()
+    # few keys per partition (a small dimension table with duplicate ids under a long fact table: runs of hundreds of probe
+    # rows per key): the kernel's sort buckets then cut the runs by payload position -- with row-id payloads, payloads from a
+    # handful of values, and one constant payload
+    os.environ["HMJ_GTABLE_SORT"] = "0"
+    os.environ["HMJ_EXPAND_FK_FANOUT"] = "1"  # (+ unique build keys with long runs through the same kernel)
+    try:
+        e2 = H.Executor(0)
+    finally:
+        del os.environ["HMJ_GTABLE_SORT"], os.environ["HMJ_EXPAND_FK_FANOUT"]
+    seen = 0
+    for nb, keys_n, npb, pay in [(60000, 20000, 2000000, "ids"), (60000, 20000, 2000000, "few"), (20000, 20000, 3000000, "ids"),
+                                 (30000, 30000, 2500000, "const"), (3000, 1000, 400000, "ids"), (9, 3, 200000, "ids")]:
+        pool = rng.integers(0, 1 << 62, keys_n, dtype=np.uint64)
+        B = np.stack([pool[rng.permutation(nb) % keys_n], rng.permutation(nb).astype(np.uint64)], 1)
+        P = np.stack([pool[rng.integers(0, keys_n, npb)], rng.permutation(npb).astype(np.uint64) + np.uint64(1 << 33)], 1)
+        if pay == "few":
+            P[:, 1] = rng.integers(0, 7, npb).astype(np.uint64)
+        elif pay == "const":
+            P[:, 1] = np.uint64(42)
+        ck, rows = oracle.equijoin(B, P)
+        r = e2.join_device(to_dev(B), to_dev(P), H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+        t = e2.last_timing()
+        seen += bool(t["path"] & XE)  # (where the key sample sees a hot key the partitions are split: write + sort)
+        assert r.checks() == ck and np.array_equal(e2.columns_to_numpy(r, host=False), rows), (nb, keys_n, npb, pay, hex(t["path"]))
+        e2.release_result()
+    e2.close()
+    assert seen >= 3, seen
     # exactly 16 copies of every key on both sides: partition sizes then vary like 16 x (a partition's key count) -- a dozen of
     # the planned 4096-row partitions exceed the kernel's 4608 rows, none by much: the join starts over with one more radix
     # bit instead of sorting 3 * 10^7 result rows
