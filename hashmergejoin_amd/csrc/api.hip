@@ -678,6 +678,9 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     }
     if ((rc = ensure_dev(c, c->lookback, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->lookback.p, 0, ((size_t)P + 1) * 8, c->stream));
+    // long runs (from 24 probe rows per build row on): the kernel's instantiation that buckets the output slots by (build
+    // rank, payload position) and ranks inside those buckets instead of inside whole runs (HMJ_FK_PAYLOAD_BUCKETS=0: never)
+    wa.extra = (wa.extra & 3u) | ((fk && c->fk_payload_buckets && nb > 0 && (double)np >= (double)c->fk_payload_buckets * (double)nb) ? 4u : 0u);
     int sp = span_begin(c, K_PROBE_WRITE, -1);
     HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, shape, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
     span_end(c, sp);
@@ -1904,6 +1907,14 @@ static int slab_chain(hmj_ctx* c, const void* dense_in, u32 n, const ChainDigit*
 // The partitioned paths rank every probe row inside its key's run, linear in the run length, and plan 18 bits for these
 // shapes: 2^16 x 2^26 rows 14-22 ms, 2^10 x 2^22 6 ms.  Anything else -- duplicate build keys, payloads too wide, a table
 // that gives up -- leaves *done false and the partitioned paths run (8 joins of cool-down).
+// ns per probe row of the partitioned one-pass ordered foreign-key write at fan-out f (profiles/r04u_side_fk_payload_buckets.txt)
+static double ordered_part_ns(double f) {
+  if (f > 700.0) return 0.25;  // (runs beyond the kernel's partitions: write + order epilogue)
+  const double lin = 0.030 + 0.00023 * f;
+  if (f < 24.0) return lin;
+  const double bucketed = 0.043 + (f > 128.0 ? 0.0001 * (f - 128.0) : 0.0);
+  return lin < bucketed ? lin : bucketed;
+}
 int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
                             hmj_result* out, bool to_host, bool* done) {
   *done = false;
@@ -1919,7 +1930,10 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     // (the plan changes), and from ~700 rows per key on it declines (runs beyond its capacity) and the write + order
     // epilogue takes over at 0.25 ns per row and more.  HMJ_GTABLE_SORT_FANOUT=1 (the experiments) skips the model.
     const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
-    const double part_ns = f < 200.0 ? 0.030 + 0.00023 * f : f <= 700.0 ? 0.00041 * f : 0.25;
+    // (later in round 4 the one-pass write learned to rank inside (build rank, payload position) buckets from fan-out 24 on:
+    //  0.043 ns per row up to fan-out ~130, + 0.0001 per further probe row per key -- 2^18 x 2^26: 7.5 -> 3.9 ms, 2^20 x 2^28:
+    //  29.3 -> 15.8 -- so this path is now for fan-outs beyond ~500 and for runs the kernel's partitions cannot hold)
+    const double part_ns = ordered_part_ns(f);
     // (round 4, later: 0.060 where the composites' passes are the chain of slab passes below, 0.072 on exact passes, + 0.02
     //  where the table leaves the L2 -- profiles/r04p_side_rank_sort_slab_chain.txt)
     const bool chain = c->gtable_sort_slab && c->slab_mode && c->gtable_sort_slab_cooldown == 0 && n_probe >= c->gtable_sort_slab_min;
@@ -1973,7 +1987,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   const bool wide = rank_bits + range_bits > 64;
   if (wide && c->gtable_sort_fanout > 1) {  // (ten passes instead of four or five: about 1.6 x the time per row)
     const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
-    const double part_ns = f < 200.0 ? 0.030 + 0.00023 * f : f <= 700.0 ? 0.00041 * f : 0.25;
+    const double part_ns = ordered_part_ns(f);
     if (0.65 + 0.145 * rows >= 0.15 + part_ns * rows) {
       c->gtable_sort_cooldown = 8;
       return HMJ_OK;
@@ -2239,6 +2253,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB")) c->gtable_sort_slab = atoi(e) != 0;  // 0: the composites' LSD passes are exact passes (hist + scan + scatter)
+  if (const char* e = getenv("HMJ_FK_PAYLOAD_BUCKETS")) c->fk_payload_buckets = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // fan-out from which the ordered foreign-key write buckets by payload (0: never)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
   if (const char* e = getenv("HMJ_ORDERED_EXPANSION")) c->expand_mode = atoi(e) != 0;  // 0: ordered joins with duplicate build keys write in probe order and sort the rows
   if (const char* e = getenv("HMJ_SORT_SLAB")) c->sort_slab = atoi(e) != 0;  // 0: hmj_sort_u64_device runs exact passes (hist + scan + scatter)

@@ -107,6 +107,7 @@ struct hmj_ctx {
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
   int gtable_sort_slab_cooldown = 0;
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)
+  u32 fk_payload_buckets = 24;     // the one-pass ordered foreign-key write ranks inside (build rank, payload position) buckets from this fan-out on (HMJ_FK_PAYLOAD_BUCKETS; 0: never)
   u32 expand_fk_fanout = 0;        // ordered foreign-key joins (unique build keys) take the expansion from this fan-out on (HMJ_EXPAND_FK_FANOUT; 0: never)
   int expand_cooldown = 0;
   bool expand_allow_rebits = true;  // (false during the retry that already took one more bit)

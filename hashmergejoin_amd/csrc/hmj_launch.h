@@ -105,7 +105,7 @@ struct ProbeArgs {
   const u64* item_base;    // unique-key write mode, slab layout: first output slot of partition p
   const u32* r_end;        // optional: end of partition p's build rows (NULL: r_off[p + 1]); with s_end this lets
   const u32* s_end;        // several "virtual" partitions share one build range (oversized probe partitions are split)
-  u32 extra;               // unique-key write mode: also accumulate checksums / sum_probe_all
+  u32 extra;               // unique-key write mode: bit 0 also accumulate checksums / sum_probe_all, bit 1 first-wins (count ext), bit 2 the ordered foreign-key write buckets its output slots by payload position
   u32 pfx_shift;           // ordered mode: verify (key >> pfx_shift) == pfx_val for every row (0 = off)
   u64 pfx_val;
   u32* matched;            // HMJ_FIRST_WINS + chunked build: one bit per probe row already paired

@@ -1027,6 +1027,7 @@ struct SortedFkSmem {
   u32 flag;
   u64 obase;
   u64 red[8];
+  unsigned long long vmin, vmax;  // the partition's matched probe payloads (round 4: buckets over (key, payload position))
 };
 static_assert(sizeof(SortedFkSmem<SWF_HALF_THREADS, SWF_HALF_ROWS, SWF_HALF_CAPB, SWF_HALF_LOGB>) <= 80 * 1024, "two workgroups per CU");
 static_assert(SWF_HALF_CAPB <= SWF_HALF_THREADS * SWF_HALF_ROWS, "tmpkey aliases sval");
@@ -1068,7 +1069,7 @@ __device__ __forceinline__ u64 lookback_publish(u64* __restrict__ state, u32 p, 
 // mixing arithmetic out of its registers (it ran at the 128-register limit of a 1024-thread workgroup with up to
 // 96 bytes of scratch per lane; the scratch reloads showed as 38 % more fetched bytes than the rows themselves,
 // profiles/r03a_ordered_unique_before_summary.txt).
-template <int THREADS, bool SLAB, bool FK, bool EXTRA, int ROWS = FP_ROWS, int CAPB_ = SWF_CAPB, int LOGB_ = SWF_LOGB>
+template <int THREADS, bool SLAB, bool FK, bool EXTRA, int ROWS = FP_ROWS, int CAPB_ = SWF_CAPB, int LOGB_ = SWF_LOGB, bool PB = false>
 __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArgs a, u64* __restrict__ lookback, int key_low, bool chained) {
   static_assert(FK || ROWS == ROWS, "the bitmap form has one shape");
   typedef typename std::conditional<FK, SortedFkSmem<THREADS, ROWS, CAPB_, LOGB_>, SortedSmem<THREADS>>::type Smem;
@@ -1190,6 +1191,10 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     lds_barrier();  // bucket counts complete; the next ticket is visible
     if constexpr (FK) {  // the match counts (the previous partition's copy-out is over: one barrier since)
       for (u32 i = tid; i < CAPB + 2; i += THREADS) sm.mcnt[i] = 0;  // (+ anydup, hot: the two words behind the array)
+      if (tid == 0) {
+        sm.vmin = ~0ull;
+        sm.vmax = 0;
+      }
     } else {
       if ((u32)tid < WORDS) sm.mbits[par ^ 1][tid] = 0;  // the next partition's bitmap (the previous one's copy-out is over)
     }
@@ -1309,6 +1314,22 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
     u32 found[FK ? ROWS : 1], slot[FK ? ROWS : 1];  // foreign-key form: a probe row's match, sorted rank + 1 (0 = none); its arrival number in the key's run
 #pragma unroll
     for (int k = 0; k < (FK ? ROWS : 1); k++) found[k] = slot[k] = 0;
+    // Foreign-key form, round 4: where the partition's build rows leave bucket bits over (2^b >= build rows, b < LOGB) the
+    // output slots are bucketed by (sorted build rank, position of the payload in the partition's payload range) instead of by
+    // build rank alone: a row then ranks itself among the few rows of its bucket, not among the f rows of its key's run --
+    // the ranking was half of this kernel's instructions at fan-out 16 and grew linearly with the fan-out.
+    int svb = 0, vsh = 0;
+    u64 vmin = 0;
+    // (The caller asks for it from ~24 probe rows per build row on: below, the extra barrier, the payload range and the scan
+    //  over all buckets cost more than the shorter ranking saves -- write phase at fan-out 8 / 16 / 32 / 64 / 256, 2^28 probe
+    //  rows: 4.3 / 5.4 / 6.0 / 8.8 / 24.2 ms without, 4.8 / 5.8 / 5.9 / 6.8 / 10.9 with.)
+    // (PB: its own instantiation -- as a run-time branch the added code cost the short-run joins 10 % in registers and scratch)
+    if constexpr (FK && PB) {
+      if (regular) {
+        const int nbits = nb > 1 ? 32 - __builtin_clz(nb - 1) : 0;
+        svb = nbits < (int)Smem::LOGB ? (int)Smem::LOGB - nbits : 0;
+      }
+    }
     if constexpr (!FK) {
       if (regular && sm.flag == 0) {
         // probe: scan the key's bucket (five rows in lockstep so their LDS latencies overlap).  Per row one packed
@@ -1391,10 +1412,41 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
             }
           }
         }
+        if (svb) {  // the partition's payload range, for the payload-position bits of the bucket number
+          u64 mn = ~0ull, mx = 0;
+#pragma unroll
+          for (int k = 0; k < ROWS; k++) {
+            if (found[k]) {
+              mn = pr[k].val < mn ? pr[k].val : mn;
+              mx = pr[k].val > mx ? pr[k].val : mx;
+            }
+          }
+#pragma unroll
+          for (int o = kWave / 2; o > 0; o >>= 1) {
+            const u64 a2 = __shfl_xor(mn, o, kWave), b2 = __shfl_xor(mx, o, kWave);
+            mn = a2 < mn ? a2 : mn;
+            mx = b2 > mx ? b2 : mx;
+          }
+          if (lane == 0 && mn <= mx) {
+            atomicMin(&sm.vmin, (unsigned long long)mn);
+            atomicMax(&sm.vmax, (unsigned long long)mx);
+          }
+        }
+      }
+      if (svb && regular) lds_barrier();
+      if (regular && sm.flag == 0) {
+        if (svb) {
+          vmin = sm.vmin;
+          const u64 vmax = sm.vmax;
+          const int rbits = vmax > vmin ? 64 - __builtin_clzll(vmax - vmin) : 0;
+          vsh = rbits > svb ? rbits - svb : 0;
+        }
 #pragma unroll
         for (int k = 0; k < ROWS; k++) {
           if (found[k]) {
-            slot[k] = atomicAdd(&sm.mcnt[found[k] - 1], 1u);  // arrival number among the probe rows of the key
+            // arrival number among the probe rows of the key -- or, with payload buckets, of the key's bucket
+            slot[k] = svb ? atomicAdd(&sm.cnt[((found[k] - 1) << svb) | (u32)((pr[k].val - vmin) >> vsh)], 1u)
+                          : atomicAdd(&sm.mcnt[found[k] - 1], 1u);
             acc_n++;
             acc_s += pr[k].val;
             if (EXTRA) {
@@ -1406,7 +1458,28 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
         }
       }
       if (regular) lds_barrier();
-      if (regular && sm.flag == 0) {  // uniform
+      if (regular && sm.flag == 0 && svb) {  // uniform
+        // every bucket's run of output slots: buckets are numbered (sorted build rank, payload position), i.e. in output order
+        u32 c[BPT], sum = 0, mx = 0;
+#pragma unroll
+        for (u32 q = 0; q < BPT; q++) {
+          c[q] = sm.cnt[tid * BPT + q];
+          sm.cnt[tid * BPT + q] = 0;  // (zero again for the next partition's build buckets)
+          sum += c[q];
+          mx = c[q] > mx ? c[q] : mx;
+        }
+        if (mx > (u32)SWF_MAXDUP) sm.mcnt[CAPB + 1] = 1;
+        if (mx > 1) sm.mcnt[CAPB] = 1;
+        u32 ex = block_excl_scan_u32<THREADS, false>(sum, sm.scratch, &total, tid);  // (a barrier follows below)
+#pragma unroll
+        for (u32 q = 0; q < BPT; q++) {
+          sm.bstart[tid * BPT + q] = (u16)ex;
+          ex += c[q];
+        }
+        if (tid == THREADS - 1) sm.bstart[tid * BPT + BPT] = (u16)ex;
+        lds_barrier();
+      }
+      if (regular && sm.flag == 0 && !svb) {  // uniform
         // every build row's run of output slots: exclusive scan of the match counts in sorted build order
         u32 c[ROWS], sum = 0, mx = 0;
 #pragma unroll
@@ -1434,7 +1507,7 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
 #pragma unroll
           for (int k = 0; k < ROWS; k++) {
             if (found[k]) {
-              const u32 o = sm.mcnt[found[k] - 1] + slot[k];
+              const u32 o = (svb ? (u32)sm.bstart[((found[k] - 1) << svb) | (u32)((pr[k].val - vmin) >> vsh)] : sm.mcnt[found[k] - 1]) + slot[k];
               sm.sval[o] = pr[k].val;
               sm.srank[o] = (u16)(found[k] - 1);
             }
@@ -1516,9 +1589,15 @@ __global__ __launch_bounds__(THREADS, 4) void probe_write_sorted_kernel(ProbeArg
           u64 v = 0;
           if (live) {
             si = sm.srank[j];
-            base = sm.mcnt[si];
-            c = (si + 1 < CAPB ? sm.mcnt[si + 1] : total) - base;
             v = sm.sval[j];
+            if (svb) {  // rank inside the (key, payload position) bucket: a few rows however long the key's run is
+              const u32 b = (si << svb) | (u32)((v - vmin) >> vsh);
+              base = sm.bstart[b];
+              c = (u32)sm.bstart[b + 1] - base;
+            } else {
+              base = sm.mcnt[si];
+              c = (si + 1 < CAPB ? sm.mcnt[si + 1] : total) - base;
+            }
           }
           u32 r = j - base;  // (runs of one row, or no repeating key in the partition: the slot is final)
           if (rank_runs) {
@@ -2243,23 +2322,31 @@ hipError_t launch_probe_write_uniq(const ProbeArgs& a, bool slab, int num_cus, h
 }
 
 // ordered unique-key write in one pass (probe_write_sorted_kernel); lookback: P + 1 words, zeroed by the caller
-template <bool SLAB, bool FK, bool EXTRA>
+template <bool SLAB, bool FK, bool EXTRA, bool PB = false>
 static hipError_t launch_sorted_t(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
   typedef typename std::conditional<FK, SortedFkSmem<1024>, SortedSmem<1024>>::type Smem;
   static_assert(sizeof(Smem) <= 160 * 1024, "one workgroup's LDS");
+  if constexpr (FK && !PB) {
+    if (a.extra & 4u) return launch_sorted_t<SLAB, FK, EXTRA, true>(a, lookback, chained, key_low, grid, st);  // payload buckets
+  }
   static SmemAttrOnce attr_once;
-  if (hipError_t e = ensure_max_smem(attr_once, reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, SLAB, FK, EXTRA>), sizeof(Smem)); e != hipSuccess) return e;
-  hipLaunchKernelGGL((probe_write_sorted_kernel<1024, SLAB, FK, EXTRA>), dim3(grid), dim3(1024), sizeof(Smem), st, a, lookback, key_low, chained);
+  const void* fn = reinterpret_cast<const void*>(probe_write_sorted_kernel<1024, SLAB, FK, EXTRA, FP_ROWS, SWF_CAPB, SWF_LOGB, PB>);
+  if (hipError_t e = ensure_max_smem(attr_once, fn, sizeof(Smem)); e != hipSuccess) return e;
+  hipLaunchKernelGGL((probe_write_sorted_kernel<1024, SLAB, FK, EXTRA, FP_ROWS, SWF_CAPB, SWF_LOGB, PB>), dim3(grid), dim3(1024), sizeof(Smem), st, a,
+                     lookback, key_low, chained);
   return hipGetLastError();
 }
 // the foreign-key form's other shapes: 512 threads x 6 rows (two workgroups per CU), 1024 threads x 6 rows
-template <int THREADS, int ROWS, int CAPB_, int LOGB_, bool SLAB, bool EXTRA>
+template <int THREADS, int ROWS, int CAPB_, int LOGB_, bool SLAB, bool EXTRA, bool PB = false>
 static hipError_t launch_sorted_shape_t(const ProbeArgs& a, u64* lookback, bool chained, int key_low, int grid, hipStream_t st) {
   typedef SortedFkSmem<THREADS, ROWS, CAPB_, LOGB_> Smem;
+  if constexpr (!PB) {
+    if (a.extra & 4u) return launch_sorted_shape_t<THREADS, ROWS, CAPB_, LOGB_, SLAB, EXTRA, true>(a, lookback, chained, key_low, grid, st);
+  }
   static SmemAttrOnce attr_once;
-  const void* fn = reinterpret_cast<const void*>(probe_write_sorted_kernel<THREADS, SLAB, true, EXTRA, ROWS, CAPB_, LOGB_>);
+  const void* fn = reinterpret_cast<const void*>(probe_write_sorted_kernel<THREADS, SLAB, true, EXTRA, ROWS, CAPB_, LOGB_, PB>);
   if (hipError_t e = ensure_max_smem(attr_once, fn, sizeof(Smem)); e != hipSuccess) return e;
-  hipLaunchKernelGGL((probe_write_sorted_kernel<THREADS, SLAB, true, EXTRA, ROWS, CAPB_, LOGB_>), dim3(grid), dim3(THREADS),
+  hipLaunchKernelGGL((probe_write_sorted_kernel<THREADS, SLAB, true, EXTRA, ROWS, CAPB_, LOGB_, PB>), dim3(grid), dim3(THREADS),
                      sizeof(Smem), st, a, lookback, key_low, chained);
   return hipGetLastError();
 }
