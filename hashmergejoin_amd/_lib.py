@@ -19,6 +19,7 @@ HMJ_PATH_DENSE_BUILD = 0x2000
 HMJ_PATH_GLOBAL_TABLE = 0x100000
 HMJ_PATH_ORDER_BY_RANK_SORT = 0x200000
 HMJ_PATH_ORDERED_EXPANSION = 0x400000
+HMJ_PATH_LDS_TABLE = 0x800000
 HMJ_PATH_SLAB_ONE_PASS = 0x80000
 HMJ_PATH_HOST_PIPELINE = 0x4000
 HMJ_PATH_SORTED_FK_HALF = 0x8000

@@ -1717,15 +1717,26 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   while (((u64)1 << log_cap) < (u64)c->gtable_slots_per_row * n_build) log_cap++;
   while (log_cap > c->gtable_max_log_cap && ((u64)1 << (log_cap - 1)) >= (n_build > c->gtable_max_rows ? 2 : 4) * n_build) log_cap--;  // (small joins of a bigger build side: 2 slots per row)
   const size_t tab_bytes = (size_t)16 << log_cap;
-  if ((rc = ensure_dev(c, c->gtab, tab_bytes)) != HMJ_OK) return rc;
+  // tiny build sides, count modes: the table in LDS, one copy per workgroup (gtable.hip, ltable_probe_kernel) -- a lookup in
+  // the L2-resident table moves a 128-byte line into L1 per probe row, which bounds that kernel at 0.42 ms per 2^26 probe rows
+  // (while its load factor stays low -- a wave walks until its longest walk ends: up to 2048 build rows, 1024 with the checksum
+  //  accumulators; 2^10 x 2^26 rows 0.36 -> 0.24 ms, 2^11: 0.41 -> 0.30, 2^12: 0.42 -> 0.57 and not taken)
+  const bool lds_table = !materialize && c->ltable_mode && n_probe >= (1u << 16) &&
+                         n_build <= (uint64_t)((flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE)) ? hmj::ltable_max_rows() / 4 : hmj::ltable_max_rows() / 2);
+  if (!lds_table && (rc = ensure_dev(c, c->gtab, tab_bytes)) != HMJ_OK) return rc;
   if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
   if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
   const bool first = flags & HMJ_FIRST_WINS, extra = flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE);
   HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
   int sp = span_begin(c, K_PROBE_COUNT, -1);
+  if (lds_table) {
+    HIP_TRY(hmj::launch_ltable_probe(R, (u32)n_build, S, (u32)n_probe, (u64*)c->accum.p, first, extra, c->num_cus, c->stream));
+  } else {
   HIP_TRY(hipMemsetAsync(c->gtab.p, 0xFF, tab_bytes, c->stream));  // every slot empty (key of all ones)
   HIP_TRY(hmj::launch_gtable_build(R, (u32)n_build, c->gtab.p, log_cap, (u64*)c->accum.p, first, c->num_cus, c->stream));
-  if (materialize) {
+  }
+  if (lds_table) {
+  } else if (materialize) {
     const size_t bytes = (size_t)(n_probe ? n_probe : 1) * 8;  // (at most one result row per probe row)
     if ((rc = ensure_dev(c, c->out_key, bytes)) != HMJ_OK) return rc;
     if ((rc = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return rc;
@@ -1762,7 +1773,7 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   out->xor_fold = hh[hmj::ACC_XOR];
   out->mix_sum = hh[hmj::ACC_MIX];
   out->sum_probe_all = hh[hmj::ACC_SUM_P];
-  c->timing.path |= HMJ_PATH_GLOBAL_TABLE;
+  c->timing.path |= HMJ_PATH_GLOBAL_TABLE | (lds_table ? HMJ_PATH_LDS_TABLE : 0u);
   c->timing.radix_bits = 0;
   c->timing.radix_passes = 0;
   c->timing.n_probe_items = 1;
@@ -2245,6 +2256,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
   if (const char* e = getenv("HMJ_ONE_PASS_SLAB")) c->one_pass_slab = atoi(e) != 0;  // 0: mid-size build sides keep the exact one-pass plan
   if (const char* e = getenv("HMJ_GTABLE")) c->gtable_mode = atoi(e) != 0;  // 0: small build sides are partitioned too
+  if (const char* e = getenv("HMJ_LTABLE")) c->ltable_mode = atoi(e) != 0;  // 0: tiny build sides take the L2-resident table too
   if (const char* e = getenv("HMJ_GTABLE_MAX_LOG2")) {
     const int l = atoi(e);
     if (l >= 0 && l <= 28) c->gtable_max_rows = 1ull << l;

@@ -100,6 +100,7 @@ struct hmj_ctx {
   u32 gtable_slots_per_row = 16;   // table slots per build row (HMJ_GTABLE_SLOTS) ...
   int gtable_max_log_cap = 18;     // ... while the table has at most 2^this slots; beyond, down to 4 per row (HMJ_GTABLE_MAX_LOG_CAP)
   int gtable_cooldown = 0;         // joins to skip it for after it gave up
+  bool ltable_mode = true;         // build sides <= 4096 rows, count modes: the table in LDS, one copy per workgroup (HMJ_LTABLE=0: the L2-resident table)
   bool gtable_sort_mode = true;    // HMJ_GTABLE_SORT=0: ordered joins of a small build side under a long probe side stay partitioned
   u32 gtable_sort_fanout = 128;    // ... from this many probe rows per build row on (HMJ_GTABLE_SORT_FANOUT)
   int gtable_sort_cooldown = 0;

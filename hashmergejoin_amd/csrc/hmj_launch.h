@@ -149,6 +149,9 @@ hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_c
                                u64* out_rval, u64* out_sval, bool first, bool extra, int num_cus, int wg_per_cu, hipStream_t st);
 
 // ordered results of a small build side under a long probe side: composites rank << range_bits | (sval - svmin), sorted, expanded
+// tiny build sides (<= ltable_max_rows()): the table in LDS, one copy per workgroup; count modes (FIRST: R's payload of the first row)
+hipError_t launch_ltable_probe(const void* R, u32 nb, const void* S, u32 np, u64* accum, bool first, bool extra, int num_cus, hipStream_t st);
+int ltable_max_rows();
 hipError_t launch_sval_range(const void* S, u32 np, u64* out2 /* {min, max}; caller: {~0, 0} */, int num_cus, hipStream_t st);
 // (wide: rank and payload as two words -- {payload, rank} emitted, sorted by payload, swapped, sorted by rank, expanded)
 hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,

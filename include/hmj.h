@@ -122,6 +122,7 @@ typedef struct {
 #define HMJ_PATH_SLAB_ONE_PASS 0x80000u /* ... of a ONE-pass plan: the probe kernel reads the pass's worker-private slabs directly */
 #define HMJ_PATH_ORDER_BY_RANK_SORT 0x200000u /* ordered, small build side under a long probe side: rows sorted as (key rank, payload) composites */
 #define HMJ_PATH_ORDERED_EXPANSION 0x400000u /* ordered, duplicate build keys: rows written in order partition by partition (no sort of result rows) */
+#define HMJ_PATH_LDS_TABLE 0x800000u /* ... of <= 4096 build rows, count modes: that table in LDS, one copy per workgroup */
 #define HMJ_PATH_GLOBAL_TABLE 0x100000u /* small build side: one global hash table, the probe side streamed unpartitioned */
 #define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
 

@@ -1382,7 +1382,7 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
     flagsets = (0, H.HMJ_CHECKSUM, H.HMJ_SUM_PROBE, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE,
                 H.HMJ_FIRST_WINS | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE)
     for nb, npb, miss, dup in [(1, 65536, 0, 0), (2, 70000, 2, 0), (1000, 65536 + 1023, 3, 0), (1000, 65536 + 1025, 0, 7),
-                               (4097, 300001, 5, 3), (60000, 262144, 0, 0), (65536, 1 << 20, 4, 5), (120000, 600000, 2, 0)]:
+                               (2000, 200000, 0, 2), (4097, 300001, 5, 3), (60000, 262144, 0, 0), (65536, 1 << 20, 4, 5), (120000, 600000, 2, 0)]:
         B = oracle.gen_build(nb)
         if dup:  # every dup-th key a second (third ...) time, a few rows further down: first-wins must mean input order
             m = len(B[dup - 1::dup])
@@ -1394,6 +1394,8 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
             r = ex.join_device(Bd, Pd, fl)
             t = ex.last_timing()
             assert t["path"] & GT and t["radix_passes"] == 0, (nb, npb, fl, hex(t["path"]))
+            # (up to 2048 build rows -- 1024 with checksums -- the table lives in LDS, a copy per workgroup: csrc/gtable.hip, ltable_probe_kernel)
+            assert bool(t["path"] & H.HMJ_PATH_LDS_TABLE) == (nb <= (1024 if fl & (H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE) else 2048)), (nb, npb, fl, hex(t["path"]))
             assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, fl)
             if fl & H.HMJ_CHECKSUM:
                 assert r.checks() == ck, (nb, npb, fl)
@@ -1443,8 +1445,7 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
     # what the table cannot hold sends the join to the partitioned path with the same answer, and the context skips
     # the attempt for the next 8 joins: (a) a build key equal to the empty-slot marker (all ones), (b) a key with
     # more copies than a lookup may walk
-    nb, npb = 5000, 200000
-    for case in ("marker", "copies"):
+    for nb, npb, case in ((5000, 200000, "marker"), (5000, 200000, "copies"), (900, 200000, "marker"), (900, 200000, "copies")):
         B, P = oracle.gen_build(nb), oracle.gen_uniform_domain(npb, nb)
         if case == "marker":
             B[77, 0] = np.uint64(M64)
