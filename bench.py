@@ -83,13 +83,63 @@ def cpu_baseline(log2n, threads, affinity):
         m = min(n, 1 << 22)  # the in-place sort is much slower: shorter sample, best of 3 (each run sorts a fresh copy)
         out["radix_int_inplace_keys_per_s"] = m / best_of(lambda: ref.radix_int_inplace(B[:m], threads), reps=3)
         out["radix_int_inplace_sample_log2"] = 22
-        out["partitioned_build_probe_tuples_per_s"] = n / best_of(lambda: ref.partitioned_join_sum(P, B, threads, 10), reps=2)  # hashjoin_bench.cc:88-96
+        # partition_only + partitioned_hash_table + probe (hashjoin_bench.cc:88-96): mutex-guarded node tables, ~3 M rows/s --
+        # a 2^22-row sample, one timed repetition (at 2^24 it took 17 of the bench's 32 s, VERDICT r4 #8)
+        mp = min(n, 1 << 22)
+        Bp, Pp = orc.gen_build(mp), orc.gen_probe(mp, mp)
+        out["partitioned_build_probe_tuples_per_s"] = mp / best_of(lambda: ref.partitioned_join_sum(Pp, Bp, threads, 10), reps=1)
+        out["partitioned_build_probe_sample_log2"] = 22
         for h in (rh, sh, oh):
             ref.pairs_free(h)
+        # BASELINE configs[0]: the reference's own benchmark relations (two create_strvec(10^6), std::string keys), construct
+        # + iterate timed as hashjoin_bench.cc:120-134 does; the GPU drop-in on the same relations: extra.configs0_strgen_1M_ms
+        words = os.path.join(ROOT, "tests", "golden", "words.txt")
+        try:
+            sec, ck = ref.hashmergejoin_strgen_timed(words, 1000000, threads, reps=3)
+            out["strgen_1M_seconds"] = sec
+            out["strgen_1M_tuples_per_s"] = 1000000 / sec
+            out["strgen_1M_checks"] = {"count": ck[0], "sum": ck[1], "fnv_pairs": ck[2]}
+            want = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["cases"]["strgen_join"] if c["n"] == 1000000][0]
+            out["strgen_1M_equals_golden"] = ck == (want["count"], want["sum"], want["fnv_pairs"])
+        except Exception as e:
+            out["strgen_1M_seconds"] = None
+            out["strgen_1M_error"] = repr(e)
     else:
         best = best_of(lambda: orc.hashmergejoin(B, P, 1, cap=0), reps=2)
         out.update(kind="port", cores=1, value=n / best, seconds=best, what="C restatement of HashMergeJoin ctor + iterate, 1 thread")
     return out
+
+
+def hipmalloc_cost_ms(sizes_gib=(1, 4)):
+    """What this box charges for creating device memory, in the bench process, before the library reserves its workspace:
+    hipMalloc + hipFree of 1 and 4 GiB straight through the HIP runtime (no caching allocator).  The first call of a join
+    context pays this per GB of partition buffers (18 GB at 2^28 x 2^28 rows): 0.3 ms in all on some boxes, 26 ms per GB on
+    the driver's round-4 box (VERDICT r4 #4) -- a property of the box, reported so that `reserve_ms` can be read."""
+    import ctypes as C
+
+    try:
+        hip = C.CDLL(None)
+        if not hasattr(hip, "hipMalloc"):
+            hip = C.CDLL("libamdhip64.so")
+        hip.hipMalloc.restype = C.c_int
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipFree.restype = C.c_int
+        hip.hipFree.argtypes = [C.c_void_p]
+        out = {}
+        for g in sizes_gib:
+            p = C.c_void_p()
+            t0 = time.perf_counter()
+            rc = hip.hipMalloc(C.byref(p), g << 30)
+            t1 = time.perf_counter()
+            if rc != 0:
+                return {"error": "hipMalloc(%d GiB) returned %d" % (g, rc)}
+            hip.hipFree(p)
+            out["%dGiB" % g] = {"hipMalloc_ms": round((t1 - t0) * 1e3, 3), "hipFree_ms": round((time.perf_counter() - t1) * 1e3, 3)}
+        big = out["%dGiB" % sizes_gib[-1]]["hipMalloc_ms"]
+        out["ms_per_GB"] = round(big / (sizes_gib[-1] * 1.073741824), 3)
+        return out
+    except Exception as e:  # reporting only
+        return {"error": repr(e)}
 
 
 def extra_runs(ex, H, torch):
@@ -111,6 +161,36 @@ def extra_runs(ex, H, torch):
         return round(best, 3), r
 
     out = {}
+    roofs = {}  # per entry: the algorithmic minimum of the call (every input row read once, every result row written once),
+    # the whole call's wall-clock ms and the fraction of the 8 TB/s peak those give -- whole calls, not kernels
+
+    def roof(key, ms, nb_, np_, rows=0, sort=False):
+        nbytes = 32 * nb_ if sort else 16 * (nb_ + np_) + 24 * rows
+        roofs[key] = {"algorithmic_bytes": nbytes, "ms": ms, "frac": round(nbytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+
+    # BASELINE configs[0] through the C++ drop-in: r = create_strvec(10^6), s = create_strvec(10^6) (strgen.cc:27-61 restated
+    # over the word-list fixture), HashMergeJoin<KeyValVec::iterator, ...> constructed + iterated (hashjoin_bench.cc:120-134):
+    # std::hash<std::string> on the host, {hash, row} pairs joined on the GPU, collisions resolved on the host.  A process
+    # of its own (tests/cpp/strgen_bench); count / sum / ordered FNV must equal the compiled reference's (the golden).
+    sb = os.path.join(ROOT, "tests", "cpp", "strgen_bench")
+    if os.path.exists(sb):
+        import subprocess
+
+        pr = subprocess.run([sb, os.path.join(ROOT, "tests", "golden", "words.txt"), "1000000", "5"], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, timeout=300)
+        js = [l for l in pr.stdout.decode().splitlines() if l.startswith("{")]
+        assert pr.returncode == 0 and js, ("strgen_bench failed", pr.returncode, pr.stderr.decode()[-500:])
+        sg = json.loads(js[-1])
+        want = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["cases"]["strgen_join"] if c["n"] == 1000000][0]
+        assert (sg["count"], sg["sum"], sg["fnv"]) == (want["count"], want["sum"], want["fnv_pairs"]), ("configs[0] differs from the golden", sg, want)
+        assert (sg["fnv_r"], sg["fnv_s"]) == (want["fnv_r"], want["fnv_s"]), "configs[0]: generated relations differ from the golden's"
+        out["configs0_strgen_1M_ms"] = sg["ms"]
+        out["configs0_strgen_1M"] = {"ms_ctor": sg["ms_ctor"], "ms_iterate": sg["ms_iterate"], "ms_first_call": sg["ms_first_call"],
+                                     "host_threads": sg["host_threads"], "tuples_per_s": round(1e6 / (sg["ms"] * 1e-3)),
+                                     "checked": "count / sum / ordered FNV of the pairs == tests/golden strgen_join (the compiled reference's output)"}
+    else:
+        out["configs0_strgen_1M_ms"] = None
+        out["configs0_strgen_1M"] = {"error": "tests/cpp/strgen_bench is not built (make)"}
     # small build sides (the reference's BM_hash_join_raw formulation, hashjoin_bench.cc:29-63): one global table, probe side unpartitioned
     n = 1 << 26
     for lb in (16, 20):
@@ -118,13 +198,16 @@ def extra_runs(ex, H, torch):
         ms, r = timed(lambda: ex.join_device(R, S, 0))
         assert int(r.n_matches) == n
         out["small_build_2p%d_x_2p26_count_ms" % lb] = ms
+        roof("small_build_2p%d_x_2p26_count_ms" % lb, ms, 1 << lb, n)
         if lb == 16:
             msm, rm = timed(lambda: ex.join_device(R, S, H.HMJ_MATERIALIZE))
             assert int(rm.n_matches) == n
             out["small_build_2p16_x_2p26_materialize_ms"] = msm
+            roof("small_build_2p16_x_2p26_materialize_ms", msm, 1 << lb, n, n)
             mso, ro = timed(lambda: ex.join_device(R, S, H.HMJ_ORDERED), reps=2)  # the operator's mode: rows in (key, rval, sval) order
             assert int(ro.n_matches) == n
             out["small_build_2p16_x_2p26_ordered_ms"] = mso
+            roof("small_build_2p16_x_2p26_ordered_ms", mso, 1 << lb, n, n)
             out["small_build_2p16_ordered_path"] = ("sort on (key rank, payload) composites" if ex.last_timing()["path"] & H.HMJ_PATH_ORDER_BY_RANK_SORT
                                                     else "partitioned (%d bits)" % ex.last_timing()["radix_bits"])
             ex.release_result()
@@ -138,12 +221,14 @@ def extra_runs(ex, H, torch):
     ms, r = timed(lambda: ex.join_device(R, S, 0))
     assert int(r.n_matches) == n
     out["configs1_2p26_planner_bits%d_ms" % ex.last_timing()["radix_bits"]] = ms
+    roof("configs1_2p26_planner_ms", ms, n, n)
     ex.set_radix_bits(10)
     try:
         ms, r = timed(lambda: ex.join_device(R, S, 0))
         assert int(r.n_matches) == n
         t = ex.last_timing()
         out["configs1_2p26_forced_10bit_ms"] = ms
+        roof("configs1_2p26_forced_10bit_ms", ms, n, n)
         out["configs1_2p26_forced_10bit_plan"] = "%d passes, chunked LDS build (%d-row build partitions)" % (t["radix_passes"], n >> 10)
     finally:
         ex.set_radix_bits(None)
@@ -164,6 +249,7 @@ def extra_runs(ex, H, torch):
         ms, r = timed(lambda: ex.join_device(R, S, fl), reps=2)
         assert int(r.n_matches) == n
         out["configs2_2p28_%s_ms" % name] = ms
+        roof("configs2_2p28_%s_ms" % name, ms, n, n, n)
     ex.release_result()
     del S
     # the same build side as the dimension table of a foreign-key join: 2^24 keys, 2^28 probe rows, ordered rows
@@ -172,6 +258,7 @@ def extra_runs(ex, H, torch):
     ms, r = timed(lambda: ex.join_device(Rf, Sf, H.HMJ_ORDERED), reps=2)
     assert int(r.n_matches) == 1 << 28
     out["fk_2p24_x_2p28_ordered_ms"] = ms
+    roof("fk_2p24_x_2p28_ordered_ms", ms, 1 << 24, 1 << 28, 1 << 28)
     ex.release_result()
     # ... and with runs of 64 probe rows per key (the run ranking is linear in the run length: DESIGN section 6)
     del Rf, Sf
@@ -180,6 +267,7 @@ def extra_runs(ex, H, torch):
     ms, r = timed(lambda: ex.join_device(Rf, Sf, H.HMJ_ORDERED), reps=2)
     assert int(r.n_matches) == 1 << 28
     out["fk_2p22_x_2p28_ordered_ms"] = ms
+    roof("fk_2p22_x_2p28_ordered_ms", ms, 1 << 22, 1 << 28, 1 << 28)
     ex.release_result()
     del R, Rf, Sf
     torch.cuda.empty_cache()
@@ -193,6 +281,7 @@ def extra_runs(ex, H, torch):
         top = torch.iinfo(torch.int64).min  # (flips the sign bit: signed compare of the flipped keys = unsigned order)
         assert bool(((k[1:] ^ top) >= (k[:-1] ^ top)).all()) and int(o[:, 1].sum()) == int(a[:, 1].sum()), name
         out["sort_2p28_%s_keys_ms" % name] = ms
+        roof("sort_2p28_%s_keys_ms" % name, ms, 1 << 28, 0, sort=True)
         out["sort_2p28_%s_path" % name] = "chain of slab passes + compaction" if ex.last_timing()["path"] & H.HMJ_PATH_SLAB else "exact passes"
         del a, o, k
         torch.cuda.empty_cache()
@@ -209,6 +298,7 @@ def extra_runs(ex, H, torch):
     ms, r = timed(lambda: ex.join_device(Rd, Sd, H.HMJ_ORDERED), reps=2)
     assert int(r.n_matches) == want_n
     out["dup8_ordered_ms"] = ms
+    roof("dup8_ordered_ms", ms, nd, nd, want_n)
     out["dup8_rows"] = want_n
     ex.release_result()
     del Rd, Sd
@@ -227,10 +317,12 @@ def extra_runs(ex, H, torch):
     Sz = ex.gen_uniform_domain(npb, nb)
     ms, r = timed(lambda: ex.join_device(Rz, Sz, 0), reps=2)
     out["configs4_zipf_2p24_x_2p30_count_ms"] = ms
+    roof("configs4_zipf_2p24_x_2p30_count_ms", ms, nb, npb)
     out["configs4_matches"] = int(r.n_matches)
     cross = {k: int(getattr(r, k)) for k in ("n_matches", "sum_r", "sum_s")}
     ms, r = timed(lambda: ex.join_device(Rz, Sz, H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE), reps=2)
     out["configs4_first_wins_ms"] = ms
+    roof("configs4_first_wins_ms", ms, nb, npb)
     # checked, not just printed: counts and sums recomputed in the generators' rank domain with plain torch ops
     # (tools/closed_forms.py; independent of the join kernels), cross product and first-wins (partitioned_hash.h:166-170)
     from tools.closed_forms import config5_checks
@@ -242,8 +334,8 @@ def extra_runs(ex, H, torch):
     out["configs4_checked"] = "n_matches / sum_r / sum_s of both modes == torch rank-domain closed forms"
     del Rz, Sz
     torch.cuda.empty_cache()
-    # (last: this join regrows the partition buffers -- a join allocates without searching for well-placed memory, and the
-    #  2^28-row runs above should see the buffers hmj_reserve placed)
+    # (last only because it regrows the partition buffers hmj_reserve placed for the 2^28-row runs; its plan does not depend on
+    #  what ran before it: what a context learns belongs to a workload, hmj_last_plan)
     # the reference's own sweep goes on to 10^9 rows (hashjoin_bench.cc:269-283): 5 * 10^8 x 5 * 10^8, count mode, on the
     # 17-bit plan the histogram-free slab partitioning makes since round 4 (9-bit + 8-bit pass)
     n = 500000000
@@ -252,44 +344,70 @@ def extra_runs(ex, H, torch):
     assert int(r.n_matches) == n and int(r.sum_r) == (n * (n - 1) // 2) % (1 << 64)
     t = ex.last_timing()
     out["scale_5e8_count_ms"] = ms
+    roof("scale_5e8_count_ms", ms, n, n)
     out["scale_5e8_plan"] = "%d bits, %s" % (t["radix_bits"], "slab path" if t["path"] & H.HMJ_PATH_SLAB else "exact path")
     del R, S
     torch.cuda.empty_cache()
+    out["roofline"] = dict(roofs, _what="per entry: algorithmic minimum bytes of the call (16 B per input row read once + 24 B per result row "
+                                        "written once; sorts: 32 B per row), wall-clock ms of the whole call, fraction of the %.0f GB/s peak; "
+                                        "per-kernel durations and PMC counters of the same workloads: profiles/r05a_paths_kernel_trace_and_pmc.txt" % HBM_PEAK_GBS)
     return out
 
 
-def self_launch(n_ranks):
+METRIC = "probe-side tuples/s + achieved HBM GB/s, |R|=|S|=2^28 u64 keys"
+
+
+def error_line(n_gpus, steps, warmup, what, detail=None):
+    """The line a failed run prints instead of a result: same metric / unit, value null, "error" set."""
+    d = {"metric": METRIC, "value": None, "unit": "probe tuples/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+         "higher_is_better": True, "error": what}
+    if detail:
+        d["detail"] = detail
+    return json.dumps(d)
+
+
+def self_launch(n_ranks, timeout_s, argv=None, steps=0, warmup=0):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this parent starts N fresh child processes
     -- one rank each, the same command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- relays rank 0's JSON line
     and returns the worst child status.  The parent never touches the GPU (no torch import, no HIP call): every
     rank initialises its GPU in a process of its own, as under torch.distributed.run.  The reference reaches all
-    of its workers from one call the same way (hashjoin.h:56-68 -> radix_hash.h:375-405)."""
+    of its workers from one call the same way (hashjoin.h:56-68 -> radix_hash.h:375-405).
+    Bounded: after timeout_s of wall clock (or 30 s after the first child failed) every child still running is stopped
+    by its own handle, each rank's stderr tail is relayed, and -- when rank 0 printed no line -- the parent prints one
+    with "error" set.  argv: the child command (tests pass a stand-in)."""
     import socket
     import subprocess
+    import tempfile
+    import threading
 
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    cmd = argv if argv is not None else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    logdir = tempfile.mkdtemp(prefix="hmj_bench_")
+    procs, errs = [], []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HMJ_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    import threading
-
+        errs.append(open(os.path.join(logdir, "rank%d.stderr" % r), "w+b"))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else errs[r], stderr=errs[r]))
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
     reader.start()  # rank 0 prints the line; EOF when it exits
-    # a rank that dies leaves the others in a collective: once one child has failed, the rest get 30 s, then are
-    # stopped (each by its own handle)
-    failed_at = None
+    t_start, failed_at, why = time.time(), None, None
     while any(p.poll() is None for p in procs):
+        now = time.time()
         if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
-            failed_at = time.time()
-        if failed_at is not None and time.time() - failed_at > 30.0:
-            for p in procs:
+            failed_at = now
+        if why is None and now - t_start > timeout_s:
+            why = "wall-clock limit of %.0f s reached with rank(s) %s still running" % (
+                timeout_s, ",".join(str(i) for i, p in enumerate(procs) if p.poll() is None))
+        elif why is None and failed_at is not None and now - failed_at > float(os.environ.get("HMJ_BENCH_GRACE_S", "30")):
+            why = "rank(s) %s failed; the others were stopped %s s later" % (
+                ",".join(str(i) for i, p in enumerate(procs) if p.poll() not in (None, 0)), os.environ.get("HMJ_BENCH_GRACE_S", "30"))
+        if why is not None:
+            for p in procs:  # each child by its own handle
                 if p.poll() is None:
                     p.kill()
         time.sleep(0.05)
@@ -299,9 +417,48 @@ def self_launch(n_ranks):
         rc = p.returncode
         if rc != 0 and (worst == 0 or abs(rc) > abs(worst)):
             worst = rc
-    sys.stdout.write(b"".join(out0).decode(errors="replace"))
+    text = b"".join(out0).decode(errors="replace")
+    sys.stdout.write(text)
+    if worst != 0 or why is not None:
+        tails = {}
+        for r, f in enumerate(errs):
+            f.seek(0)
+            tail = f.read().decode(errors="replace")[-1500:]
+            tails["rank%d" % r] = {"returncode": procs[r].returncode, "stderr_tail": tail}
+            sys.stderr.write("---- rank %d (exit %s) stderr tail ----\n%s\n" % (r, procs[r].returncode, tail))
+        if not any(l.startswith("{") for l in text.splitlines()):
+            print(error_line(n_ranks, steps, warmup, why or "a rank exited with status %d" % worst,
+                             {k: v["returncode"] for k, v in tails.items()}))
+        if worst == 0:
+            worst = 124
+    else:
+        for r, f in enumerate(errs):  # warnings of a good run stay visible
+            f.seek(0)
+            sys.stderr.write(f.read().decode(errors="replace"))
+    for f in errs:
+        f.close()
     sys.stdout.flush()
     return worst if worst >= 0 else 128 - worst
+
+
+def arm_process_watchdog(timeout_s, rank, n_gpus, steps, warmup):
+    """Under ANY launcher (torch.distributed.run included) a rank that is stuck -- a rendezvous, a barrier, a driver
+    call -- must not keep the whole job alive: after timeout_s this thread prints the error line (rank 0) and ends
+    the process with status 124.  The exchange itself gives up much earlier (hmj_comm_set_timeout_ms)."""
+    import threading
+
+    def fire():
+        msg = "rank %d: wall-clock limit of %.0f s reached" % (rank, timeout_s)
+        if rank == 0:
+            print(error_line(n_gpus, steps, warmup, msg), flush=True)
+        sys.stderr.write("bench.py: " + msg + "\n")
+        sys.stderr.flush()
+        os._exit(124)
+
+    t = threading.Timer(timeout_s, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -315,10 +472,15 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configs / modes timed beside the headline")
     ap.add_argument("--bits", type=int, default=-1, help="force total radix bits")
+    ap.add_argument("--timeout-s", type=float, default=900.0,
+                    help="wall-clock limit of the whole run; past it every rank is stopped and an error line is printed")
+    ap.add_argument("--step-timeout-s", type=float, default=120.0,
+                    help="N > 1: deadline of one exchange step inside the library (hmj_comm_set_timeout_ms)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(a.gpus))  # before anything touches the GPU
+        sys.exit(self_launch(a.gpus, a.timeout_s, steps=a.steps, warmup=a.warmup))  # before anything touches the GPU
+    watchdog = arm_process_watchdog(a.timeout_s, int(os.environ.get("RANK", "0")), a.gpus, a.steps, a.warmup)
 
     import torch
     import torch.distributed as dist
@@ -353,9 +515,14 @@ def main():
     if a.bits >= 0:
         ex.set_radix_bits(a.bits)
     if world > 1:
-        hdist.init_comm(ex)    # RCCL communicator inside the library (or the gloo callback transport)
+        hdist.init_comm(ex, timeout_s=a.step_timeout_s)  # RCCL communicator inside the library (or the gloo callback transport)
     elif force_dist:
-        hdist.init_comm_single(ex)
+        hdist.init_comm_single(ex, timeout_s=a.step_timeout_s)
+    # test hook (tests/test_dist_gpu.py): "kill:<rank>:<step>" ends that rank before its step, "stall:<rank>:<step>" makes
+    # it sleep instead of entering the step -- the other ranks must come back with HMJ_E_TIMEOUT and the run must end
+    fault = os.environ.get("HMJ_BENCH_FAULT", "").split(":")
+    fault = (fault[0], int(fault[1]), int(fault[2])) if len(fault) == 3 else None
+    step_no = [0]
     distributed = world > 1 or force_dist
     # synthetic relations generated on device: this rank's row shard [rank*n, (rank+1)*n)
     R = ex.gen_build(n, start=rank * n)
@@ -367,14 +534,30 @@ def main():
         if not distributed:
             res = ex.join_device(R, S, flags)
             return res, ex.last_timing(), None
-        loc, glob = ex.exchange_join(R, S, flags)  # owner split, exchange rounds, prepared build, local join
+        if fault and fault[1] == rank and fault[2] == step_no[0]:
+            if fault[0] == "kill":
+                os.kill(os.getpid(), 9)
+            time.sleep(10 * a.step_timeout_s)
+        step_no[0] += 1
+        try:
+            loc, glob = ex.exchange_join(R, S, flags)  # owner split, exchange rounds, prepared build, local join
+        except H.HmjError as e:
+            # a step that failed (HMJ_E_TIMEOUT: a peer never took part) ends the run on this rank at once: the line says why
+            if rank == 0:
+                print(error_line(world, a.steps, a.warmup, "exchange step %d failed: %s" % (step_no[0] - 1, e)), flush=True)
+            sys.stderr.write("bench.py rank %d: exchange step failed: %s\n" % (rank, e))
+            sys.stderr.flush()
+            os._exit(5)  # (no teardown: the communicator is gone and a torch barrier would wait for the lost peer)
         return glob, ex.last_timing(), ex.last_exchange_info()
 
     # Workspace ahead of the first join, as a caller who cares about the first join's latency does (hmj_reserve):
     # this is also where the library may search for well-placed partition buffers, under its wall-clock budget
     # (`placement`; a join that allocates on its own only probes what it got).  Outside the timed region.
     reserve_ms = None
+    malloc_cost = None
     if not distributed:
+        torch.cuda.synchronize()
+        malloc_cost = hipmalloc_cost_ms()
         t_w = time.perf_counter()
         ex.reserve(n, n, n if a.materialize else 0, flags)
         torch.cuda.synchronize()
@@ -482,7 +665,7 @@ def main():
         else:
             plan_txt = "%d-bit radix in %d LSD passes" % (last_tm["radix_bits"], last_tm["radix_passes"])
         line = {
-            "metric": "probe-side tuples/s + achieved HBM GB/s, |R|=|S|=2^28 u64 keys",
+            "metric": METRIC,
             "value": n_total * K / dt,
             "unit": "probe tuples/s",
             "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -505,6 +688,7 @@ def main():
             "placement": {"probing": os.environ.get("HMJ_PLACE", "default: joins probe only; hmj_reserve searches (<= 4 candidates, "
                                                                    "<= HMJ_PLACE_BUDGET_MS = 50 ms per buffer)"),
                           "buffers": ex.placement_info(),
+                          "hipmalloc_cost": malloc_cost,
                           "reserve_ms": None if reserve_ms is None else round(reserve_ms, 2),
                           "first_join_ms": None if first_ms is None else round(first_ms, 2)},
         }
@@ -549,6 +733,7 @@ def main():
                 except Exception as e:  # the baseline is reporting only; never fail the bench on it
                     line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    watchdog.cancel()
     ex.close()
     if world > 1:
         dist.destroy_process_group()

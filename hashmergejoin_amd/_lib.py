@@ -8,6 +8,7 @@ HMJ_ORDERED = 0x02
 HMJ_FIRST_WINS = 0x04
 HMJ_CHECKSUM = 0x08
 HMJ_SUM_PROBE = 0x10
+HMJ_E_RCCL, HMJ_E_PEER, HMJ_E_TIMEOUT = -6, -7, -8
 # hmj_timing.path bits
 HMJ_PATH_SLAB, HMJ_PATH_EXACT, HMJ_PATH_UNIQ_WRITE, HMJ_PATH_SPLIT, HMJ_PATH_WINDOW = 0x1, 0x2, 0x4, 0x8, 0x10
 HMJ_PATH_ORDER_DEFERRED, HMJ_PATH_ORDER_BY_KEY, HMJ_PATH_PREPARED, HMJ_PATH_CHUNKED_BUILD = 0x20, 0x40, 0x80, 0x100
@@ -20,6 +21,7 @@ HMJ_PATH_GLOBAL_TABLE = 0x100000
 HMJ_PATH_ORDER_BY_RANK_SORT = 0x200000
 HMJ_PATH_ORDERED_EXPANSION = 0x400000
 HMJ_PATH_LDS_TABLE = 0x800000
+HMJ_PATH_RANK_RUNS = 0x1000000
 HMJ_PATH_SLAB_ONE_PASS = 0x80000
 HMJ_PATH_HOST_PIPELINE = 0x4000
 HMJ_PATH_SORTED_FK_HALF = 0x8000
@@ -61,6 +63,32 @@ class Timing(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class PlanDesc(C.Structure):
+    """hmj_plan_desc: how the last join was planned and why (include/hmj.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("path", C.c_uint32), ("radix_bits", C.c_int32), ("radix_passes", C.c_int32),
+                ("pass_bits", C.c_int32 * 4), ("key_prefix_bits", C.c_int32), ("key_window_low", C.c_int32),
+                ("n_partitions", C.c_uint32), ("probe_items", C.c_uint32), ("attempts", C.c_uint32), ("refused", C.c_uint32),
+                ("cooling", C.c_uint32), ("workload", C.c_uint64)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["pass_bits"] = list(self.pass_bits)
+        return d
+
+
+# hmj_plan_desc.refused / .cooling bits
+HMJ_REFUSED_GTABLE_SHAPE, HMJ_REFUSED_GTABLE_COOLING, HMJ_REFUSED_GTABLE_GAVE_UP = 0x1, 0x2, 0x4
+HMJ_REFUSED_RANK_SORT_MODEL, HMJ_REFUSED_RANK_SORT_COOLING, HMJ_REFUSED_RANK_SORT_GAVE_UP = 0x8, 0x10, 0x20
+HMJ_REFUSED_SLAB_SHAPE, HMJ_REFUSED_SLAB_COOLING, HMJ_REFUSED_SLAB_SORTED_INPUT, HMJ_REFUSED_SLAB_OVERFLOW = 0x40, 0x80, 0x100, 0x200
+HMJ_REFUSED_FAST_WRITE_COOLING, HMJ_REFUSED_FAST_WRITE_GAVE_UP = 0x400, 0x800
+HMJ_REFUSED_SLAB_PROBE_COOLING, HMJ_REFUSED_SLAB_PROBE_OVERFLOW = 0x1000, 0x2000
+HMJ_REFUSED_PREFIX_VIOLATED, HMJ_REFUSED_EXPANSION_GAVE_UP = 0x4000, 0x8000
+HMJ_COOL_UNIQ_WRITE, HMJ_COOL_SORTED_WRITE, HMJ_COOL_GTABLE, HMJ_COOL_GTABLE_WRITE = 0x1, 0x2, 0x4, 0x8
+HMJ_COOL_RANK_SORT, HMJ_COOL_RANK_SORT_SLAB, HMJ_COOL_EXPANSION, HMJ_COOL_SORT_SLAB = 0x10, 0x20, 0x40, 0x80
+HMJ_COOL_SLAB, HMJ_COOL_SLAB_PROBE, HMJ_COOL_ONE_PASS_WRITE, HMJ_COOL_EXACT_PREFIX = 0x100, 0x200, 0x400, 0x800
+HMJ_COOL_RANK_RUNS = 0x1000
 
 
 class PlaceInfo(C.Structure):
@@ -140,6 +168,10 @@ def load_library():
     L.hmj_set_profiling.argtypes = [vp, i]
     L.hmj_last_timing.restype = i
     L.hmj_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.hmj_last_plan.restype = i
+    L.hmj_last_plan.argtypes = [vp, C.POINTER(PlanDesc)]
+    L.hmj_forget_workloads.restype = i
+    L.hmj_forget_workloads.argtypes = [vp]
     L.hmj_placement_info.restype = i
     L.hmj_placement_info.argtypes = [vp, C.POINTER(PlaceInfo), i]
     L.hmj_strerror.restype = cp
@@ -182,6 +214,10 @@ def load_library():
     L.hmj_owner_split_u64_device.argtypes = [vp, vp, u, i, _U64P, vp, vp]
     L.hmj_last_exchange_info.restype = i
     L.hmj_last_exchange_info.argtypes = [vp, C.POINTER(ExchangeInfo)]
+    L.hmj_comm_set_timeout_ms.restype = i
+    L.hmj_comm_set_timeout_ms.argtypes = [vp, u]
+    L.hmj_comm_get_timeout_ms.restype = i
+    L.hmj_comm_get_timeout_ms.argtypes = [vp, _U64P]
     L.hmj_comm_set_owner_path.restype = i
     L.hmj_comm_set_owner_path.argtypes = [vp, i]
     L.hmj_comm_set_self_exchange.restype = i

@@ -42,6 +42,38 @@ int fail(hmj_ctx* c, int code, const char* what, hipError_t e) {
     if (_e != hipSuccess) return fail(c, HMJ_E_HIP, #expr, _e);         \
   } while (0)
 
+// ---- what the context has learnt, per workload ------------------------------------------------------------------
+static int ilog2_u64(uint64_t v) { return v ? 63 - __builtin_clzll(v) : 0; }
+uint64_t workload_signature(uint64_t n_build, uint64_t n_probe, uint32_t flags, int kind) {
+  const uint32_t mode = ((flags & HMJ_ORDERED) ? 4u : 0u) | ((flags & (HMJ_MATERIALIZE | HMJ_ORDERED)) ? 2u : 0u) |
+                        ((flags & HMJ_FIRST_WINS) ? 1u : 0u);
+  return ((uint64_t)(kind & 15) << 20) | ((uint64_t)mode << 16) | ((uint64_t)ilog2_u64(n_build) << 8) | (uint64_t)ilog2_u64(n_probe);
+}
+WorkloadMemo* memo_for(hmj_ctx* c, uint64_t sig) {
+  auto it = c->memos.find(sig);
+  if (it == c->memos.end()) {
+    if (c->memos.size() >= 1024) c->memos.clear();  // (a context that has seen a thousand shapes starts over)
+    it = c->memos.emplace(sig, c->memo_init).first;
+  }
+  c->wm = &it->second;
+  c->wm_sig = sig;
+  return c->wm;
+}
+uint32_t WorkloadMemo::cooling() const {
+  return (uniq_cooldown ? HMJ_COOL_UNIQ_WRITE : 0u) | (sorted_cooldown ? HMJ_COOL_SORTED_WRITE : 0u) | (gtable_cooldown ? HMJ_COOL_GTABLE : 0u) |
+         (gtable_write_cooldown ? HMJ_COOL_GTABLE_WRITE : 0u) | (gtable_sort_cooldown ? HMJ_COOL_RANK_SORT : 0u) |
+         (gtable_sort_slab_cooldown ? HMJ_COOL_RANK_SORT_SLAB : 0u) | (expand_cooldown ? HMJ_COOL_EXPANSION : 0u) |
+         (sort_slab_cooldown ? HMJ_COOL_SORT_SLAB : 0u) | (slab_cooldown ? HMJ_COOL_SLAB : 0u) | (slab_probe_cooldown ? HMJ_COOL_SLAB_PROBE : 0u) |
+         (one_pass_write_cooldown ? HMJ_COOL_ONE_PASS_WRITE : 0u) | (exact_prefix_joins ? HMJ_COOL_EXACT_PREFIX : 0u) |
+         (rank_runs_cooldown ? HMJ_COOL_RANK_RUNS : 0u);
+}
+
+int wait_arrival(hmj_ctx* c, hipEvent_t ev) {
+  if (c->arrive_wait) return c->arrive_wait(c, ev);
+  HIP_TRY(hipStreamWaitEvent(c->stream, ev, 0));
+  return HMJ_OK;
+}
+
 int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return HMJ_OK;
   // a prepared build side (hmj_prepare_build_u64_device) lives in these buffers: once one of them is
@@ -652,11 +684,11 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     return HMJ_OK;
   };
   // ---- ordered joins: probe, sort and write in one pass (probe_write_sorted_kernel) when the keys allow it
-  if (ordered && c->sorted_cooldown > 0) c->sorted_cooldown--;
+  if (ordered && c->wm->sorted_cooldown > 0) c->wm->sorted_cooldown--;
   // two forms of the kernel: unique probe keys (a match bitmap), and repeating probe keys (a foreign-key join:
   // match counts and a rank by payload inside every key's run).  The context remembers which one the last join
   // needed, and asks the cheaper one again every 64 ordered joins.
-  if (ordered && c->sorted_fk && ++c->sorted_fk_age >= 64) c->sorted_fk = false;
+  if (ordered && c->wm->sorted_fk && ++c->wm->sorted_fk_age >= 64) c->wm->sorted_fk = false;
   // The foreign-key form has a small shape (512 threads, 3072 probe / 2048 build rows per partition, two workgroups
   // per CU) for the partitions the planner makes for fan-out >= 6: about 2048 probe rows + 5 sigma, sigma =
   // sqrt(fan-out x mean).  A partition beyond it makes the kernel give up ("does not fit"): the big shape then runs.
@@ -664,8 +696,8 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   // a probe side of more than twice the build side cannot have unique keys if its rows match: start with the
   // foreign-key form (the bitmap form would only find out: 1.9 ms at 2^24 x 2^28)
   const bool must_repeat = nb > 0 && (double)np >= 2.0 * (double)nb;
-  for (int form = (c->sorted_fk || must_repeat || fk_wide_plan) ? 1 : 0;
-       form < 2 && ordered && c->sorted_mode && c->sorted_cooldown == 0; form++) {
+  for (int form = (c->wm->sorted_fk || must_repeat || fk_wide_plan) ? 1 : 0;
+       form < 2 && ordered && c->sorted_mode && c->wm->sorted_cooldown == 0; form++) {
     const bool fk = form == 1;
     bool half = false;
     int shape = 0;
@@ -682,12 +714,12 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     // rank, payload position) and ranks inside those buckets instead of inside whole runs (HMJ_FK_PAYLOAD_BUCKETS=0: never)
     wa.extra = (wa.extra & 3u) | ((fk && c->fk_payload_buckets && nb > 0 && (double)np >= (double)c->fk_payload_buckets * (double)nb) ? 4u : 0u);
     int sp = span_begin(c, K_PROBE_WRITE, -1);
-    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, shape, (u64*)c->lookback.p, c->sorted_chained, low, c->num_cus, c->stream));
+    HIP_TRY(hmj::launch_probe_write_sorted(wa, slab, fk, shape, (u64*)c->lookback.p, c->wm->sorted_chained, low, c->num_cus, c->stream));
     span_end(c, sp);
     HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (h[hmj::ACC_ERR] & hmj::ERR_SLAB) {
-      c->slab_cooldown = 8;
+      c->wm->slab_cooldown = 8;
       return kRetryNoSlab;
     }
     if (h[hmj::ACC_ERR] & hmj::ERR_PREFIX) return kRetryNoPrefix;
@@ -705,8 +737,8 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
       const u64 *rk = wa.out_key, *rr = wa.out_rval, *rs = wa.out_sval;
       // the next ordered join: chained output offsets if this one had unmatched probe rows (dense without an
       // epilogue, 5.6 instead of 4.0 + 3.1 ms at 2^28 rows), the probe rows' own slots if it had none
-      const bool was_chained = c->sorted_chained;
-      if (!c->sorted_chained_forced) c->sorted_chained = out->n_matches != (u64)np;
+      const bool was_chained = c->wm->sorted_chained;
+      if (!c->sorted_chained_forced) c->wm->sorted_chained = out->n_matches != (u64)np;
       if (!was_chained && out->n_matches != (u64)np) {
         // unmatched probe rows left gaps at the end of every partition's slots: the ordered epilogue closes them
         HIP_TRY(hmj::launch_scan_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p, P, c->stream));
@@ -723,16 +755,16 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
     const bool try_fk = !fk && (why & 256) && !(why & (128 | 512 | 1024 | 2048));
     const bool try_big = fk && half && (why & 512) && !(why & (128 | 1024 | 2048));
     if (try_fk) {
-      c->sorted_fk = true;
-      c->sorted_fk_age = 0;
+      c->wm->sorted_fk = true;
+      c->wm->sorted_fk_age = 0;
     } else if (try_big) {
       no_half = true;  // same form again, one workgroup per CU with the full capacities
       form--;
     } else {
-      c->sorted_cooldown = 64;
+      c->wm->sorted_cooldown = 64;
       form = 2;
     }
-    if (fk_wide_plan && !try_big) c->sorted_wide = false;  // the 16-bit plan did not pay off here: plan for 5120 rows from now on
+    if (fk_wide_plan && !try_big) c->wm->sorted_wide = false;  // the 16-bit plan did not pay off here: plan for 5120 rows from now on
     if (why & 1024) {  // never expected: say so whether or not tracing is on, and leave a mark the tests can see
       c->timing.path |= HMJ_PATH_LOOKBACK_TIMEOUT;
       std::fprintf(stderr, "[hmj] one-pass ordered write: a chained partition waited beyond the spin limit for its predecessor; "
@@ -758,12 +790,12 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   HIP_TRY(hipMemcpyAsync(h, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (h[hmj::ACC_ERR] & hmj::ERR_SLAB) {
-    c->slab_cooldown = 8;
+    c->wm->slab_cooldown = 8;
     return kRetryNoSlab;
   }
   if (h[hmj::ACC_ERR] & hmj::ERR_PREFIX) return kRetryNoPrefix;
   if (h[hmj::ACC_ERR] & hmj::ERR_FASTPATH) {
-    c->uniq_cooldown = 8;
+    c->wm->uniq_cooldown = 8;
     return kRetryNoFastWrite;
   }
   out->n_matches = h[hmj::ACC_N];
@@ -804,27 +836,32 @@ int unique_key_write(hmj_ctx* c, hmj::ProbeArgs& wa, bool slab, u32 nb, u32 np, 
   return deliver(rk, rr, rs);
 }
 
-int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
-                     uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix,
-                     bool allow_slab, bool allow_fast_write, bool allow_win_ordered, bool prefix_unsafe,
-                     bool allow_slab_probe) {
+// ---- one attempt of the partitioned join = plan_join (key sample, radix bits, partition window, which kernels are on
+// offer: everything decided before a row moves) + execute_join (partition, build + probe, retries reported as kRetry*).
+// What the attempt may try is the caller's (join_device's retry loop); what it decided is a JoinPlan.
+struct JoinPlan {
+  bool allow_slab, allow_slab_probe;   // still allowed after the sample (a relation in key order takes no slab pass)
+  int B, passes, pass_bits[4];         // total radix bits, LSD passes, bits per pass
+  bool fk_wide_plan;                   // the bits rely on the wide shape of the one-pass ordered write (foreign-key form)
+  double dense_scale;                  // the populated partitions hold this many times the mean (dense-build plan)
+  bool asc_r, asc_s;                   // the sample found the build / probe rows in ascending key order
+  u32 P, Q;                            // partitions, probe slices per partition
+  u64 items;
+  int prefix, low;                     // partition id = (key >> low) & (P - 1)
+  bool win_ordered, hot_hint, verify_pfx;
+  u64 pfx_ref;
+  bool probe_fits, fast_write;
+  u32 np_plan;                         // probe size the plan was made for
+};
+
+static int plan_join(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
+                     bool allow_auto_prefix, bool allow_slab, bool allow_fast_write, bool allow_win_ordered, bool prefix_unsafe,
+                     bool allow_slab_probe, JoinPlan* plan_out) {
   int rc;
-  if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
-  std::memset(out, 0, sizeof(*out));
-  if ((rc = check_rel(c, R, n_build, "build_aos is NULL")) != HMJ_OK) return rc;
-  if ((rc = check_rel(c, S, n_probe, "probe_aos is NULL")) != HMJ_OK) return rc;
-  if (flags & HMJ_ORDERED) flags |= HMJ_MATERIALIZE;
-  const bool materialize = flags & HMJ_MATERIALIZE, first = flags & HMJ_FIRST_WINS;
-  const bool extra = flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE);
+  const bool materialize = flags & HMJ_MATERIALIZE;
   const u32 nb = (u32)n_build, np = (u32)n_probe;
   const u32 np_plan = c->prepare_only ? (u32)c->probe_hint : np;  // probe size the plan is made for
 
-  // a build side partitioned ahead by hmj_prepare_build pins the partitioning path of the join that uses it (a
-  // slab cool-down that ran out in between must not make the join partition the build side a second time)
-  if (!c->prepare_only && c->prep.valid && !c->prep.slab && c->prep.ptr == R && c->prep.n == nb) allow_slab = false;
-  if (c->slab_cooldown > 0 && allow_slab) c->slab_cooldown--;  // before the plan: one decision per join
-  if (c->slab_probe_cooldown > 0 && allow_slab_probe) c->slab_probe_cooldown--;  // (likewise: the plan below asks about it)
-  if (c->one_pass_write_cooldown > 0 && materialize && allow_slab_probe) c->one_pass_write_cooldown--;
 
   int B, passes, pass_bits[4];
   bool fk_wide_plan = false;  // the plan relies on the wide shape of the one-pass ordered write (foreign-key form)
@@ -853,7 +890,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       // (A probe side that was still arriving when the sample ran -- host pipeline, exchange rounds -- has arrived by
       //  now, or will have once its events fire: this IS the retry.  Its keys must be in the exact prefix, or an
       //  ordered join whose probe keys lie outside the build keys' prefix would fail a second time)
-      for (hipEvent_t ev : c->arrive_ev) HIP_TRY(hipStreamWaitEvent(c->stream, ev, 0));
+      for (hipEvent_t ev : c->arrive_ev)
+        if ((rc = wait_arrival(c, ev)) != HMJ_OK) return rc;
       const bool probe_readable = !c->sample_build_only || !c->arrive_ev.empty();
       u64* ex3 = (u64*)c->offs64.p;
       const u64 init[3] = {0, ~0ull, 0};
@@ -878,7 +916,10 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
         const u64 up = (w >> 16) & 0xFFFF, dn = (w >> 32) & 0xFFFF;
         return up + dn >= 64 && (up * 10 >= (up + dn) * 9 || dn * 10 >= (up + dn) * 9);
       };
-      if (sorted_like(smp[2]) || sorted_like(smp[3])) allow_slab = allow_slab_probe = false;
+      if (sorted_like(smp[2]) || sorted_like(smp[3])) {
+        if (allow_slab || allow_slab_probe) c->plan.refused |= HMJ_REFUSED_SLAB_SORTED_INPUT;
+        allow_slab = allow_slab_probe = false;
+      }
       auto ascending = [](u64 w) {
         const u64 up = (w >> 16) & 0xFFFF, dn = (w >> 32) & 0xFFFF;
         return up + dn >= 64 && up * 10 >= (up + dn) * 9;
@@ -937,7 +978,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // write has a 6144-row shape, so 16 bits still hold mean + 5 sigma of a 2^28-row probe side at fan-out 16 -- and
     // 16 bits partition on the slab path (32 instead of 48 B per row and pass)
     const bool wide_ok = materialize && (flags & HMJ_ORDERED) && allow_fast_write && !c->prepare_only && c->sorted_mode &&
-                         c->sorted_wide && c->sorted_cooldown <= 1 && f >= 2.5;
+                         c->wm->sorted_wide && c->wm->sorted_cooldown <= 1 && f >= 2.5;
     bool wide_ok_override = true;
     const int B_narrow = [&] {
       int b = Bp;
@@ -950,7 +991,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // of a fall to the exact path: 2^24 x 2^28 ordered, wide 16-bit plan 3.79 + 4.27 ms, 17-bit plan + small shape
     // 3.93 + 3.78 ms (profiles/r04c_*).  HMJ_FK_PLAN=wide|half|narrow pins the choice (measurements).
     const bool half_ok = materialize && (flags & HMJ_ORDERED) && allow_fast_write && !c->prepare_only && c->sorted_mode &&
-                         c->sorted_half && c->sorted_cooldown <= 1 && f >= 2.0 && c->fk_plan != 1 && c->fk_plan != 3;
+                         c->sorted_half && c->wm->sorted_cooldown <= 1 && f >= 2.0 && c->fk_plan != 1 && c->fk_plan != 3;
     int B_half = Bp;
     while (B_half < 18 && fk_probe_rows_hi((double)np_dense / (double)(1ull << B_half), f, (double)(1ull << B_half)) > 3072.0) B_half++;
     const bool half_fits = fk_probe_rows_hi((double)np_dense / (double)(1ull << B_half), f, (double)(1ull << B_half)) <= 3072.0 &&
@@ -972,11 +1013,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     if (!materialize)
       while (Bp < 16 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
     fk_wide_plan = wide_ok && wide_ok_override && !take_half && Bp < B_narrow;
-    const bool slab_ok = allow_slab && c->slab_mode && c->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
+    const bool slab_ok = allow_slab && c->slab_mode && c->wm->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     // (count joins whose build-side plan is ONE pass keep it when the probe side can stay in that pass's slabs -- the
     //  one-pass slab path below: 2^21 x 2^28 rows, 18-bit probe-side plan 7.0 ms, 9-bit build-side plan 2.9 ms)
-    const bool one_pass_count = !(flags & HMJ_ORDERED) && (!materialize || c->one_pass_write_cooldown == 0) && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
-                                c->slab_probe_cooldown == 0 && !c->prepare_only && np_plan >= (1u << 22) && (u64)np_plan >= 8ull * nb;
+    const bool one_pass_count = !(flags & HMJ_ORDERED) && (!materialize || c->wm->one_pass_write_cooldown == 0) && passes == 1 && B >= 5 && c->one_pass_slab && allow_slab_probe && c->slab_mode &&
+                                c->wm->slab_probe_cooldown == 0 && !c->prepare_only && np_plan >= (1u << 22) && (u64)np_plan >= 8ull * nb;
     if (Bp > B && !one_pass_count &&
         // (count joins: up to 16 bits only.  The 9-bit slab passes would allow 17 and 18, but a probe side that needs them
         //  is >= 3 * 10^8 rows over a much smaller build side -- BASELINE configs[4] -- where partitioning BOTH sides that
@@ -997,20 +1038,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     if (Q < 1) Q = 1;
   }
   u64 items = (u64)P * Q;
-
-  if ((rc = ensure_dev(c, c->r_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
-  if ((rc = ensure_dev(c, c->s_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
-  if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
-  if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
-  if (materialize) {
-    if ((rc = ensure_dev(c, c->part_count, (size_t)items * 8)) != HMJ_OK) return rc;
-    if ((rc = ensure_dev(c, c->part_out_off, ((size_t)items + 1) * 8)) != HMJ_OK) return rc;
-  }
   c->timing.radix_bits = B;
   c->timing.radix_passes = passes;
-
-  HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
-  const void *Rp, *Sp;
   int prefix = c->prefix_bits < 0 ? 0 : c->prefix_bits;
   bool sampled = false, win_ordered = false, hot_hint = false;
   u64 pfx_ref = 0;
@@ -1069,11 +1098,9 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   c->timing.key_window_low = low;
   if (hot_hint) c->timing.path |= HMJ_PATH_HOT_KEY_HINT;
   if (((u64)nb >> B) > hmj::PB_CAP) c->timing.path |= HMJ_PATH_CHUNKED_BUILD;
-  // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
-  hmj::SlabGeom gr, gs;
   // materialising joins whose build keys are unique take the unique-key write mode (one probe pass,
   // no count pass); it works on either partition layout
-  if (c->uniq_cooldown > 0 && allow_fast_write && materialize) c->uniq_cooldown--;
+  if (c->wm->uniq_cooldown > 0 && allow_fast_write && materialize) c->wm->uniq_cooldown--;
   // the pipelined probe kernels hold one partition's probe rows in registers (5120 at most)
   const bool probe_fits = ((u64)((double)np_plan * dense_scale) >> B) <= 4608;  // (the wide foreign-key plan keeps the mean at <= 4608 too)
   // A small materialising join (fewer partitions than the probe grid has workgroups) would share every table among
@@ -1081,7 +1108,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // a join keeps Q = 1 while that mode is on offer -- one pass on half the chip beats count + write + order on all of
   // it (ordered, 2^20 + 3000 rows: 0.34 -> 0.22 ms, 2^21 + 3000: 0.45 -> 0.27 ms).  After a failed attempt (duplicate
   // build keys: uniq_cooldown) the slices are back.
-  if (Q > 1 && allow_fast_write && c->uniq_cooldown == 0 && materialize && !win_ordered && P >= 2 && probe_fits &&
+  if (Q > 1 && allow_fast_write && c->wm->uniq_cooldown == 0 && materialize && !win_ordered && P >= 2 && probe_fits &&
       !c->prepare_only) {
     Q = 1;
     items = P;
@@ -1092,11 +1119,74 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // (ordered foreign-key joins with LONG runs -- expand_fk_fanout probe rows per build row and more -- skip the one-pass
   //  ordered write, whose in-run ranking is linear in the run, for count + scan + the ordered expansion, whose sort buckets
   //  cut the runs by payload: probe_expand_ordered_kernel)
-  const bool long_runs = (flags & HMJ_ORDERED) && c->expand_mode && c->expand_cooldown == 0 && c->expand_fk_fanout > 0 && nb > 0 &&
+  const bool long_runs = (flags & HMJ_ORDERED) && c->expand_mode && c->wm->expand_cooldown == 0 && c->expand_fk_fanout > 0 && nb > 0 &&
                          (double)np >= (double)c->expand_fk_fanout * (double)nb && !(flags & HMJ_FIRST_WINS);
-  const bool fast_write = allow_fast_write && c->uniq_cooldown == 0 && materialize && !win_ordered && !long_runs &&
+  const bool fast_write = allow_fast_write && c->wm->uniq_cooldown == 0 && materialize && !win_ordered && !long_runs &&
                           Q == 1 && P >= 2 && probe_fits && !c->prepare_only;
-  if (allow_slab && c->slab_mode && c->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
+  // what this attempt will not even try because an earlier join of the workload gave up on it
+  if (!c->prepare_only) {
+    if (allow_fast_write && materialize && c->wm->uniq_cooldown > 0) c->plan.refused |= HMJ_REFUSED_FAST_WRITE_COOLING;
+    if (allow_slab && c->slab_mode && c->wm->slab_cooldown > 0) c->plan.refused |= HMJ_REFUSED_SLAB_COOLING;
+    if (allow_slab_probe && c->slab_mode && c->wm->slab_probe_cooldown > 0) c->plan.refused |= HMJ_REFUSED_SLAB_PROBE_COOLING;
+  }
+  JoinPlan& p = *plan_out;
+  p.allow_slab = allow_slab;
+  p.allow_slab_probe = allow_slab_probe;
+  p.B = B;
+  p.passes = passes;
+  for (int i = 0; i < 4; i++) p.pass_bits[i] = i < passes ? pass_bits[i] : 0;
+  p.fk_wide_plan = fk_wide_plan;
+  p.dense_scale = dense_scale;
+  p.asc_r = asc_r;
+  p.asc_s = asc_s;
+  p.P = P;
+  p.Q = Q;
+  p.items = items;
+  p.prefix = prefix;
+  p.low = low;
+  p.win_ordered = win_ordered;
+  p.hot_hint = hot_hint;
+  p.verify_pfx = verify_pfx;
+  p.pfx_ref = pfx_ref;
+  p.probe_fits = probe_fits;
+  p.fast_write = fast_write;
+  p.np_plan = np_plan;
+  for (int i = 0; i < 4; i++) c->plan.pass_bits[i] = p.pass_bits[i];
+  (void)rc;
+  return HMJ_OK;
+}
+
+static int execute_join(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
+                        hmj_result* out, bool to_host, const JoinPlan& p) {
+  int rc;
+  const bool materialize = flags & HMJ_MATERIALIZE, first = flags & HMJ_FIRST_WINS;
+  const bool extra = flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE);
+  const u32 nb = (u32)n_build, np = (u32)n_probe, np_plan = p.np_plan;
+  const bool allow_slab = p.allow_slab, allow_slab_probe = p.allow_slab_probe;
+  const int B = p.B, passes = p.passes, prefix = p.prefix, low = p.low;
+  const int* pass_bits = p.pass_bits;
+  const bool fk_wide_plan = p.fk_wide_plan, asc_r = p.asc_r, asc_s = p.asc_s, win_ordered = p.win_ordered, hot_hint = p.hot_hint;
+  const bool verify_pfx = p.verify_pfx, probe_fits = p.probe_fits, fast_write = p.fast_write;
+  const double dense_scale = p.dense_scale;
+  const u32 P = p.P, Q = p.Q;
+  const u64 items = p.items, pfx_ref = p.pfx_ref;
+  if ((rc = ensure_dev(c, c->r_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->s_off, ((size_t)P + 1) * 4)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  if (materialize) {
+    if ((rc = ensure_dev(c, c->part_count, (size_t)items * 8)) != HMJ_OK) return rc;
+    if ((rc = ensure_dev(c, c->part_out_off, ((size_t)items + 1) * 8)) != HMJ_OK) return rc;
+  }
+  HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+  const void *Rp, *Sp;
+  // ---- histogram-free slab path (plain count joins of large, evenly distributed relations)
+  hmj::SlabGeom gr, gs;
+  if (allow_slab && c->slab_mode && c->wm->slab_cooldown == 0 && !c->prepare_only && !(c->timing.path & HMJ_PATH_SLAB) &&
+      !((!materialize || fast_write) && Q == 1 && probe_fits && passes == 2 && pass_bits[0] <= hmj::SLAB_MAX_BITS &&
+        pass_bits[1] <= hmj::SLAB_MAX_BITS && dense_scale <= 2.5))
+    c->plan.refused |= HMJ_REFUSED_SLAB_SHAPE;
+  if (allow_slab && c->slab_mode && c->wm->slab_cooldown == 0 && (!materialize || fast_write) && Q == 1 &&
       probe_fits &&
       passes == 2 && pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS &&
       slab_sizes_ok(c, nb, np_plan, materialize || np_plan < nb) &&
@@ -1135,7 +1225,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
         // ranges, so the workers whose rows are complete start after each round's event
         u32 w_done = 0;
         for (size_t i = 0; i < c->arrive_ev.size(); i++) {
-          HIP_TRY(hipStreamWaitEvent(c->stream, c->arrive_ev[i], 0));
+          if ((rc = wait_arrival(c, c->arrive_ev[i])) != HMJ_OK) return rc;
           const bool last = i + 1 == c->arrive_ev.size();
           const u32 w_end = last ? sd.g->WA : (u32)std::min<u64>(sd.g->WA, c->arrive_rows[i] / sd.g->rpw);
           if (w_end > w_done) {
@@ -1158,7 +1248,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {
-        c->slab_cooldown = 8;
+        c->wm->slab_cooldown = 8;
         return kRetryNoSlab;
       }
       c->prep.valid = true;
@@ -1218,7 +1308,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // skewed digits: remember, and take the exact path
-      c->slab_cooldown = 8;
+      c->wm->slab_cooldown = 8;
       return kRetryNoSlab;
     }
     out->n_matches = hh[hmj::ACC_N];
@@ -1254,7 +1344,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     c->prep.B = B;
     return HMJ_OK;
   }
-  for (hipEvent_t ev : c->arrive_ev) HIP_TRY(hipStreamWaitEvent(c->stream, ev, 0));  // probe rows still on the links
+  for (hipEvent_t ev : c->arrive_ev)
+    if ((rc = wait_arrival(c, ev)) != HMJ_OK) return rc;  // probe rows still on the links
   // ---- probe-heavy count joins (BASELINE configs[4]: 2^24 build rows, 2^30 probe rows): the build side is
   // small and was partitioned exactly above; the probe side -- almost all of the bytes -- takes the
   // histogram-free slab partitioning (32 instead of 48 B per row and pass) and the generic kernel reads a
@@ -1263,7 +1354,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     hmj::SlabGeom gp;
     // 2^bits_a * KB >= 512 pass-B workers (HMJ_SLAB_PROBE_KB: any piece count, for the bounds regression tests)
     const u32 kb = c->slab_probe_kb ? c->slab_probe_kb : (pass_bits[0] < 7 ? (512u >> pass_bits[0]) : 4u);
-    if (allow_slab_probe && c->slab_mode && c->slab_probe_cooldown == 0 && !materialize && !probe_fits && Q == 1 && passes == 2 &&
+    if (allow_slab_probe && c->slab_mode && c->wm->slab_probe_cooldown == 0 && !materialize && !probe_fits && Q == 1 && passes == 2 &&
         pass_bits[0] <= hmj::SLAB_MAX_BITS && pass_bits[1] <= hmj::SLAB_MAX_BITS && np >= c->slab_min_rows && (u64)np >= 4ull * nb &&
         hmj::slab_geometry(np, pass_bits[0], pass_bits[1], &gp, kb, (double)np / (double)(nb ? nb : 1))) {  // (a foreign-key
       // probe side repeats every key np / nb times: the slabs are sized for that spread)
@@ -1309,7 +1400,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // a probe slab overflowed (skewed probe keys)
-        c->slab_probe_cooldown = 8;
+        c->wm->slab_probe_cooldown = 8;
         return kRetryNoSlabProbe;
       }
       out->n_matches = hh[hmj::ACC_N];
@@ -1326,8 +1417,8 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // probe side 16 (histogram) + 32 (scatter) + 16 (probe) bytes per row.  Here its one pass is the histogram-free slab
   // pass A (32 B), and the generic kernel reads a partition straight out of the pass's worker-private slabs: partition p =
   // the WA pieces [p][0 .. WA), an item = (partition, a run of pieces), a wave per piece.  48 instead of 64 B per row.
-  if (allow_slab_probe && c->slab_mode && c->one_pass_slab && c->slab_probe_cooldown == 0 && !(flags & HMJ_ORDERED) &&
-      (!materialize || c->one_pass_write_cooldown == 0) && passes == 1 &&
+  if (allow_slab_probe && c->slab_mode && c->one_pass_slab && c->wm->slab_probe_cooldown == 0 && !(flags & HMJ_ORDERED) &&
+      (!materialize || c->wm->one_pass_write_cooldown == 0) && passes == 1 &&
       B >= 5 && B <= hmj::SLAB_MAX_BITS && np >= (1u << 22) && (u64)np >= 8ull * nb && nb > 0) {
     hmj::SlabGeom g1;
     if (hmj::slab_geometry_one_pass(np, B, dense_scale * (double)nb / (double)P, 512, &g1)) {
@@ -1391,11 +1482,11 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       if (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) {  // a slab overflowed (skewed probe keys): the exact path, and not again for a while
-        c->slab_probe_cooldown = 8;
+        c->wm->slab_probe_cooldown = 8;
         return kRetryNoSlabProbe;
       }
       if (hh[hmj::ACC_ERR] & hmj::ERR_FASTPATH) {  // more result rows than probe rows: the general materialising passes
-        c->one_pass_write_cooldown = 8;
+        c->wm->one_pass_write_cooldown = 8;
         return kRetryNoSlabProbe;
       }
       out->n_matches = hh[hmj::ACC_N];
@@ -1610,7 +1701,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     bool expanded = false;
     // (An unordered result takes it too -- rows in order are rows: 1.15 against 1.9 ms for the general write pass, whose
     //  workgroups re-probe their partition; there the partitions need not be key ranges.)
-    if (c->expand_cooldown > 0) c->expand_cooldown--;
+    if (c->wm->expand_cooldown > 0) c->wm->expand_cooldown--;
     //  Only where the result is several times the input: the kernel runs one workgroup per CU through a dozen barriers per
     //  partition -- at about one result row per input row the general write pass is as fast: 2^28 x 2^28, every 4th build key
     //  doubled: 6.4 against 6.9 ms.)
@@ -1630,7 +1721,7 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
           c->expand_rebits = B + 1;
           return kRetryMoreBits;
         }
-        c->expand_cooldown = 8;
+        c->wm->expand_cooldown = 8;
         HIP_TRY(hipMemsetAsync((u64*)c->accum.p + hmj::ACC_ERR, 0, sizeof(u64), c->stream));
         std::vector<Span> keep;
         for (const Span& s2 : c->spans)
@@ -1678,6 +1769,31 @@ int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   return HMJ_OK;
 }
 
+int join_device_impl(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
+                     uint32_t flags, hmj_result* out, bool to_host, bool allow_auto_prefix,
+                     bool allow_slab, bool allow_fast_write, bool allow_win_ordered, bool prefix_unsafe,
+                     bool allow_slab_probe) {
+  int rc;
+  if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
+  std::memset(out, 0, sizeof(*out));
+  if ((rc = check_rel(c, R, n_build, "build_aos is NULL")) != HMJ_OK) return rc;
+  if ((rc = check_rel(c, S, n_probe, "probe_aos is NULL")) != HMJ_OK) return rc;
+  if (flags & HMJ_ORDERED) flags |= HMJ_MATERIALIZE;
+  // a build side partitioned ahead by hmj_prepare_build pins the partitioning path of the join that uses it (a
+  // slab cool-down that ran out in between must not make the join partition the build side a second time)
+  if (!c->prepare_only && c->prep.valid && !c->prep.slab && c->prep.ptr == R && c->prep.n == (u32)n_build) allow_slab = false;
+  // one decision per join about every cool-down the plan asks about
+  const bool materialize = flags & HMJ_MATERIALIZE;
+  if (c->wm->slab_cooldown > 0 && allow_slab) c->wm->slab_cooldown--;
+  if (c->wm->slab_probe_cooldown > 0 && allow_slab_probe) c->wm->slab_probe_cooldown--;
+  if (c->wm->one_pass_write_cooldown > 0 && materialize && allow_slab_probe) c->wm->one_pass_write_cooldown--;
+  JoinPlan p;
+  if ((rc = plan_join(c, R, n_build, S, n_probe, flags, allow_auto_prefix, allow_slab, allow_fast_write, allow_win_ordered,
+                      prefix_unsafe, allow_slab_probe, &p)) != HMJ_OK)
+    return rc;
+  return execute_join(c, R, n_build, S, n_probe, flags, out, to_host, p);
+}
+
 // Small build side, count modes: one global hash table, the probe side streamed once (gtable.hip).  *done = the join
 // was answered here.  Not taken (or given up: duplicates / a clustering key set raise ERR_GTABLE, then the context
 // skips it for the next 8 joins) -> the partitioned paths run as before.
@@ -1690,10 +1806,7 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   // (materialising joins: the unordered form only -- an ordered result needs the probe rows in key order, which IS the
   //  partitioning -- and only while no earlier attempt met duplicate build keys: gtable_write_cooldown)
   const bool materialize = (flags & HMJ_MATERIALIZE) != 0;
-  if (materialize && c->gtable_write_cooldown > 0) {
-    c->gtable_write_cooldown--;
-    return HMJ_OK;
-  }
+  c->plan.refused |= HMJ_REFUSED_GTABLE_SHAPE;  // (cleared below once the join is inside the table's window)
   if (!c->gtable_mode || (flags & HMJ_ORDERED) || c->prepare_only || c->force_bits >= 0 ||
       !c->arrive_ev.empty() || n_build == 0 || n_probe > 0xFFFFFFFFull || n_probe < c->gtable_min_probe ||
       // big probe sides: the table must stay in an XCD's L2.  Small joins (a few hundred microseconds of dependent launches on
@@ -1704,8 +1817,16 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
       n_probe < (uint64_t)c->gtable_min_fanout * n_build ||
       (c->prep.valid && c->prep.ptr == R && c->prep.n == (u32)n_build))
     return HMJ_OK;
-  if (c->gtable_cooldown > 0) {
-    c->gtable_cooldown--;
+  c->plan.refused &= ~HMJ_REFUSED_GTABLE_SHAPE;
+  // (the cool-downs count joins that COULD have taken the table: checked after the eligibility tests)
+  if (materialize && c->wm->gtable_write_cooldown > 0) {
+    c->wm->gtable_write_cooldown--;
+    c->plan.refused |= HMJ_REFUSED_GTABLE_COOLING;
+    return HMJ_OK;
+  }
+  if (c->wm->gtable_cooldown > 0) {
+    c->wm->gtable_cooldown--;
+    c->plan.refused |= HMJ_REFUSED_GTABLE_COOLING;
     return HMJ_OK;
   }
   int rc;
@@ -1729,11 +1850,27 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   const bool first = flags & HMJ_FIRST_WINS, extra = flags & (HMJ_CHECKSUM | HMJ_SUM_PROBE);
   HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
   int sp = span_begin(c, K_PROBE_COUNT, -1);
+  // (a launcher that refuses its operands -- a device without 128 KiB of LDS per workgroup, a table beyond 2^30 slots after
+  //  HMJ_GTABLE_MAX_LOG2 was raised -- means "not taken", not a failed join: the partitioned paths run)
+  auto not_taken = [&]() {
+    (void)hipGetLastError();
+    c->wm->gtable_cooldown = 64;
+    c->plan.refused |= HMJ_REFUSED_GTABLE_SHAPE;
+    std::vector<Span> keep;
+    for (const Span& s2 : c->spans)
+      if (s2.kind == K_TOTAL || s2.kind == K_H2D) keep.push_back(s2);
+    c->spans.swap(keep);
+    return HMJ_OK;
+  };
   if (lds_table) {
-    HIP_TRY(hmj::launch_ltable_probe(R, (u32)n_build, S, (u32)n_probe, (u64*)c->accum.p, first, extra, c->num_cus, c->stream));
+    const hipError_t e = hmj::launch_ltable_probe(R, (u32)n_build, S, (u32)n_probe, (u64*)c->accum.p, first, extra, c->num_cus, c->stream);
+    if (e == hipErrorInvalidValue) return not_taken();
+    HIP_TRY(e);
   } else {
-  HIP_TRY(hipMemsetAsync(c->gtab.p, 0xFF, tab_bytes, c->stream));  // every slot empty (key of all ones)
-  HIP_TRY(hmj::launch_gtable_build(R, (u32)n_build, c->gtab.p, log_cap, (u64*)c->accum.p, first, c->num_cus, c->stream));
+    HIP_TRY(hipMemsetAsync(c->gtab.p, 0xFF, tab_bytes, c->stream));  // every slot empty (key of all ones)
+    const hipError_t e = hmj::launch_gtable_build(R, (u32)n_build, c->gtab.p, log_cap, (u64*)c->accum.p, first, c->num_cus, c->stream);
+    if (e == hipErrorInvalidValue) return not_taken();
+    HIP_TRY(e);
   }
   if (lds_table) {
   } else if (materialize) {
@@ -1755,9 +1892,10 @@ int try_global_table(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
   HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const bool dup_write = materialize && !first && hh[hmj::ACC_PAD] != 0;  // duplicate build keys: a probe row may expand to several rows
-  if (dup_write && !(hh[hmj::ACC_ERR] & hmj::ERR_GTABLE)) c->gtable_write_cooldown = 8;
+  if (dup_write && !(hh[hmj::ACC_ERR] & hmj::ERR_GTABLE)) c->wm->gtable_write_cooldown = 8;
   if ((hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) || dup_write) {
-    if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) c->gtable_cooldown = 8;
+    if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) c->wm->gtable_cooldown = 8;
+    c->plan.refused |= HMJ_REFUSED_GTABLE_GAVE_UP;
     std::vector<Span> keep;  // forget the abandoned attempt's span
     for (const Span& s2 : c->spans)
       if (s2.kind == K_TOTAL || s2.kind == K_H2D) keep.push_back(s2);
@@ -1831,6 +1969,9 @@ static int slab_chain(hmj_ctx* c, const void* dense_in, u32 n, const ChainDigit*
   DevBuf* cn[2] = {&c->cnt_a, &c->cnt_bs};
   u64* acc = (u64*)c->accum.p;
   u64* hh = (u64*)c->h_accum.p;
+  // the chain's verdict is the ERR_SLAB bit of this word: it starts from zero whatever an earlier call (or a fresh
+  // allocation: hmj_sort_u64_device on a new context) left there
+  HIP_TRY(hipMemsetAsync(acc + hmj::ACC_ERR, 0, sizeof(u64), c->stream));
   u32 W = 0, C = 0;
   int bprev = 0;
   double dens_prev = 1.0;
@@ -1926,6 +2067,19 @@ static double ordered_part_ns(double f) {
   const double bucketed = 0.043 + (f > 128.0 ? 0.0001 * (f - 128.0) : 0.0);
   return lin < bucketed ? lin : bucketed;
 }
+// The rank-run form (gtable.hip): every rank's run of probe rows must fit one workgroup's LDS sort with room for its
+// spread (mean + 8 sigma of a run of a uniform foreign key), both digits of the rank must be slab passes, and the runs
+// must be long enough for a workgroup per rank to pay.
+static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe) {
+  if (!c->rank_runs_mode || !c->slab_mode || c->wm->rank_runs_cooldown > 0 || n_build < 4 || n_probe > 0xFFFFFFFFull ||
+      n_probe < (1u << 16))  // (a slab pass wants a few dozen tiles of rows)
+    return false;
+  const int rank_bits = 64 - __builtin_clzll(n_build - 1);
+  if (rank_bits < 2 || rank_bits > 2 * hmj::SLAB_MAX_BITS) return false;
+  const double f = (double)n_probe / (double)n_build;
+  return f >= 16.0 && f + 8.0 * std::sqrt(f) + 24.0 <= (double)hmj::rank_sort_max_run();
+}
+
 int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
                             hmj_result* out, bool to_host, bool* done) {
   *done = false;
@@ -1947,12 +2101,18 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     const double part_ns = ordered_part_ns(f);
     // (round 4, later: 0.060 where the composites' passes are the chain of slab passes below, 0.072 on exact passes, + 0.02
     //  where the table leaves the L2 -- profiles/r04p_side_rank_sort_slab_chain.txt)
-    const bool chain = c->gtable_sort_slab && c->slab_mode && c->gtable_sort_slab_cooldown == 0 && n_probe >= c->gtable_sort_slab_min;
-    const double rank_ns = (chain ? 0.060 : 0.072) + (n_build > c->gtable_max_rows ? 0.02 : 0.0);
-    if (c->gtable_sort_fanout > 1 && 0.65 + rank_ns * rows >= 0.15 + part_ns * rows) return HMJ_OK;
+    const bool chain = c->gtable_sort_slab && c->slab_mode && c->wm->gtable_sort_slab_cooldown == 0 && n_probe >= c->gtable_sort_slab_min;
+    // (round 5: runs that fit one workgroup's LDS sort -- fan-out up to ~1700 -- are partitioned by rank with two slab passes
+    //  and sorted run by run, rank_runs_fit below: ~0.040 ns per probe row whatever the payloads' width)
+    const double rank_ns = (rank_runs_fit(c, n_build, n_probe) ? 0.040 : chain ? 0.060 : 0.072) + (n_build > c->gtable_max_rows ? 0.02 : 0.0);
+    if (c->gtable_sort_fanout > 1 && 0.65 + rank_ns * rows >= 0.15 + part_ns * rows) {
+      c->plan.refused |= HMJ_REFUSED_RANK_SORT_MODEL;
+      return HMJ_OK;
+    }
   }
-  if (c->gtable_sort_cooldown > 0) {
-    c->gtable_sort_cooldown--;
+  if (c->wm->gtable_sort_cooldown > 0) {
+    c->wm->gtable_sort_cooldown--;
+    c->plan.refused |= HMJ_REFUSED_RANK_SORT_COOLING;
     return HMJ_OK;
   }
   int rc;
@@ -1971,36 +2131,42 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
   u64* hh = (u64*)c->h_accum.p;
   auto give_up = [&](const char* why) {
-    c->gtable_sort_cooldown = 8;
+    c->wm->gtable_sort_cooldown = 8;
+    c->plan.refused |= HMJ_REFUSED_RANK_SORT_GAVE_UP;
     std::vector<Span> keep;  // forget the abandoned attempt's spans
     for (const Span& s2 : c->spans)
       if (s2.kind == K_TOTAL || s2.kind == K_H2D) keep.push_back(s2);
     c->spans.swap(keep);
-    std::memset(&c->timing, 0, sizeof(c->timing));
+    c->timing.path = 0;  // (only what this attempt set: its path bits and pass bytes)
+    c->timing.bytes_scatter = c->timing.bytes_hist = 0;
+    c->timing.n_scatter_launches = 0;
     if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: sort-by-rank path gave up (%s) -> partitioned path\n", nb, np, why);
     return HMJ_OK;
   };
-  // ---- 1. which 8-bit digits the build keys differ in, and the range of the probe payloads (one read-back)
+  // ---- 1. which 8-bit digits the build keys differ in, and -- for the composite form -- the range of the probe payloads
+  // (one read-back)
+  bool use_runs = rank_runs_fit(c, n_build, n_probe);
   {
     const u64 init[5] = {0, ~0ull, 0, ~0ull, 0};
     HIP_TRY(hipMemcpyAsync(c->offs64.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hmj::launch_key_exact(R, nb, nullptr, 0u, 0, (u64*)c->offs64.p, c->num_cus, c->stream, true));
-    HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
+    if (!use_runs) HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
     HIP_TRY(hipMemcpyAsync(hh, c->offs64.p, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
-  const u64 key_diff = hh[0], svmin = np ? hh[3] : 0, svmax = np ? hh[4] : 0;
-  const int range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
+  const u64 key_diff = hh[0];
+  u64 svmin = (np && !use_runs) ? hh[3] : 0, svmax = (np && !use_runs) ? hh[4] : 0;
+  int range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
   const int rank_bits = nb > 1 ? 32 - __builtin_clz(nb - 1) : 0;
   // rank and payload in ONE word where they fit; else as two (payloads that are hashes, doubles, pointers): sorted by the
   // payload's varying digits first, then stably by the rank -- up to 8 + 3 passes instead of 4-5, still well under the
   // partitioned paths' run ranking at these fan-outs (a wide-payload join needs twice the fan-out to take this path)
-  const bool wide = rank_bits + range_bits > 64;
+  bool wide = rank_bits + range_bits > 64;
   if (wide && c->gtable_sort_fanout > 1) {  // (ten passes instead of four or five: about 1.6 x the time per row)
     const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
     const double part_ns = ordered_part_ns(f);
     if (0.65 + 0.145 * rows >= 0.15 + part_ns * rows) {
-      c->gtable_sort_cooldown = 8;
+      c->wm->gtable_sort_cooldown = 8;
       return HMJ_OK;
     }
   }
@@ -2029,6 +2195,91 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   HIP_TRY(hipMemsetAsync(c->gtab.p, 0xFF, tab_bytes, c->stream));
   int sp = span_begin(c, K_PROBE_COUNT, -1);
   HIP_TRY(hmj::launch_gtable_build(sortedR, nb, c->gtab.p, log_cap, (u64*)c->accum.p, true, c->num_cus, c->stream));
+  // ---- 4a. the rank-run form: {rank, sval} rows, two slab passes on the rank's digits, every rank's run sorted in LDS and
+  // written at its offset (gtable.hip).  A slab that overflows or a run beyond the kernel (a hot foreign key) leaves the
+  // table as it is; the composite form below starts over from the emit, and the workload skips this form 8 times.
+  bool runs_done = false;
+  u64 n = 0;
+  if (use_runs) {
+    HIP_TRY(hmj::launch_gtable_emit_ranks(S, np, c->gtab.p, log_cap, (u64*)c->accum.p, c->sbuf[0].p, extra, c->num_cus, c->gtable_wg_per_cu, c->stream));
+    span_end(c, sp);
+    HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) return give_up("the table gave up");
+    if (hh[hmj::ACC_PAD] != 0) return give_up("duplicate build keys");
+    n = hh[hmj::ACC_N];
+    const int bb = rank_bits / 2, ba = rank_bits - bb;  // LSD: pass A on the low digit, pass B on the high one
+    const u32 P = 1u << rank_bits;
+    hmj::SlabGeom g;
+    const bool geom = n > 0 && hmj::slab_geometry((u32)n, ba, bb, &g, 0, 1.0, (double)P / (double)nb);
+    if (geom) {
+      u64* acc = (u64*)c->accum.p;
+      if ((rc = ensure_dev(c, c->slab_a, g.rows_a * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_a, ((size_t)g.WA << ba) * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->slab_bs, g.rows_b * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * g.KB * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->part_count, (size_t)P * 8)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->part_out_off, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
+      const size_t bytes = (size_t)n * 8;
+      if ((rc = ensure_dev(c, c->out_key, bytes)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return rc;
+      int s2 = span_begin(c, K_SCATTER, 1, 0);
+      HIP_TRY(hmj::launch_slab_a(c->sbuf[0].p, (u32)n, 0, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->stream));
+      span_end(c, s2);
+      s2 = span_begin(c, K_SCATTER, 1, 1);
+      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, ba, bb, g, c->slab_bs.p, c->slab_bs.cap / 16, (u32*)c->cnt_bs.p,
+                                 c->cnt_bs.cap / 4, acc, c->stream));
+      span_end(c, s2);
+      s2 = span_begin(c, K_OUT_SCAN, -1);
+      HIP_TRY(hmj::launch_slab_np((const u32*)c->cnt_bs.p, P, (u64*)c->part_count.p, c->stream));
+      HIP_TRY(hmj::launch_scan_chunked_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p, P, c->stream));
+      span_end(c, s2);
+      s2 = span_begin(c, K_PROBE_WRITE, -1);
+      HIP_TRY(hmj::launch_rank_sort_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, sortedR, nb,
+                                          (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, acc, extra, c->num_cus, c->stream));
+      span_end(c, s2);
+      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      runs_done = !(hh[hmj::ACC_ERR] & (hmj::ERR_SLAB | hmj::ERR_FASTPATH));
+      if (runs_done) {
+        c->timing.bytes_scatter += 2 * 32ull * n;
+        c->timing.path |= HMJ_PATH_SLAB | HMJ_PATH_RANK_RUNS;
+        c->timing.radix_bits = rank_bits;
+        c->timing.radix_passes = 2;
+      }
+    } else if (n == 0) {
+      runs_done = true;  // no probe row matched: an empty result
+    }
+    if (!runs_done) {
+      // start over on the composite form: the table stays, the accumulators and the emit are redone with the payload range
+      c->wm->rank_runs_cooldown = 8;
+      if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: rank-run form gave up (%s) -> composite sort\n", nb, np,
+                                 !geom ? "no slab geometry" : (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) ? "a slab overflowed" : "a run beyond the kernel");
+      std::vector<Span> keep;
+      for (const Span& s3 : c->spans)
+        if (s3.kind == K_TOTAL || s3.kind == K_H2D) keep.push_back(s3);
+      c->spans.swap(keep);
+      c->timing.bytes_scatter = 0;
+      use_runs = false;
+      const u64 init2[2] = {~0ull, 0};
+      HIP_TRY(hipMemcpyAsync((u64*)c->offs64.p + 3, init2, sizeof(init2), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
+      HIP_TRY(hipMemcpyAsync(hh, (u64*)c->offs64.p + 3, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      svmin = np ? hh[0] : 0;
+      svmax = np ? hh[1] : 0;
+      range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
+      wide = rank_bits + range_bits > 64;
+      HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+      sp = span_begin(c, K_PROBE_COUNT, -1);
+    }
+  }
+  int which = 0, n_passes = 0;  // `sorted` lies in sbuf[which]
+  u32 pc_n = 0, pc_cap = 0;  // the sorted composites as pieces (pc_n != 0): c->slab_* / c->cnt_* [pc_which]
+  int pc_which = 0;
+  const void* sorted = c->sbuf[0].p;
+  if (!runs_done) {
   // ---- 4. one composite per matching probe row
   HIP_TRY(hmj::launch_gtable_emit(S, np, c->gtab.p, log_cap, svmin, range_bits, (u64*)c->accum.p, c->sbuf[0].p, extra, wide,
                                   c->num_cus, c->gtable_wg_per_cu, c->stream));
@@ -2037,10 +2288,8 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) return give_up("the table gave up");
   if (hh[hmj::ACC_PAD] != 0) return give_up("duplicate build keys");
-  const u64 n = hh[hmj::ACC_N];
+  n = hh[hmj::ACC_N];
   // ---- 5. sort the composites: only their rank_bits + range_bits low bits differ
-  const void* sorted = c->sbuf[0].p;
-  int which = 0, n_passes = 0;  // `sorted` lies in sbuf[which]
   auto lsd = [&](int total) -> int {  // stable LSD passes over the key word's bits [0, total), 9-bit digits at most
     if (total <= 0 || n <= 1) return HMJ_OK;
     const int passes = (total + hmj::RP_MAX_BITS - 1) / hmj::RP_MAX_BITS;
@@ -2061,9 +2310,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   // the last pass's pieces expanded in place (gtable_expand_pieces_kernel).  The digits that hold the payload range's and the
   // rank's top bits are sized for how much of their range is in use.  An overflow (skewed payload bits, a hot key): the exact
   // passes run from the dense composites, which the chain has not touched, and the chain is left alone for the next 8 such joins.
-  u32 pc_n = 0, pc_cap = 0;  // the sorted composites as pieces (pc_n != 0): c->slab_* / c->cnt_* [pc_which]
-  int pc_which = 0;
-  if (c->gtable_sort_slab_cooldown > 0 && !wide) c->gtable_sort_slab_cooldown--;
+  if (c->wm->gtable_sort_slab_cooldown > 0 && !wide) c->wm->gtable_sort_slab_cooldown--;
   else if (!wide && c->slab_mode && c->gtable_sort_slab && n >= c->gtable_sort_slab_min && rank_bits + range_bits > 0) {
     const int total = rank_bits + range_bits;
     const int passes = (total + hmj::RP_MAX_BITS - 1) / hmj::RP_MAX_BITS;
@@ -2085,7 +2332,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       n_passes = passes;
       c->timing.path |= HMJ_PATH_SLAB;
     } else {
-      c->gtable_sort_slab_cooldown = 8;
+      c->wm->gtable_sort_slab_cooldown = 8;
       if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: a slab of the composite sort's chain overflowed -> exact passes\n", nb, np);
     }
   }
@@ -2125,6 +2372,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  }  // (!runs_done)
   std::memset(out, 0, sizeof(*out));
   out->n_matches = n;
   out->sum_r = hh[hmj::ACC_SUM_R];
@@ -2133,8 +2381,10 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   out->mix_sum = hh[hmj::ACC_MIX];
   out->sum_probe_all = hh[hmj::ACC_SUM_P];
   c->timing.path |= HMJ_PATH_GLOBAL_TABLE | HMJ_PATH_ORDER_BY_RANK_SORT;
-  c->timing.radix_bits = rank_bits + range_bits;
-  c->timing.radix_passes = n_passes;
+  if (!runs_done) {
+    c->timing.radix_bits = rank_bits + range_bits;
+    c->timing.radix_passes = n_passes;
+  }
   c->timing.n_probe_items = 1;
   c->timing.bytes_probe_write = 16ull * (n_build + n_probe) + 24ull * n;
   if (n) {
@@ -2160,8 +2410,29 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   return HMJ_OK;
 }
 
+static int join_device_planned(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
+                               hmj_result* out, bool to_host);
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
+  // the workload this call belongs to (a prepared build side: the join it was announced for) and what is known about it
+  memo_for(c, workload_signature(n_build, c->prepare_only ? c->probe_hint : n_probe, flags, 0));
+  std::memset(&c->plan, 0, sizeof(c->plan));
+  const int rc = join_device_planned(c, R, n_build, S, n_probe, flags, out, to_host);
+  hmj_plan_desc& p = c->plan;
+  p.struct_size = sizeof(p);
+  p.path = c->timing.path;
+  p.radix_bits = c->timing.radix_bits;
+  p.radix_passes = c->timing.radix_passes;
+  p.key_prefix_bits = c->timing.key_prefix_bits;
+  p.key_window_low = c->timing.key_window_low;
+  p.n_partitions = (c->timing.path & (HMJ_PATH_GLOBAL_TABLE | HMJ_PATH_LDS_TABLE)) ? 0u : (p.radix_bits < 32 ? 1u << p.radix_bits : 0u);
+  p.probe_items = c->timing.n_probe_items;
+  p.cooling = c->wm->cooling();
+  p.workload = c->wm_sig;
+  return rc;
+}
+static int join_device_planned(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
+                               hmj_result* out, bool to_host) {
   {
     bool done = false;
     int rc = try_global_table(c, R, n_build, S, n_probe, flags, out, to_host, &done);
@@ -2170,8 +2441,8 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
     if (rc != HMJ_OK || done) return rc;
   }
   bool auto_prefix = true, slab = true, fast_write = true, win_ordered = true, prefix_unsafe = false, slab_probe = true;
-  if ((flags & HMJ_ORDERED) && c->exact_prefix_joins > 0) {  // (a failed attempt costs more than the pass over the keys)
-    c->exact_prefix_joins--;
+  if ((flags & HMJ_ORDERED) && c->wm->exact_prefix_joins > 0) {  // (a failed attempt costs more than the pass over the keys)
+    c->wm->exact_prefix_joins--;
     prefix_unsafe = true;
   }
   bool forced_here = false;  // (kRetryMoreBits pins the plan's bits for the rest of THIS join)
@@ -2184,8 +2455,12 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
     }
   } unforce{c, &forced_here};
   for (int attempt = 0; attempt < 8; attempt++) {
+    c->plan.attempts = (uint32_t)attempt + 1;
     int rc = join_device_impl(c, R, n_build, S, n_probe, flags, out, to_host, auto_prefix, slab, fast_write,
                               win_ordered, prefix_unsafe, slab_probe);
+    c->plan.refused |= rc == kRetryNoSlab ? HMJ_REFUSED_SLAB_OVERFLOW : rc == kRetryNoPrefix ? HMJ_REFUSED_PREFIX_VIOLATED
+                       : rc == kRetryNoFastWrite ? HMJ_REFUSED_FAST_WRITE_GAVE_UP : rc == kRetryNoSlabProbe ? HMJ_REFUSED_SLAB_PROBE_OVERFLOW
+                       : rc == kRetryMoreBits ? HMJ_REFUSED_EXPANSION_GAVE_UP : 0u;
     if (c->trace)
       std::fprintf(stderr, "[hmj] join nb=%llu np=%llu flags=%#x attempt %d: rc=%d bits=%d passes=%d path=%#x prefix=%d low=%d items=%u%s\n",
                    (unsigned long long)n_build, (unsigned long long)n_probe, flags, attempt, rc, c->timing.radix_bits,
@@ -2216,7 +2491,7 @@ int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint
       else if (rc == kRetryNoWinOrdered) win_ordered = false;
       else if (!prefix_unsafe && win_ordered) {  // outliers: the exact prefix (join_device_impl), also for the next joins
         prefix_unsafe = true;
-        c->exact_prefix_joins = 32;
+        c->wm->exact_prefix_joins = 32;
       }
       else auto_prefix = false;
       continue;
@@ -2256,19 +2531,9 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_SLAB")) c->slab_mode = atoi(e);
   if (const char* e = getenv("HMJ_ONE_PASS_SLAB")) c->one_pass_slab = atoi(e) != 0;  // 0: mid-size build sides keep the exact one-pass plan
   if (const char* e = getenv("HMJ_GTABLE")) c->gtable_mode = atoi(e) != 0;  // 0: small build sides are partitioned too
-  if (const char* e = getenv("HMJ_LTABLE")) c->ltable_mode = atoi(e) != 0;  // 0: tiny build sides take the L2-resident table too
-  if (const char* e = getenv("HMJ_GTABLE_MAX_LOG2")) {
-    const int l = atoi(e);
-    if (l >= 0 && l <= 28) c->gtable_max_rows = 1ull << l;
-  }
-  if (const char* e = getenv("HMJ_GTABLE_FANOUT")) c->gtable_min_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;
-  if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+  if (const char* e = getenv("HMJ_RANK_RUNS")) c->rank_runs_mode = atoi(e) != 0;  // 0: ordered small-build joins always sort composites
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
-  if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB")) c->gtable_sort_slab = atoi(e) != 0;  // 0: the composites' LSD passes are exact passes (hist + scan + scatter)
-  if (const char* e = getenv("HMJ_FK_PAYLOAD_BUCKETS")) c->fk_payload_buckets = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // fan-out from which the ordered foreign-key write buckets by payload (0: never)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
-  if (const char* e = getenv("HMJ_ORDERED_EXPANSION")) c->expand_mode = atoi(e) != 0;  // 0: ordered joins with duplicate build keys write in probe order and sort the rows
-  if (const char* e = getenv("HMJ_SORT_SLAB")) c->sort_slab = atoi(e) != 0;  // 0: hmj_sort_u64_device runs exact passes (hist + scan + scatter)
   if (const char* e = getenv("HMJ_SORT_SLAB_MIN_LOG2")) {
     const int l = atoi(e);
     if (l >= 12 && l <= 32) c->sort_slab_min = 1ull << l;
@@ -2278,8 +2543,6 @@ int hmj_create(hmj_ctx** out, int device_id) {
     if (l >= 12 && l <= 32) c->gtable_sort_slab_min = 1ull << l;
   }
   if (const char* e = getenv("HMJ_GTABLE_SORT_FANOUT")) c->gtable_sort_fanout = atoi(e) > 0 ? (u32)atoi(e) : 1u;
-  if (const char* e = getenv("HMJ_GTABLE_SLOTS")) c->gtable_slots_per_row = atoi(e) >= 2 ? (u32)atoi(e) : 2u;
-  if (const char* e = getenv("HMJ_GTABLE_MAX_LOG_CAP")) c->gtable_max_log_cap = atoi(e);
   if (const char* e = getenv("HMJ_PLACE")) {  // 0: nothing is probed; n: joins search too (at most n candidates per buffer)
     c->place_tune = atoi(e) != 0;
     if (atoi(e) > 0) {
@@ -2294,18 +2557,6 @@ int hmj_create(hmj_ctx** out, int device_id) {
     const long long mb = atoll(e);
     if (mb >= 1) c->place_min_bytes = (size_t)mb << 20;
   }
-  if (const char* e = getenv("HMJ_DENSE_PLAN")) c->dense_plan = atoi(e) != 0;
-  if (const char* e = getenv("HMJ_SORTED_WRITE")) {
-    c->sorted_mode = atoi(e) != 0;
-    c->sorted_chained = atoi(e) == 2;
-    c->sorted_chained_forced = atoi(e) == 2 || atoi(e) == 3;  // 3: never chained
-  }
-  if (const char* e = getenv("HMJ_SORTED_HALF")) c->sorted_half = atoi(e) != 0;
-  if (const char* e = getenv("HMJ_FK_PLAN"))  // ordered foreign-key joins: pin the plan (1 wide, 2 half, 3 narrow; else automatic)
-    c->fk_plan = std::strcmp(e, "wide") == 0 ? 1 : std::strcmp(e, "half") == 0 ? 2 : std::strcmp(e, "narrow") == 0 ? 3 : 0;
-  if (const char* e = getenv("HMJ_SORTED_WIDE")) c->sorted_wide = atoi(e) != 0;
-  if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
-  if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_UPLOAD")) c->staged_upload = std::strcmp(e, "staged") == 0;
   if (const char* e = getenv("HMJ_HOST_PIPELINE")) c->host_pipeline = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SLAB_MIN_LOG2")) {
@@ -2316,9 +2567,39 @@ int hmj_create(hmj_ctx** out, int device_id) {
     const int k = atoi(e);
     if (k >= 1 && k <= 512) c->slab_probe_kb = (u32)k;
   }
-  if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
   if (const char* e = getenv("HMJ_TRACE")) c->trace = atoi(e) != 0;
+  // Switches that only serve ablations and the experiments under tools/ (developer builds, tools/build_variant.sh): the
+  // release library plans from the data, hmj_last_plan says how, and tests assert on that instead of pinning paths.
 #ifdef HMJ_DEV
+  if (const char* e = getenv("HMJ_LTABLE")) c->ltable_mode = atoi(e) != 0;  // 0: tiny build sides take the L2-resident table too
+  if (const char* e = getenv("HMJ_GTABLE_MAX_LOG2")) {
+    const int l = atoi(e);
+    if (l >= 0 && l <= 28) c->gtable_max_rows = 1ull << l;
+  }
+  if (const char* e = getenv("HMJ_GTABLE_FANOUT")) c->gtable_min_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;
+  if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+  if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB")) c->gtable_sort_slab = atoi(e) != 0;  // 0: the composites' LSD passes are exact passes (hist + scan + scatter)
+  if (const char* e = getenv("HMJ_FK_PAYLOAD_BUCKETS")) c->fk_payload_buckets = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // fan-out from which the ordered foreign-key write buckets by payload (0: never)
+  if (const char* e = getenv("HMJ_ORDERED_EXPANSION")) c->expand_mode = atoi(e) != 0;  // 0: ordered joins with duplicate build keys write in probe order and sort the rows
+  if (const char* e = getenv("HMJ_SORT_SLAB")) c->sort_slab = atoi(e) != 0;  // 0: hmj_sort_u64_device runs exact passes (hist + scan + scatter)
+  if (const char* e = getenv("HMJ_GTABLE_SLOTS")) c->gtable_slots_per_row = atoi(e) >= 2 ? (u32)atoi(e) : 2u;
+  if (const char* e = getenv("HMJ_GTABLE_MAX_LOG_CAP")) {
+    const int l = atoi(e);
+    if (l >= 10 && l <= 30) c->gtable_max_log_cap = l;  // (the build launcher takes tables of up to 2^30 slots)
+  }
+  if (const char* e = getenv("HMJ_DENSE_PLAN")) c->dense_plan = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_SORTED_WRITE")) {
+    c->sorted_mode = atoi(e) != 0;
+    c->memo_init.sorted_chained = atoi(e) == 2;
+    c->sorted_chained_forced = atoi(e) == 2 || atoi(e) == 3;  // 3: never chained
+  }
+  if (const char* e = getenv("HMJ_SORTED_HALF")) c->sorted_half = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_FK_PLAN"))  // ordered foreign-key joins: pin the plan (1 wide, 2 half, 3 narrow; else automatic)
+    c->fk_plan = std::strcmp(e, "wide") == 0 ? 1 : std::strcmp(e, "half") == 0 ? 2 : std::strcmp(e, "narrow") == 0 ? 3 : 0;
+  if (const char* e = getenv("HMJ_SORTED_WIDE")) c->memo_init.sorted_wide = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_WINDOW")) c->window_mode = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;
+  if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
   if (const char* e = getenv("HMJ_DEBUG_ABLATE")) c->dev_ablate = (u32)atoi(e);
 #endif
   hipDeviceProp_t prop;
@@ -2453,6 +2734,23 @@ int hmj_placement_info(hmj_ctx* c, hmj_place_info* out, int max_entries) {
   return n;
 }
 
+int hmj_last_plan(hmj_ctx* c, hmj_plan_desc* out) {
+  if (!c || !out || out->struct_size < 8) return HMJ_E_ARG;
+  const uint32_t room = out->struct_size < sizeof(hmj_plan_desc) ? out->struct_size : (uint32_t)sizeof(hmj_plan_desc);
+  hmj_plan_desc p = c->plan;
+  p.struct_size = room;
+  std::memcpy(out, &p, room);
+  return HMJ_OK;
+}
+
+int hmj_forget_workloads(hmj_ctx* c) {
+  if (!c) return HMJ_E_ARG;
+  c->memos.clear();
+  c->wm = &c->memo_init;
+  c->wm_sig = 0;
+  return HMJ_OK;
+}
+
 int hmj_last_timing(hmj_ctx* c, hmj_timing* out) {
   if (!c || !out) return HMJ_E_ARG;
   *out = c->timing;
@@ -2469,6 +2767,7 @@ const char* hmj_strerror(int code) {
     case HMJ_E_UNSUPPORTED: return "unsupported flag combination for this input";
     case HMJ_E_RCCL: return "RCCL / transport error";
     case HMJ_E_PEER: return "another rank of the collective failed";
+    case HMJ_E_TIMEOUT: return "the exchange step timed out (a peer never took part); the communicator was aborted";
     default: return "unknown error";
   }
 }
@@ -2758,6 +3057,7 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
   HIP_TRY(hipSetDevice(c->device));
   spans_reset(c);
   if (n == 0) return HMJ_OK;
+  memo_for(c, workload_signature(n, 0, 0, 1));  // (what earlier sorts of this size learnt: the chain's cool-down)
   c->prep.valid = false;  // rbuf[0] is the sort's ping-pong buffer
   if ((rc = ensure_dev(c, c->rbuf[0], (size_t)n * 16)) != HMJ_OK) return rc;
   // Digits in which no key differs need no pass (a stable pass on a constant digit is a copy): integer ids below 2^32
@@ -2801,7 +3101,7 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
   // are sized for the share of its values in use; digits that are not evenly filled overflow a slab -> the exact passes below
   // (the input is untouched: the chain writes only its own buffers), and the chain is left alone for the next 8 sorts.
   bool chained = false;
-  if (c->sort_slab_cooldown > 0) c->sort_slab_cooldown--;
+  if (c->wm->sort_slab_cooldown > 0) c->wm->sort_slab_cooldown--;
   else if (k >= 2 && c->slab_mode && c->sort_slab && n >= c->sort_slab_min && n < 0xFFFFFFF0ull) {
     // exact: `diff` holds every bit in which keys differ (digits are trimmed to them).  Otherwise the sample saw all eight
     // digits vary and `sdiff` holds the bits IT saw varying: every digit keeps its eight bits (a bit the sample missed must
@@ -2841,7 +3141,7 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
       c->timing.path |= HMJ_PATH_SLAB;
       chained = true;
     } else {
-      c->sort_slab_cooldown = 8;
+      c->wm->sort_slab_cooldown = 8;
     }
   }
   if (chained) {

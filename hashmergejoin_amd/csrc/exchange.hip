@@ -19,10 +19,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 #include "hmj_ctx.h"
 
@@ -44,6 +47,8 @@ struct RcclApi {
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                        // optional: absent -> a timed-out communicator is leaked
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
   std::string error;
 };
 
@@ -77,6 +82,8 @@ bool rccl_load(RcclApi& api) {
   HMJ_SYM(AllGather, "ncclAllGather")
   HMJ_SYM(GetErrorString, "ncclGetErrorString")
 #undef HMJ_SYM
+  api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.dl, "ncclCommAbort"));
+  api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(dlsym(api.dl, "ncclCommGetAsyncError"));
   return true;
 }
 // loaded once per process, whichever thread / context asks first (contexts on several threads may initialise
@@ -112,6 +119,25 @@ struct hmj_comm {
   bool round_bytes_set = false;           // the host chose the round size itself (hmj_comm_set_message_bytes)
   int owner_path = HMJ_OWNER_DIGIT;       // non-ordered joins: digit ranges (default) or round 2's hash owner split (hmj_comm_set_owner_path, HMJ_EXCHANGE_OWNER=split)
   hmj_exchange_info info;
+  // ---- the deadline of a step (hmj_comm_set_timeout_ms).  Every host wait of a step that depends on another rank is a
+  // poll under this deadline; a watchdog thread aborts the RCCL communicator when the host itself is blocked inside an
+  // RCCL call (ncclGroupEnd setting up a connection to a peer that never arrives).  `mu` orders the owner thread's RCCL
+  // calls against the watchdog's ncclCommAbort: enqueue calls are made under it, calls that may block are made without
+  // it (in_blocking_call), which is the one use ncclCommAbort from another thread is meant for.
+  u64 timeout_ms = 120000;
+  std::chrono::steady_clock::time_point deadline;
+  bool step_open = false;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread watchdog;
+  bool wd_stop = false, wd_armed = false, in_blocking_call = false;
+  std::atomic<bool> broken{false};  // the communicator was aborted (timeout / asynchronous RCCL error): every later step fails
+  int broken_code = HMJ_OK;
+  // test hook HMJ_FAULT_STALL=<round>:<ms>: before that round's messages are posted the communication stream is held by a
+  // kernel that spins for <ms> milliseconds and then exits -- what a peer that stops sending looks like from this rank
+  // (RCCL's receive kernel spinning on data that does not come), with an end every wave reaches
+  int fault_stall_round = -1;
+  unsigned fault_stall_ms = 0;
 };
 
 namespace {
@@ -133,8 +159,158 @@ int rccl_fail(hmj_ctx* c, const char* what, ncclResult_t r) {
     if (_r != ncclSuccess) return rccl_fail(c, #expr, _r); \
   } while (0)
 
+// ---- the deadline of a step -----------------------------------------------------------------------------
+using Clock = std::chrono::steady_clock;
+
+// Mark the communicator broken and, with abort_now, abort it: RCCL's kernels leave their wait loops, the communication
+// stream drains, a host thread blocked inside an RCCL call returns.  The owner thread, which notices an expired deadline in
+// one of its own polls, only marks (it is not blocked, and ncclCommAbort itself waits for the communicator's kernels: the
+// step must return at its deadline, the abort happens at teardown); the watchdog aborts at once -- that is what unblocks
+// an owner stuck inside RCCL.  m->mu held.
+void abort_locked(hmj_comm* m, int code, bool abort_now) {
+  if (!m->broken.load()) {
+    m->broken_code = code;
+    m->broken.store(true);
+  }
+  if (abort_now && m->nccl) {
+    RcclApi* a = rccl_api();
+    if (a && a->CommAbort) (void)a->CommAbort(m->nccl);
+    m->nccl = nullptr;  // (a librccl without ncclCommAbort: the handle is leaked, never used again)
+  }
+}
+
+// The watchdog: sleeps until a step is open, then until one second past its deadline (the owner thread's own polls
+// notice an expired deadline first; the watchdog is for an owner that is blocked INSIDE an RCCL call).
+void watchdog_main(hmj_comm* m) {
+  std::unique_lock<std::mutex> lk(m->mu);
+  while (!m->wd_stop) {
+    if (!m->wd_armed) {
+      m->cv.wait(lk);
+      continue;
+    }
+    const auto fire = m->deadline + std::chrono::milliseconds(1000);
+    if (m->cv.wait_until(lk, fire) == std::cv_status::timeout && m->wd_armed && !m->wd_stop && Clock::now() >= fire) {
+      abort_locked(m, HMJ_E_TIMEOUT, true);
+      m->wd_armed = false;
+    }
+  }
+}
+
+bool expired(const hmj_comm* m) { return m->timeout_ms && Clock::now() >= m->deadline; }
+
+// The step cannot complete: abort the communicator and report why.
+int give_up(hmj_ctx* c, const char* waiting_for) {
+  hmj_comm* m = c->comm;
+  int code;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    abort_locked(m, HMJ_E_TIMEOUT, false);
+    code = m->broken_code;
+  }
+  char msg[256];
+  if (code == HMJ_E_TIMEOUT)
+    std::snprintf(msg, sizeof(msg),
+                  "rank %d of %d: no progress within %llu ms while waiting for %s -- a peer did not take part in the step; "
+                  "the communicator is unusable", m->rank, m->n_ranks, (unsigned long long)m->timeout_ms, waiting_for);
+  else
+    std::snprintf(msg, sizeof(msg), "rank %d of %d: the communicator failed while waiting for %s and is unusable", m->rank,
+                  m->n_ranks, waiting_for);
+  return fail(c, code == HMJ_E_TIMEOUT ? HMJ_E_TIMEOUT : HMJ_E_RCCL, msg);
+}
+
+// A host wait that may depend on another rank: poll `query` (hipStreamQuery / hipEventQuery) under the step's deadline,
+// looking at the communicator's asynchronous error state once a millisecond.  timeout 0: the plain blocking call.
+template <class Query, class Block>
+int wait_bounded(hmj_ctx* c, Query query, Block block, const char* what) {
+  hmj_comm* m = c->comm;
+  if (!m->timeout_ms) {
+    const hipError_t e = block();
+    return e == hipSuccess ? HMJ_OK : fail(c, HMJ_E_HIP, what, e);
+  }
+  auto next_look = Clock::now() + std::chrono::milliseconds(1);
+  for (int spin = 0;; spin++) {
+    const hipError_t e = query();
+    if (e == hipSuccess) return HMJ_OK;
+    if (e != hipErrorNotReady) return fail(c, HMJ_E_HIP, what, e);
+    if (spin < 256) continue;  // the usual case: done within microseconds
+    std::this_thread::sleep_for(std::chrono::microseconds(spin < 2048 ? 20 : 200));
+    const auto now = Clock::now();
+    if (now < next_look) continue;
+    next_look = now + std::chrono::milliseconds(1);
+    if (m->broken.load()) return give_up(c, what);  // (the watchdog was faster)
+    if (m->nccl && !m->has_cb) {
+      RcclApi* a = rccl_api();
+      std::lock_guard<std::mutex> lk(m->mu);
+      ncclResult_t st = ncclSuccess;
+      if (m->nccl && a && a->CommGetAsyncError && a->CommGetAsyncError(m->nccl, &st) == ncclSuccess && st != ncclSuccess &&
+          st != ncclInProgress) {
+        abort_locked(m, HMJ_E_RCCL, false);
+        return rccl_fail(c, "asynchronous RCCL error (ncclCommGetAsyncError)", st);
+      }
+    }
+    if (expired(m)) return give_up(c, what);
+  }
+}
+int wait_stream(hmj_ctx* c, hipStream_t s, const char* what) {
+  return wait_bounded(c, [s] { return hipStreamQuery(s); }, [s] { return hipStreamSynchronize(s); }, what);
+}
+int wait_event(hmj_ctx* c, hipEvent_t ev, const char* what) {
+  return wait_bounded(c, [ev] { return hipEventQuery(ev); }, [ev] { return hipEventSynchronize(ev); }, what);
+}
+// hmj_ctx::arrive_wait during a step: probe rows still on the links are waited for on the HOST, under the deadline
+// (api.hip would queue a device-side wait, and the join's next synchronisation would block for ever on a lost peer)
+int arrive_wait_hook(hmj_ctx* c, hipEvent_t ev) { return wait_event(c, ev, "an exchange round (probe rows)"); }
+
+// Is the stream idle within `ms`?  (teardown: never block for ever on a stream a lost peer left busy)
+bool drained_within(hipStream_t s, int ms) {
+  const auto until = Clock::now() + std::chrono::milliseconds(ms);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return true;  // idle, or an error that no wait will cure
+    if (Clock::now() >= until) return false;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
+struct StepScope {  // opens the step's deadline, arms the watchdog (RCCL transport); closes both on every exit
+  hmj_ctx* c;
+  explicit StepScope(hmj_ctx* ctx) : c(ctx) {
+    hmj_comm* m = c->comm;
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->deadline = Clock::now() + std::chrono::milliseconds(m->timeout_ms ? m->timeout_ms : 1000ull * 3600 * 24 * 365);
+    m->step_open = true;
+    if (m->timeout_ms && !m->has_cb && m->nccl) {
+      if (!m->watchdog.joinable()) m->watchdog = std::thread(watchdog_main, m);
+      m->wd_armed = true;
+      m->cv.notify_all();
+    }
+    if (m->timeout_ms) c->arrive_wait = arrive_wait_hook;
+  }
+  ~StepScope() {
+    hmj_comm* m = c->comm;
+    c->arrive_wait = nullptr;
+    if (!m) return;
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->step_open = false;
+    m->wd_armed = false;
+    m->cv.notify_all();
+  }
+};
+
 void comm_free(hmj_comm* m) {  // everything a (possibly half-built) communicator holds, except the RCCL handle
-  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->watchdog.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(m->mu);
+      m->wd_stop = true;
+      m->cv.notify_all();
+    }
+    m->watchdog.join();
+  }
+  if (m->stream && !drained_within(m->stream, 5000)) {
+    // a transfer that can never complete is still on the stream (no ncclCommAbort in this librccl, or the abort did not
+    // take): freeing the buffers it uses would block or fault -- leak them with the communicator
+    return;
+  }
   DevBuf* devs[] = {&m->parted_r, &m->parted_s, &m->recv_r, &m->recv_s, &m->offs, &m->gather_dev, &m->sample_dev};
   for (DevBuf* b : devs) free_dev(*b);
   free_host(m->gather_host);
@@ -164,8 +340,30 @@ int comm_ensure(hmj_ctx* c) {
   if (const char* e = getenv("HMJ_EXCHANGE_OWNER")) {  // "split": round 2's owner-split path for all non-ordered joins
     if (std::strcmp(e, "split") == 0) m->owner_path = HMJ_OWNER_SPLIT;
   }
+  if (const char* e = getenv("HMJ_COMM_TIMEOUT_MS")) m->timeout_ms = std::strtoull(e, nullptr, 10);  // (0: no deadline)
+  if (const char* e = getenv("HMJ_FAULT_STALL")) {  // test hook, see hmj_comm
+    int r = -1;
+    unsigned ms = 0;
+    if (std::sscanf(e, "%d:%u", &r, &ms) == 2 && ms <= 60000) {
+      m->fault_stall_round = r;
+      m->fault_stall_ms = ms;
+    }
+  }
   c->comm = m;
   return HMJ_OK;
+}
+
+// what a host-supplied collective returned: 0 ok, HMJ_E_TIMEOUT = it gave up waiting for a peer, anything else = failed
+int transport_cb_status(hmj_ctx* c, int rc, const char* what) {
+  if (rc == 0) return HMJ_OK;
+  if (rc == HMJ_E_TIMEOUT) return give_up(c, what);
+  return fail(c, HMJ_E_RCCL, what);
+}
+
+// (test hook) one wave that holds its stream for `ticks` of the constant-rate wall clock, then exits
+__global__ void fault_stall_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
 }
 
 // ---- transport ----------------------------------------------------------------------------------------
@@ -178,31 +376,35 @@ int transport_allgather(hmj_ctx* c, const u64* send, u64* recv, int count) {
     std::memcpy(recv, send, (size_t)count * 8);
     return HMJ_OK;
   }
-  if (m->has_cb) {
-    if (m->cb.allgather_u64(m->cb.user, send, recv, count) != 0) return fail(c, HMJ_E_RCCL, "transport: allgather_u64 failed");
-    return HMJ_OK;
-  }
+  if (m->has_cb) return transport_cb_status(c, m->cb.allgather_u64(m->cb.user, send, recv, count), "transport: allgather_u64");
   RcclApi* a = rccl_api();
   int rc;
   const size_t bytes = (size_t)count * 8;
   if ((rc = ensure_dev(c, m->gather_dev, bytes * (m->n_ranks + 1))) != HMJ_OK) return rc;
   char* d = static_cast<char*>(m->gather_dev.p);
   HIP_TRY(hipMemcpyAsync(d, send, bytes, hipMemcpyHostToDevice, m->stream));
-  RCCL_TRY(a->AllGather(d, d + bytes, (size_t)count, ncclUint64, m->nccl, m->stream));
+  {
+    // (the call may block while RCCL connects to its peers: made without the lock, so that the watchdog can abort it)
+    std::unique_lock<std::mutex> lk(m->mu);
+    if (m->broken.load() || !m->nccl) {
+      lk.unlock();
+      return give_up(c, "the all-gather");
+    }
+    ncclComm_t h = m->nccl;
+    lk.unlock();
+    const ncclResult_t r = a->AllGather(d, d + bytes, (size_t)count, ncclUint64, h, m->stream);
+    if (m->broken.load()) return give_up(c, "the all-gather");
+    if (r != ncclSuccess) return rccl_fail(c, "ncclAllGather", r);
+  }
   HIP_TRY(hipMemcpyAsync(recv, d + bytes, bytes * m->n_ranks, hipMemcpyDeviceToHost, m->stream));
-  HIP_TRY(hipStreamSynchronize(m->stream));
-  return HMJ_OK;
+  return wait_stream(c, m->stream, "the all-gather");
 }
 
 // one round of the all-to-all-v on device memory, queued on the communication stream
 int transport_round(hmj_ctx* c, int round, const void* const* sp, const u64* sb, void* const* rp, const u64* rb) {
   hmj_comm* m = c->comm;
   const int G = m->n_ranks, me = m->rank;
-  if (m->has_cb) {
-    if (m->cb.alltoallv(m->cb.user, round, sp, sb, rp, rb, (void*)m->stream) != 0)
-      return fail(c, HMJ_E_RCCL, "transport: alltoallv failed");
-    return HMJ_OK;
-  }
+  if (m->has_cb) return transport_cb_status(c, m->cb.alltoallv(m->cb.user, round, sp, sb, rp, rb, (void*)m->stream), "transport: alltoallv");
   RcclApi* a = rccl_api();
   // this rank's own bucket: a device copy when there are peers (it overlaps the link traffic); with a single
   // rank the copy goes through RCCL's send/recv pair as well, which keeps that path exercised on one GPU
@@ -216,19 +418,36 @@ int transport_round(hmj_ctx* c, int round, const void* const* sp, const u64* sb,
   // message goes as consecutive pieces; both sides cut the same byte count the same way, and pieces between one
   // pair of ranks match in the order they are posted.
   const u64 lim = m->max_msg_bytes;
-  RCCL_TRY(a->GroupStart());
-  for (int g = 0; g < G; g++) {
-    if (g == me && !self_rccl) continue;
-    for (u64 off = 0; off < sb[g]; off += lim)
-      RCCL_TRY(a->Send(static_cast<const char*>(sp[g]) + off, (size_t)std::min<u64>(lim, sb[g] - off), ncclUint8, g, m->nccl, m->stream));
-    for (u64 off = 0; off < rb[g]; off += lim)
-      RCCL_TRY(a->Recv(static_cast<char*>(rp[g]) + off, (size_t)std::min<u64>(lim, rb[g] - off), ncclUint8, g, m->nccl, m->stream));
+  if (m->fault_stall_round == round && m->fault_stall_ms) {  // (test hook)
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
+    hipLaunchKernelGGL(fault_stall_kernel, dim3(1), dim3(64), 0, m->stream, (unsigned long long)khz * m->fault_stall_ms);
   }
-  RCCL_TRY(a->GroupEnd());
+  // Sends and receives are only recorded inside the group (under the lock: the watchdog cannot abort the communicator
+  // between two of them); ncclGroupEnd launches -- and may block while RCCL connects to a peer -- so it runs without.
+  std::unique_lock<std::mutex> lk(m->mu);
+  if (m->broken.load() || !m->nccl) {
+    lk.unlock();
+    return give_up(c, "an exchange round");
+  }
+  ncclResult_t r = a->GroupStart();
+  for (int g = 0; g < G && r == ncclSuccess; g++) {
+    if (g == me && !self_rccl) continue;
+    for (u64 off = 0; off < sb[g] && r == ncclSuccess; off += lim)
+      r = a->Send(static_cast<const char*>(sp[g]) + off, (size_t)std::min<u64>(lim, sb[g] - off), ncclUint8, g, m->nccl, m->stream);
+    for (u64 off = 0; off < rb[g] && r == ncclSuccess; off += lim)
+      r = a->Recv(static_cast<char*>(rp[g]) + off, (size_t)std::min<u64>(lim, rb[g] - off), ncclUint8, g, m->nccl, m->stream);
+  }
+  lk.unlock();
+  const ncclResult_t re = a->GroupEnd();  // (always: a group that was started must be ended)
+  if (m->broken.load()) return give_up(c, "an exchange round");
+  if (r != ncclSuccess) return rccl_fail(c, "ncclSend / ncclRecv", r);
+  if (re != ncclSuccess) return rccl_fail(c, "ncclGroupEnd", re);
   return HMJ_OK;
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------
+
 // K keys of a relation: one from each of K equal strata, at a pseudo-random position inside the stratum (a regular
 // stride aliases with periodic key patterns: every 128th row of "every fourth key is in another cluster" never
 // sees that cluster)
@@ -457,10 +676,20 @@ namespace hmj_host {
 void comm_destroy(hmj_ctx* c) {
   hmj_comm* m = c->comm;
   if (!m) return;
-  if (m->stream) (void)hipStreamSynchronize(m->stream);
-  if (m->nccl) {
-    RcclApi* a = rccl_api();
-    if (a) (void)a->CommDestroy(m->nccl);
+  c->arrive_wait = nullptr;
+  {
+    // ncclCommDestroy waits for everything queued on the communicator: only when the communication stream drains;
+    // otherwise (a peer was lost and nobody noticed yet) the communicator is aborted
+    const bool idle = !m->stream || drained_within(m->stream, 5000);
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (m->nccl) {
+      RcclApi* a = rccl_api();
+      if (idle && a && !m->broken.load())
+        (void)a->CommDestroy(m->nccl);
+      else if (a && a->CommAbort)
+        (void)a->CommAbort(m->nccl);
+      m->nccl = nullptr;
+    }
   }
   comm_free(m);
   c->comm = nullptr;
@@ -534,6 +763,20 @@ int hmj_comm_set_message_bytes(hmj_ctx* c, uint64_t max_message_bytes, uint64_t 
     c->comm->target_round_bytes = probe_round_bytes < 16 ? 16 : probe_round_bytes;
     c->comm->round_bytes_set = true;
   }
+  return HMJ_OK;
+}
+
+int hmj_comm_set_timeout_ms(hmj_ctx* c, uint64_t timeout_ms) {
+  if (!c || !c->comm) return c ? fail(c, HMJ_E_ARG, "no communicator") : HMJ_E_ARG;
+  std::lock_guard<std::mutex> lk(c->comm->mu);
+  if (c->comm->step_open) return fail(c, HMJ_E_ARG, "hmj_comm_set_timeout_ms during a step");
+  c->comm->timeout_ms = timeout_ms;
+  return HMJ_OK;
+}
+
+int hmj_comm_get_timeout_ms(hmj_ctx* c, uint64_t* timeout_ms) {
+  if (!c || !c->comm || !timeout_ms) return HMJ_E_ARG;
+  *timeout_ms = c->comm->timeout_ms;
   return HMJ_OK;
 }
 
@@ -897,18 +1140,16 @@ int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np
   const auto t_local = std::chrono::steady_clock::now();
   std::memset(local_out, 0, sizeof(*local_out));
   int lerr = HMJ_OK;
-  {
-    hipError_t e = *err == HMJ_OK ? hipStreamWaitEvent(c->stream, m->ev_build, 0) : hipSuccess;
-    if (e != hipSuccess) lerr = fail(c, HMJ_E_HIP, "hipStreamWaitEvent", e);
-  }
+  // The waits for rows from other ranks are HOST waits under the step's deadline (a join cannot start before its rows
+  // are there anyway): the compute stream never depends on a peer, so nothing this rank queues on it can block for ever.
+  if (*err == HMJ_OK) lerr = wait_event(c, m->ev_build, "the build side's exchange rounds");
+  if (m->broken.load()) return lerr != HMJ_OK ? lerr : give_up(c, "the build side's exchange rounds");
   if (*err != HMJ_OK) lerr = *err;  // (a local failure while the rounds were queued: no joins, straight to the reduction)
   for (u32 r = 0; r < NR && lerr == HMJ_OK; r++) {
     const u64 nr_ = round_off_r[r + 1] - round_off_r[r], ns_ = round_off_s[r + 1] - round_off_s[r];
-    hipError_t e = hipStreamWaitEvent(c->stream, m->round_ev[r], 0);
-    if (e != hipSuccess) {
-      lerr = fail(c, HMJ_E_HIP, "round event", e);
-      break;
-    }
+    lerr = wait_event(c, m->round_ev[r], "an exchange round (probe rows)");
+    if (m->broken.load()) return lerr != HMJ_OK ? lerr : give_up(c, "an exchange round (probe rows)");
+    if (lerr != HMJ_OK) break;
     if (ns_ == 0) continue;                              // no probe rows: no result rows, no probe payloads
     if (nr_ == 0 && !(flags & HMJ_SUM_PROBE)) continue;  // nothing can match (and no probe payload sum is asked for)
     hmj_result res;
@@ -938,8 +1179,11 @@ int exchange_digit_path(hmj_ctx* c, const void* R, u64 nb, const void* S, u64 np
   }
   if (lerr != HMJ_OK) *err = lerr;
   // the sends of this rank must have left its buffers before the next step may overwrite them
-  hipError_t e = hipStreamSynchronize(m->stream);
-  if (e != hipSuccess && *err == HMJ_OK) *err = fail(c, HMJ_E_HIP, "communication stream", e);
+  {
+    const int w = wait_stream(c, m->stream, "this rank's sends (communication stream)");
+    if (m->broken.load()) return w != HMJ_OK ? w : give_up(c, "this rank's sends");
+    if (w != HMJ_OK && *err == HMJ_OK) *err = w;
+  }
   m->info.ms_local = ms_since(t_local);
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, m->ev_t0, m->ev_t3) == hipSuccess) m->info.ms_exchange_build = ms;
@@ -1080,8 +1324,10 @@ int exchange_owner_path(hmj_ctx* c, const void* build_shard_dev, u64 n_build, co
   // ---- local join: build side as soon as it is complete, probe side as its rounds arrive
   const auto t_local = std::chrono::steady_clock::now();
   int lerr = *err;
-  hipError_t e = lerr == HMJ_OK ? hipStreamWaitEvent(c->stream, m->ev_build, 0) : hipSuccess;
-  if (e != hipSuccess) lerr = fail(c, HMJ_E_HIP, "hipStreamWaitEvent", e);
+  // (host waits under the step's deadline, as in the digit path; the probe side's rounds are waited for inside the
+  //  join through hmj_ctx::arrive_wait)
+  if (lerr == HMJ_OK) lerr = wait_event(c, m->ev_build, "the build side's exchange rounds");
+  if (m->broken.load()) return lerr != HMJ_OK ? lerr : give_up(c, "the build side's exchange rounds");
   spans_reset(c);
   c->sample_build_only = true;
   // count modes (checksums and first-wins included): the build side is partitioned while the probe rows are on
@@ -1102,8 +1348,11 @@ int exchange_owner_path(hmj_ctx* c, const void* build_shard_dev, u64 n_build, co
     m->info.ms_kernels = kernel_ms(c->timing);
   }
   if (lerr != HMJ_OK) *err = lerr;
-  e = hipStreamSynchronize(m->stream);
-  if (e != hipSuccess && *err == HMJ_OK) *err = fail(c, HMJ_E_HIP, "communication stream", e);
+  {
+    const int w = m->broken.load() ? HMJ_E_TIMEOUT : wait_stream(c, m->stream, "this rank's sends (communication stream)");
+    if (m->broken.load()) return lerr == HMJ_E_TIMEOUT ? lerr : give_up(c, "the exchange rounds");
+    if (w != HMJ_OK && *err == HMJ_OK) *err = w;
+  }
   m->info.ms_local = ms_since(t_local);
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, m->ev_t0, m->ev_t1) == hipSuccess) m->info.ms_exchange_build = ms;
@@ -1122,7 +1371,11 @@ extern "C" int hmj_exchange_join_u64_device(hmj_ctx* c, const void* build_shard_
   HIP_TRY(hipSetDevice(c->device));
   hmj_comm* m = c->comm;
   const int G = m->n_ranks;
+  if (m->broken.load())
+    return fail(c, m->broken_code == HMJ_E_TIMEOUT ? HMJ_E_TIMEOUT : HMJ_E_RCCL,
+                "the communicator was aborted by an earlier step (timeout or RCCL error): destroy it and create a new one");
   if (!m->has_cb && !m->nccl) return fail(c, HMJ_E_ARG, "communicator has no transport");
+  StepScope step_scope(c);  // the deadline of this step; closed on every return below
   if (flags & HMJ_ORDERED) flags |= HMJ_MATERIALIZE;
   std::memset(&m->info, 0, sizeof(m->info));
   std::memset(local_out, 0, sizeof(*local_out));

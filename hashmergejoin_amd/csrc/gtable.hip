@@ -454,9 +454,22 @@ __global__ __launch_bounds__(GTW_THREADS) void gtable_write_kernel(const Tup* __
 // one composite per matching probe row -> LSD radix passes over the composite's rank_bits + range_bits low bits ->
 // gtable_expand_kernel turns every composite back into its result row.  The partitioned paths rank every probe row inside
 // its key's run, linear in the run: 2^16 x 2^26 rows ordered 14-22 ms, 2^10 x 2^22 6 ms (an 18-bit plan of 2^18 partitions).
+// (one atomic pair per WORKGROUP and four loads in flight per thread: with one pair per wave of a 2048-workgroup grid, the
+//  16 384 same-address atomics were half of the kernel's 0.38 ms at 2^26 rows -- profiles/r05a_small16_ord_summary.txt)
 __global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__ S, u32 np, u64* __restrict__ out) {
+  __shared__ u64 wmn[4], wmx[4];
   u64 mn = ~0ull, mx = 0;
-  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < np; i += (u64)gridDim.x * 256) {
+  const u64 stride = (u64)gridDim.x * 256;
+  u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < np; i += 4 * stride) {
+    const u64 v0 = load_stream(&S[i]).val, v1 = load_stream(&S[i + stride]).val, v2 = load_stream(&S[i + 2 * stride]).val,
+              v3 = load_stream(&S[i + 3 * stride]).val;
+    const u64 lo01 = v0 < v1 ? v0 : v1, lo23 = v2 < v3 ? v2 : v3, hi01 = v0 > v1 ? v0 : v1, hi23 = v2 > v3 ? v2 : v3;
+    const u64 lo = lo01 < lo23 ? lo01 : lo23, hi = hi01 > hi23 ? hi01 : hi23;
+    mn = lo < mn ? lo : mn;
+    mx = hi > mx ? hi : mx;
+  }
+  for (; i < np; i += stride) {
     const u64 v = S[i].val;
     mn = v < mn ? v : mn;
     mx = v > mx ? v : mx;
@@ -467,7 +480,16 @@ __global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__
     mn = a2 < mn ? a2 : mn;
     mx = b2 > mx ? b2 : mx;
   }
-  if ((threadIdx.x & 63) == 0 && np) {
+  if ((threadIdx.x & 63) == 0) {
+    wmn[threadIdx.x >> 6] = mn;
+    wmx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && np) {
+    for (int w = 1; w < 4; w++) {
+      mn = wmn[w] < mn ? wmn[w] : mn;
+      mx = wmx[w] > mx ? wmx[w] : mx;
+    }
     atomicMin(reinterpret_cast<unsigned long long*>(out), (unsigned long long)mn);
     atomicMax(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)mx);
   }
@@ -477,7 +499,8 @@ __global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__
 // pairs[cursor++] = {rank << range_bits | (sval - svmin), 0}; accum[ACC_N] is the cursor.
 // WIDE (rank and payload do not fit one word together): pairs[..] = {sval - svmin, rank} -- sorted by the payload first, then
 // (after gtable_swap_kernel) stably by the rank.
-template <bool EXTRA, bool WIDE>
+// RANKKEY (round 5, the rank-run form below): pairs[..] = {rank, sval} -- no payload range needed, any payload width.
+template <bool EXTRA, bool WIDE, bool RANKKEY = false>
 __global__ __launch_bounds__(GTW_THREADS) void gtable_emit_kernel(const Tup* __restrict__ S, u32 np, const Tup* __restrict__ tab,
                                                                   int log_cap, u64 svmin, int range_bits, u64* __restrict__ accum,
                                                                   Tup* __restrict__ pairs) {
@@ -549,7 +572,10 @@ __global__ __launch_bounds__(GTW_THREADS) void gtable_emit_kernel(const Tup* __r
     for (int r = 0; r < GT_ROWS; r++) {
       if ((hit >> r) & 1u) {
         Tup o;
-        if (WIDE) {
+        if (RANKKEY) {
+          o.key = rank[r];
+          o.val = t[r].val;
+        } else if (WIDE) {
           o.key = t[r].val - svmin;
           o.val = rank[r];
         } else {
@@ -698,6 +724,249 @@ __global__ __launch_bounds__(256) void pieces_compact_kernel(const Tup* __restri
   }
 }
 
+// ---- the rank-run form (round 5): ordered result of a small build side under a probe side of fan-out ~32 ... ~1700 ------
+// With unique build keys the operator's order (key, rval, sval) is: the probe rows grouped by the RANK of their key, every
+// group sorted by sval.  The composite form above sorts (rank, sval - svmin) with 4-10 global LSD passes of 32 B per row
+// each (2^16 x 2^26 rows: 4.7 ms = 0.07 of the HBM peak, 8.8 ms when the payloads span 64 bits: profiles/r05a_small16_ord*).
+// Here the rows {rank, sval} are PARTITIONED by rank with the join's own two histogram-free slab passes (rank bits = the
+// two digits, so partition p = the rows of rank p, in four slab pieces), and one workgroup per rank sorts its run of svals
+// in LDS -- a register-tiled bitonic network on 32-bit keys sval - min (or the 64-bit svals where a run spans more) -- and
+// writes (key, rval, sval) at the rank's offset.  Two global passes instead of five, no payload range needed, payload
+// width irrelevant.  Runs beyond RS_CAP rows (a hot key, fan-out > ~1700) raise ERR_FASTPATH: the composite form runs.
+constexpr int RS_THREADS = 256, RS_EPT = 8, RS_CAP = RS_THREADS * RS_EPT;  // 2048 rows per rank at most
+// LDS position of element i: the low three index bits XORed with bits 5..7, so that the eight consecutive elements a
+// thread takes in the stride-1 steps fall into different banks than its neighbours' (16-way conflicts otherwise)
+__device__ __forceinline__ u32 rs_sw(u32 i) { return i ^ ((i >> 5) & 7u); }
+
+template <typename K>
+__device__ __forceinline__ void rs_ce(K& a, K& b, bool asc) {
+  const K lo = a < b ? a : b, hi = a < b ? b : a;
+  a = asc ? lo : hi;
+  b = asc ? hi : lo;
+}
+// three levels of a bitonic merge on the eight elements v[i] = element base + i * q: strides 4q, 2q, q
+template <typename K>
+__device__ __forceinline__ void rs_three_levels(K (&v)[RS_EPT], bool asc) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) rs_ce(v[i], v[i + 4], asc);
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if (!(i & 2)) rs_ce(v[i], v[i | 2], asc);
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) rs_ce(v[i], v[i + 1], asc);
+}
+// Sort s[rs_sw(0 .. N)) ascending; N a power of two in [8, RS_CAP]; threads tid < N / 8 work, all threads pass the barriers.
+template <typename K>
+__device__ __forceinline__ void rs_bitonic(K* __restrict__ s, u32 N, int tid) {
+  const bool active = (u32)tid < (N >> 3);
+  K v[RS_EPT];
+  // phases k = 2, 4, 8: inside a thread's eight consecutive elements
+  if (active) {
+    const u32 base = (u32)tid << 3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = s[rs_sw(base + i)];
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) rs_ce(v[i], v[i + 1], (i & 2) == 0);  // k = 2
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (!(i & 2)) rs_ce(v[i], v[i | 2], (i & 4) == 0);  // k = 4, j = 2
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) rs_ce(v[i], v[i + 1], (i & 4) == 0);  // k = 4, j = 1
+    rs_three_levels(v, (base & 8u) == 0);  // k = 8
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[rs_sw(base + i)] = v[i];
+  }
+  lds_barrier();
+  for (u32 k = 16; k <= N; k <<= 1) {
+    // Levels k/2 ... 1 of this merge, three per round trip through LDS: a group works on the strides (4q, 2q, q).  q starts
+    // at k/8 and drops by 8 while a full group is left; the last group is always (4, 2, 1).  Where that repeats a level
+    // already done (k = 16: (8, 4, 2) then (4, 2, 1)) the repeat is a no-op: after level j every element of a 2j-block's
+    // lower half is <= every element of its upper half, which the lower levels -- permutations inside the halves -- keep.
+    for (u32 q = k >> 3;;) {
+      if (active) {
+        const u32 lq = 31u - (u32)__builtin_clz(q);
+        const u32 base = (((u32)tid >> lq) << (lq + 3)) | ((u32)tid & (q - 1));
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = s[rs_sw(base + (u32)i * q)];
+        rs_three_levels(v, (base & k) == 0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[rs_sw(base + (u32)i * q)] = v[i];
+      }
+      lds_barrier();
+      if (q == 1) break;
+      q = q >= 8 ? (q >> 3) : 1u;
+    }
+  }
+}
+
+template <bool EXTRA>
+__global__ __launch_bounds__(RS_THREADS) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
+                                                                     u32 P, const u64* __restrict__ out_off,
+                                                                     const Tup* __restrict__ sortedR, u32 nb, u64* __restrict__ out_key,
+                                                                     u64* __restrict__ out_rval, u64* __restrict__ out_sval,
+                                                                     u64* __restrict__ accum) {
+  __shared__ __attribute__((aligned(16))) u64 keys[RS_CAP];  // 16 KiB: 64-bit keys, or 32-bit keys in its first half
+  __shared__ u64 red[8];
+  __shared__ u64 wmn[RS_THREADS / kWave], wmx[RS_THREADS / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 8) red[tid] = 0;
+  u64 acc_r = 0, acc_x = 0, acc_m = 0;
+  bool bad = false;
+  for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
+    const u32* q = cnt + (u64)p * SLAB_KB;
+    const u32 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+    const u32 n = c0 + c1 + c2 + c3;
+    if (n == 0) continue;
+    if (n > (u32)RS_CAP || p >= nb || c0 > cap || c1 > cap || c2 > cap || c3 > cap) {  // (uniform) a run beyond the kernel, or counts no slab pass wrote
+      bad = true;
+      continue;
+    }
+    const Tup* __restrict__ base = slabs + (u64)p * SLAB_KB * cap;
+    // ---- the run's payloads, coalesced piece by piece; their range
+    u64 sv[RS_EPT];
+    u64 mn = ~0ull, mx = 0;
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+      const u32 i = (u32)tid + (u32)r * RS_THREADS;
+      sv[r] = 0;
+      if (i < n) {
+        const u32 k = i < c0 ? 0u : i < c0 + c1 ? 1u : i < c0 + c1 + c2 ? 2u : 3u;
+        const u32 start = k == 0 ? 0u : k == 1 ? c0 : k == 2 ? c0 + c1 : c0 + c1 + c2;
+        sv[r] = load_stream(&base[(u64)k * cap + (i - start)]).val;
+        mn = sv[r] < mn ? sv[r] : mn;
+        mx = sv[r] > mx ? sv[r] : mx;
+      }
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      const u64 a2 = __shfl_xor(mn, o, kWave), b2 = __shfl_xor(mx, o, kWave);
+      mn = a2 < mn ? a2 : mn;
+      mx = b2 > mx ? b2 : mx;
+    }
+    if (lane == 0) {
+      wmn[wv] = mn;
+      wmx[wv] = mx;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int w = 0; w < RS_THREADS / kWave; w++) {
+      mn = wmn[w] < mn ? wmn[w] : mn;
+      mx = wmx[w] > mx ? wmx[w] : mx;
+    }
+    const u64 range = mx - mn;
+    u32 N = 8;
+    while (N < n) N <<= 1;
+    const Tup b = sortedR[p];
+    const u64 off = out_off[p];
+    if (range < 0xFFFFFFFFull) {  // 32-bit keys sval - min; the padding (all ones) is above every real key
+      u32* k32 = reinterpret_cast<u32*>(keys);
+#pragma unroll
+      for (int r = 0; r < RS_EPT; r++) {
+        const u32 i = (u32)tid + (u32)r * RS_THREADS;
+        if (i < N) k32[rs_sw(i)] = i < n ? (u32)(sv[r] - mn) : 0xFFFFFFFFu;
+      }
+      lds_barrier();
+      rs_bitonic<u32>(k32, N, tid);
+#pragma unroll
+      for (int r = 0; r < RS_EPT; r++) {
+        const u32 i = (u32)tid + (u32)r * RS_THREADS;
+        if (i < n) sv[r] = (u64)k32[rs_sw(i)] + mn;
+      }
+    } else if (range != ~0ull) {
+#pragma unroll
+      for (int r = 0; r < RS_EPT; r++) {
+        const u32 i = (u32)tid + (u32)r * RS_THREADS;
+        if (i < N) keys[rs_sw(i)] = i < n ? sv[r] - mn : ~0ull;
+      }
+      lds_barrier();
+      rs_bitonic<u64>(keys, N, tid);
+#pragma unroll
+      for (int r = 0; r < RS_EPT; r++) {
+        const u32 i = (u32)tid + (u32)r * RS_THREADS;
+        if (i < n) sv[r] = keys[rs_sw(i)] + mn;
+      }
+    } else {  // payloads 0 and 2^64 - 1 in one run: no value is free for the padding
+      bad = true;
+      lds_barrier();
+      continue;
+    }
+    // ---- rows out: the rank's key and payload, the sorted probe payloads
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+      const u32 i = (u32)tid + (u32)r * RS_THREADS;
+      if (i < n) {
+        out_key[off + i] = b.key;
+        out_rval[off + i] = b.val;
+        out_sval[off + i] = sv[r];
+        if (EXTRA) {
+          const u64 m = tmix(b.key, b.val, sv[r]);
+          acc_x ^= m;
+          acc_m += m;
+        }
+      }
+    }
+    if (tid == 0) acc_r += b.val * (u64)n;
+    lds_barrier();  // (keys / wmn / wmx are rewritten by the next run)
+  }
+  if (bad && tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
+  __syncthreads();
+  const u64 v[6] = {0, acc_r, 0, acc_x, acc_m, 0};
+  block_accumulate(red, accum, v, 1u << ACC_XOR);
+}
+
+// off[i] = in[0] + ... + in[i - 1], off[n] = total: ONE workgroup, a contiguous share per thread (two passes over values that
+// stay in L2) -- 2^16 ... 2^18 partition totals in ~20 us (scan_u64_kernel walks them 1024 at a time behind three barriers
+// each: 0.19 ms for 2^17, profiles/r05a_fk22_ord_summary.txt)
+__global__ __launch_bounds__(1024) void scan_chunked_u64_kernel(const u64* __restrict__ in, u64* __restrict__ off, u32 n) {
+  __shared__ u64 wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const u32 per = (n + 1023u) / 1024u, b = (u32)tid * per, e = b + per < n ? b + per : n;
+  u64 s = 0;
+  for (u32 i = b; i < e; i++) s += in[i];
+  u64 incl = s;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const u64 up = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += up;
+  }
+  if (lane == kWave - 1) wtot[wv] = incl;
+  __syncthreads();
+  u64 before = 0, all = 0;
+  for (int w2 = 0; w2 < 16; w2++) {
+    if (w2 < wv) before += wtot[w2];
+    all += wtot[w2];
+  }
+  u64 run = before + incl - s;
+  for (u32 i = b; i < e; i++) {
+    const u64 v = in[i];
+    off[i] = run;
+    run += v;
+  }
+  if (tid == 0) off[n] = all;
+}
+
+hipError_t launch_scan_chunked_u64(const u64* in, u64* off, u32 n, hipStream_t st) {
+  if (!in || !off || n == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(scan_chunked_u64_kernel, dim3(1), dim3(1024), 0, st, in, off, n);
+  return hipGetLastError();
+}
+
+int rank_sort_max_run() { return RS_CAP; }
+hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb,
+                                  u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st) {
+  if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0)
+    return hipErrorInvalidValue;
+  u32 grid = (u32)num_cus * 8u;  // 16 KiB of LDS and 256 threads per workgroup: eight per CU
+  if (grid > P) grid = P;
+  if (extra)
+    hipLaunchKernelGGL((rank_sort_write_kernel<true>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
+                       static_cast<const Tup*>(sortedR), nb, out_key, out_rval, out_sval, accum);
+  else
+    hipLaunchKernelGGL((rank_sort_write_kernel<false>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
+                       static_cast<const Tup*>(sortedR), nb, out_key, out_rval, out_sval, accum);
+  return hipGetLastError();
+}
+
 hipError_t launch_pieces_compact(const void* slabs, const u32* cnt, const u64* off, u32 n_pieces, u32 cap, void* out, int num_cus,
                                  hipStream_t st) {
   if (!slabs || !cnt || !off || !out || n_pieces == 0 || cap == 0) return hipErrorInvalidValue;
@@ -789,7 +1058,26 @@ hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_c
 }
 
 hipError_t launch_sval_range(const void* S, u32 np, u64* out2, int num_cus, hipStream_t st) {
-  hipLaunchKernelGGL(sval_range_kernel, dim3(num_cus * 8), dim3(256), 0, st, static_cast<const Tup*>(S), np, out2);
+  u64 grid = ((u64)np + 1023) / 1024;  // (a workgroup per 1024 rows at most: a tiny relation does not launch 2048 of them)
+  if (grid > (u64)num_cus * 8) grid = (u64)num_cus * 8;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(sval_range_kernel, dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(S), np, out2);
+  return hipGetLastError();
+}
+
+hipError_t launch_gtable_emit_ranks(const void* S, u32 np, const void* tab, int log_cap, u64* accum, void* pairs, bool extra, int num_cus,
+                                    int wg_per_cu, hipStream_t st) {
+  if (log_cap < 4 || log_cap > 30 || !pairs) return hipErrorInvalidValue;
+  const u64 tiles = ((u64)np + GTW_THREADS * GT_ROWS - 1) / (GTW_THREADS * GT_ROWS);
+  u64 grid = (u64)num_cus * (u64)(wg_per_cu > 0 ? wg_per_cu : 8) * GT_THREADS / GTW_THREADS;
+  if (grid > tiles) grid = tiles;
+  if (grid < 1) grid = 1;
+  if (extra)
+    hipLaunchKernelGGL((gtable_emit_kernel<true, false, true>), dim3((u32)grid), dim3(GTW_THREADS), 0, st, static_cast<const Tup*>(S), np,
+                       static_cast<const Tup*>(tab), log_cap, 0ull, 0, accum, static_cast<Tup*>(pairs));
+  else
+    hipLaunchKernelGGL((gtable_emit_kernel<false, false, true>), dim3((u32)grid), dim3(GTW_THREADS), 0, st, static_cast<const Tup*>(S), np,
+                       static_cast<const Tup*>(tab), log_cap, 0ull, 0, accum, static_cast<Tup*>(pairs));
   return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hmj.h"
@@ -33,12 +34,41 @@ struct Span {
   int pass;               // K_SCATTER: 0 = a relation's first radix pass, 1 = a later one
 };
 
+// What a context has LEARNT about a workload -- which fast paths gave up on it and are skipped for its next joins, which
+// form of the ordered kernels its keys need -- keyed by the workload's signature (log2 of both sizes, the mode flags):
+// a join that overflows a slab or meets duplicate build keys changes the plans of later joins OF THE SAME SHAPE only.
+// (Until round 4 these were eleven counters of the context: BASELINE configs[4]'s failed slab attempt put the next eight
+//  joins of ANY shape on the exact path, VERDICT r4 #4.)  A cool-down of n: the next n joins of this workload skip the path.
+struct WorkloadMemo {
+  int uniq_cooldown = 0;            // unique-key write mode (after duplicate build keys)
+  int sorted_cooldown = 0;          // one-pass ordered write
+  bool sorted_chained = false;      // dense output offsets by a chained scan over the partitions (on after an ordered join
+                                    // with unmatched probe rows; HMJ_SORTED_WRITE=2 always, 3 never)
+  bool sorted_wide = true;          // ordered foreign-key joins may be planned for the 6144-row shape (HMJ_SORTED_WIDE=0: never)
+  bool sorted_fk = false;           // the last ordered join's probe keys repeated: start with the foreign-key form
+  int sorted_fk_age = 0;
+  int gtable_cooldown = 0;          // global table, count modes (after it gave up: duplicates, a clustering key set)
+  int gtable_write_cooldown = 0;    // ... materialising (after duplicate build keys)
+  int gtable_sort_cooldown = 0;     // ordered by a sort on (key rank, payload) composites
+  int gtable_sort_slab_cooldown = 0;  // ... its passes as a chain of slab passes (after a slab overflowed)
+  int rank_runs_cooldown = 0;       // ... the rank-run form (after a slab overflowed or a run did not fit one workgroup's sort)
+  int expand_cooldown = 0;          // ordered expansion (after a partition did not fit the kernel)
+  int sort_slab_cooldown = 0;       // hmj_sort_u64_device: chain of slab passes (after a slab overflowed: skewed digits)
+  int slab_cooldown = 0;            // histogram-free slab partitioning of both sides (after a slab overflowed: skewed keys)
+  int slab_probe_cooldown = 0;      // ... of the probe side only (probe-heavy count joins, one-pass slab walk)
+  int one_pass_write_cooldown = 0;  // materialising on the one-pass slab walk (after duplicate build keys)
+  int exact_prefix_joins = 0;       // ordered joins that still take the shared key prefix from a pass over ALL keys: the
+                                    // sample of an earlier join missed a few keys above an otherwise dense range
+  uint32_t cooling() const;         // HMJ_COOL_* bits of the non-zero counters (hmj_plan_desc.cooling)
+};
+
 }  // namespace hmj_host
 
 struct hmj_ctx {
   using DevBuf = hmj_host::DevBuf;
   using HostBuf = hmj_host::HostBuf;
   using Span = hmj_host::Span;
+  using WorkloadMemo = hmj_host::WorkloadMemo;
   using u32 = hmj::u32;
   using u64 = hmj::u64;
   int device = 0, num_cus = 256;
@@ -51,6 +81,12 @@ struct hmj_ctx {
   std::vector<hipStream_t> up_streams;
   std::vector<hipEvent_t> up_events;  // 2 per staging thread
   std::vector<HostBuf> up_slots;      // 2 per staging thread
+  // adaptive state, per workload signature (hmj_host::memo_for); `wm` is the memo of the call in progress
+  std::unordered_map<uint64_t, WorkloadMemo> memos;
+  WorkloadMemo memo_init;   // what a new workload starts from (HMJ_SORTED_WRITE / HMJ_SORTED_WIDE set its flags)
+  WorkloadMemo* wm = &memo_init;
+  uint64_t wm_sig = 0;
+  hmj_plan_desc plan;       // hmj_last_plan: how the last join was planned and why
   int force_bits = -1;
   int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
   int min_prefix_bits = 0;  // with sampling: the partition window starts at or below this many top bits (internal: exchange rounds)
@@ -63,7 +99,6 @@ struct hmj_ctx {
     int low = 0, B = 0;
   } prep;
   bool prepare_only = false;
-  int uniq_cooldown = 0;  // joins left before the unique-key write mode is tried again
   // placement of big allocations (ensure_dev, api.hip): candidates are probed with a fill and the fastest kept
   int place_tries = 4;     // candidates per allocation when a search runs (HMJ_PLACE=n); a fresh candidate of 6 GB costs 3-450 ms
   float place_budget_ms = 50.f;  // wall-clock budget of one buffer's search (HMJ_PLACE_BUDGET_MS)
@@ -75,16 +110,10 @@ struct hmj_ctx {
   size_t place_min_bytes = 2048ull << 20;  // only allocations of this size and more are probed (HMJ_PLACE_MIN_MB)
   std::vector<hmj_place_info> place_log;  // one entry per probed buffer (hmj_placement_info)
   bool dense_plan = true;    // HMJ_DENSE_PLAN=0: never size the plan by the build keys' share of the key range
-  int sorted_cooldown = 0;   // ordered joins left before the one-pass ordered write is tried again
   bool sorted_mode = true;   // HMJ_SORTED_WRITE=0: ordered joins always take write + order epilogue
-  bool sorted_chained = false;  // dense output offsets by a chained scan over the partitions (adaptive: on after an
-                                // ordered join with unmatched probe rows; HMJ_SORTED_WRITE=2 always, 3 never)
   bool sorted_chained_forced = false;
-  bool sorted_wide = true;   // HMJ_SORTED_WIDE=0: ordered foreign-key joins are never planned for the 6144-row shape
   bool sorted_half = true;   // HMJ_SORTED_HALF=0: the foreign-key form never takes its two-workgroups-per-CU shape
   int fk_plan = 0;           // HMJ_FK_PLAN: 0 automatic, 1 wide (6144-row shape), 2 half (3072-row shape, two workgroups per CU), 3 narrow (5120 rows)
-  bool sorted_fk = false;  // the last ordered join's probe keys repeated: start with the foreign-key form of the kernel
-  int sorted_fk_age = 0;
   u64 probe_hint = 0;
   // small build sides: one global hash table, probe side streamed unpartitioned (gtable.hip, count modes).  Measured
   // (tools/exp_gtable.py, profiles/r04b_*; 2^26 probe rows, ms per join, partitioned path -> global table): build rows
@@ -99,24 +128,19 @@ struct hmj_ctx {
   int gtable_wg_per_cu = 8;        // probe grid (HMJ_GTABLE_WG)
   u32 gtable_slots_per_row = 16;   // table slots per build row (HMJ_GTABLE_SLOTS) ...
   int gtable_max_log_cap = 18;     // ... while the table has at most 2^this slots; beyond, down to 4 per row (HMJ_GTABLE_MAX_LOG_CAP)
-  int gtable_cooldown = 0;         // joins to skip it for after it gave up
   bool ltable_mode = true;         // build sides <= 4096 rows, count modes: the table in LDS, one copy per workgroup (HMJ_LTABLE=0: the L2-resident table)
   bool gtable_sort_mode = true;    // HMJ_GTABLE_SORT=0: ordered joins of a small build side under a long probe side stay partitioned
   u32 gtable_sort_fanout = 128;    // ... from this many probe rows per build row on (HMJ_GTABLE_SORT_FANOUT)
-  int gtable_sort_cooldown = 0;
+  bool rank_runs_mode = true;      // ordered, small build side, fan-out 16 ... ~1700: partition by rank, sort every rank's run in LDS (HMJ_RANK_RUNS=0: composites)
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
-  int gtable_sort_slab_cooldown = 0;
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)
   u32 fk_payload_buckets = 24;     // the one-pass ordered foreign-key write ranks inside (build rank, payload position) buckets from this fan-out on (HMJ_FK_PAYLOAD_BUCKETS; 0: never)
   u32 expand_fk_fanout = 0;        // ordered foreign-key joins (unique build keys) take the expansion from this fan-out on (HMJ_EXPAND_FK_FANOUT; 0: never)
-  int expand_cooldown = 0;
   bool expand_allow_rebits = true;  // (false during the retry that already took one more bit)
   int expand_rebits = 0;            // the bits that retry plans         // ordered joins to keep on write + sort after a partition did not fit the expansion kernel
   bool sort_slab = true;           // hmj_sort_u64_device: LSD passes as a chain of slab passes + one compaction (HMJ_SORT_SLAB=0: exact passes)
   u64 sort_slab_min = 1ull << 25;  // ... from this many rows on (HMJ_SORT_SLAB_MIN_LOG2)
-  int sort_slab_cooldown = 0;      // sorts to keep on the exact passes after a slab of the chain overflowed (skewed digits)  // joins to keep on the exact passes after a slab of the chain overflowed (skewed digits)
-  int gtable_write_cooldown = 0;   // materialising joins to skip it for after one met duplicate build keys
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)
   bool staged_upload = false;  // HMJ_UPLOAD=staged
   bool host_pipeline = true;   // HMJ_HOST_PIPELINE=0: host entry points upload, join and download one after the other
@@ -129,13 +153,8 @@ struct hmj_ctx {
                                  // kernels got faster; round 3's size sweep, tools/exp_cliffs.py, count mode, exact vs slab:
                                  // 2.7 M rows 0.295 vs 0.251 ms, 2^22 0.359 vs 0.304, 2^24 0.827 vs 0.651, 28.5 M 1.345 vs
                                  // 0.970; ordered and materialising joins alike.)  HMJ_SLAB_MIN_LOG2 overrides (tests).
-  int slab_cooldown = 0;  // joins to skip the slab path for after it overflowed (skewed keys)
-  int exact_prefix_joins = 0;  // ordered joins that still take the shared key prefix from a pass over ALL keys: the
-                               // sample of an earlier join missed a few keys above an otherwise dense range
   u32 slab_probe_kb = 0;  // HMJ_SLAB_PROBE_KB: pieces per partition of the probe-side slabs (0 = 512 >> bits of pass A)
   bool one_pass_slab = true;  // HMJ_ONE_PASS_SLAB=0: count joins of a one-pass plan never leave the probe side in pass-A slabs
-  int one_pass_write_cooldown = 0;  // materialising joins to keep off the one-pass slab path after one met duplicate build keys there
-  int slab_probe_cooldown = 0;  // the same for the probe-side-only slab partitioning of probe-heavy count joins
   int scatter_variant = 1;  // 1 = write-combining scatter (default), 0 = plain (HMJ_SCATTER=plain)
   bool profiling = false;
   bool trace = false;  // HMJ_TRACE=1: one stderr line per join attempt (plan, paths taken, why an attempt was retried)
@@ -155,6 +174,9 @@ struct hmj_ctx {
   std::vector<u64> arrive_rows;
   std::vector<hipEvent_t> arrive_ev;
   bool sample_build_only = false;  // the key sample must not read the probe side (it is still arriving)
+  // How the join waits for arrive_ev[i].  nullptr (host pipeline): a device-side wait queued on the ctx stream.  Set by
+  // exchange.hip during a step with a deadline: a host wait that gives up (HMJ_E_TIMEOUT) when a peer never sends.
+  int (*arrive_wait)(hmj_ctx*, hipEvent_t) = nullptr;
 };
 
 
@@ -177,4 +199,9 @@ int radix_pass(hmj_ctx* c, const void* src, void* dst, hmj::u32 n, int shift, in
 // partition the build side only (hmj_prepare_build_u64_device without the API prologue)
 int prepare_build(hmj_ctx* c, const void* R, uint64_t n_build, uint64_t n_probe_hint);
 void comm_destroy(hmj_ctx* c);  // exchange.hip: called by hmj_destroy
+// probe rows [.., arrive_rows[i]) are complete after this (device-side wait, or hmj_ctx::arrive_wait on the host)
+int wait_arrival(hmj_ctx* c, hipEvent_t ev);
+// the signature adaptive state is keyed by, and the memo of that workload (created on first use)
+uint64_t workload_signature(uint64_t n_build, uint64_t n_probe, uint32_t flags, int kind);
+WorkloadMemo* memo_for(hmj_ctx* c, uint64_t sig);
 }  // namespace hmj_host

@@ -157,6 +157,13 @@ hipError_t launch_sval_range(const void* S, u32 np, u64* out2 /* {min, max}; cal
 hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,
                               void* pairs, bool extra, bool wide, int num_cus, int wg_per_cu, hipStream_t st);
 hipError_t launch_gtable_swap(const void* in, void* out, u64 n, int num_cus, hipStream_t st);
+// the rank-run form: {rank, sval} rows, partitioned by rank with two slab passes, every rank's run sorted in LDS and written
+hipError_t launch_gtable_emit_ranks(const void* S, u32 np, const void* tab, int log_cap, u64* accum, void* pairs, bool extra, int num_cus,
+                                    int wg_per_cu, hipStream_t st);
+int rank_sort_max_run();
+hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb,
+                                  u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st);
+hipError_t launch_scan_chunked_u64(const u64* in, u64* off /* n + 1 */, u32 n, hipStream_t st);
 hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u64 svmin, int range_bits, u64* out_key,
                                 u64* out_rval, u64* out_sval, u64* accum, bool extra, bool wide, int num_cus, hipStream_t st);
 // Sorted composites that lie in the worker-private slabs of a chain of slab passes (piece i = rows [i * cap, + cnt[i]); the

@@ -1378,7 +1378,21 @@ __global__ __launch_bounds__(256) void key_exact_kernel(const Tup* __restrict__ 
     mn = a2 < mn ? a2 : mn;
     mx = b2 > mx ? b2 : mx;
   }
+  // one set of atomics per WORKGROUP (same-address atomics cost ~11 ns each wherever they come from: a set per wave of a
+  // 2048-workgroup grid was 0.2 ms for a 2^16-row build side, profiles/r05a_small16_ord_summary.txt)
+  __shared__ u64 wx[4], wmn[4], wmx[4];
   if ((threadIdx.x & 63) == 0) {
+    wx[threadIdx.x >> 6] = x;
+    wmn[threadIdx.x >> 6] = mn;
+    wmx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      x |= wx[w];
+      mn = wmn[w] < mn ? wmn[w] : mn;
+      mx = wmx[w] > mx ? wmx[w] : mx;
+    }
     if (x) atomicOr(reinterpret_cast<unsigned long long*>(out), (unsigned long long)x);
     if (nb) {
       atomicMin(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)mn);
@@ -1389,7 +1403,10 @@ __global__ __launch_bounds__(256) void key_exact_kernel(const Tup* __restrict__ 
 
 hipError_t launch_key_exact(const void* R, u32 nb, const void* S, u32 np, u64 ref, u64* out, int num_cus, hipStream_t st,
                             bool ref_is_first_key) {
-  hipLaunchKernelGGL(key_exact_kernel, dim3(num_cus * 8), dim3(256), 0, st, static_cast<const Tup*>(R), nb,
+  u64 grid = ((u64)nb + np + 1023) / 1024;  // (a workgroup per 1024 rows at most)
+  if (grid > (u64)num_cus * 8) grid = (u64)num_cus * 8;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(key_exact_kernel, dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(R), nb,
                      static_cast<const Tup*>(S), np, ref, ref_is_first_key, out);
   return hipGetLastError();
 }

@@ -111,8 +111,11 @@ class GroupTransport:
     library passes are device memory and are staged through host tensors (rehearsal of several ranks on one GPU,
     where RCCL refuses duplicate devices); device=False: host pointers (CPU tests of the exchange plan)."""
 
-    def __init__(self, group=None, device=True):
+    def __init__(self, group=None, device=True, timeout_s=None):
         self.group, self.device = group, device
+        # every wait on a peer is bounded by this (hmj_comm_set_timeout_ms tells the library the same number): a peer
+        # that never takes part makes the callback return HMJ_E_TIMEOUT instead of blocking for ever
+        self.timeout_s = timeout_s
         self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.hip = _hip() if device else None
         self.rounds_seen = 0
@@ -126,12 +129,34 @@ class GroupTransport:
         try:
             mine = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).view(np.int64).copy())
             outs = [torch.empty(count, dtype=torch.int64) for _ in range(self.n_ranks)]
-            dist.all_gather(outs, mine, group=self.group)
+            work = dist.all_gather(outs, mine, group=self.group, async_op=True)
+            if not self._wait([work]):
+                return _lib.HMJ_E_TIMEOUT
             np.ctypeslib.as_array(recv, shape=(count * self.n_ranks,))[:] = torch.cat(outs).numpy().view(np.uint64)
             return 0
         except Exception as e:  # an exception must not unwind through the C frames
             print("GroupTransport.allgather failed:", repr(e), flush=True)
             return 1
+
+    def _wait(self, works):
+        """Wait for all of `works` under one deadline; False = it passed (the peers never showed up)."""
+        import datetime
+        import time
+
+        if not self.timeout_s:
+            for w in works:
+                w.wait()
+            return True
+        until = time.monotonic() + self.timeout_s
+        for w in works:
+            left = until - time.monotonic()
+            try:
+                if left <= 0 or not w.wait(datetime.timedelta(seconds=max(left, 0.001))):
+                    raise RuntimeError("timed out")
+            except RuntimeError as e:
+                print("GroupTransport rank %d: gave up waiting for a peer after %.1f s (%s)" % (self.rank, self.timeout_s, str(e)[:80]), flush=True)
+                return False
+        return True
 
     def _copy(self, dst, src, nbytes, kind):
         if self.device:
@@ -161,8 +186,8 @@ class GroupTransport:
                 if rb[g]:
                     outs[g] = torch.empty(rb[g], dtype=torch.uint8)
                     reqs.append(dist.irecv(outs[g], src=self._peer(g), group=self.group))
-            for q in reqs:
-                q.wait()
+            if not self._wait(reqs):
+                return _lib.HMJ_E_TIMEOUT
             for g, t in outs.items():
                 self._copy(rp[g], t.data_ptr(), rb[g], 1)  # host to device
             return 0
@@ -181,10 +206,12 @@ def new_unique_id():
     return bytes(buf)
 
 
-def init_comm(ex, group=None, force_transport=None):
+def init_comm(ex, group=None, force_transport=None, timeout_s=120.0):
     """Give `ex` (an Executor) the communicator of a torch.distributed group.  backend nccl -> RCCL inside the
     library (its own communicator over xGMI; torch's group only carries the 128-byte id); anything else -> the
-    callback transport over the group.  force_transport: "rccl" | "group"."""
+    callback transport over the group.  force_transport: "rccl" | "group".
+    timeout_s: the deadline of one exchange step (hmj_comm_set_timeout_ms; None / 0 = wait for ever): a step that a
+    peer never joins returns HMJ_E_TIMEOUT on every other rank instead of blocking."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     kind = force_transport or ("rccl" if dist.get_backend(group) == "nccl" else "group")
     if kind == "rccl":
@@ -197,15 +224,18 @@ def init_comm(ex, group=None, force_transport=None):
             dist.broadcast(t, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
         ex.comm_init_rccl(world, rank, bytes(t.cpu().numpy().tobytes()))
     else:
-        ex.comm_set_transport(GroupTransport(group, device=True))
+        ex.comm_set_transport(GroupTransport(group, device=True, timeout_s=timeout_s))
+    ex.comm_set_timeout_ms(int((timeout_s or 0) * 1000))
     return kind
 
 
-def init_comm_single(ex, self_exchange=True):
+def init_comm_single(ex, self_exchange=True, timeout_s=None):
     """One rank, RCCL transport.  self_exchange=True: the whole exchange path with self send/recv (tests,
     HMJ_FORCE_DIST); False: what a one-rank job does by default -- the plain local join, nothing crosses RCCL."""
     ex.comm_init_rccl(1, 0, new_unique_id())
     ex.comm_set_self_exchange(self_exchange)
+    if timeout_s is not None:
+        ex.comm_set_timeout_ms(int(timeout_s * 1000))
 
 
 def distributed_join(ex, r_shard, s_shard, flags=0):

@@ -97,6 +97,17 @@ class Executor:
         self._check(self.L.hmj_last_timing(self.h, C.byref(t)))
         return t.as_dict()
 
+    def last_plan(self):
+        """hmj_last_plan: path, bits per pass, attempts, why faster formulations were refused, what the workload is
+        skipping from now on (dict of hmj_plan_desc's fields)."""
+        p = _lib.PlanDesc()
+        p.struct_size = C.sizeof(_lib.PlanDesc)
+        self._check(self.L.hmj_last_plan(self.h, C.byref(p)))
+        return p.as_dict()
+
+    def forget_workloads(self):
+        self._check(self.L.hmj_forget_workloads(self.h))
+
     def placement_info(self):
         """One dict per big partition buffer this executor probed (hmj_placement_info; empty with HMJ_PLACE=0):
         name, bytes, fill rate of the allocation kept, candidates tried, whether a search ran (hmj_reserve or
@@ -180,6 +191,16 @@ class Executor:
         """Non-ordered distributed joins: digit-range owners with per-round joins (default) or, split=True, round 2's
         hash owner with its separate owner split and one local join (hmj_comm_set_owner_path)."""
         self._check(self.L.hmj_comm_set_owner_path(self.h, 1 if split else 0))
+
+    def comm_set_timeout_ms(self, timeout_ms):
+        """Deadline of one exchange step (hmj_comm_set_timeout_ms; 0 = wait for ever): past it the step returns
+        HMJ_E_TIMEOUT and the communicator is unusable."""
+        self._check(self.L.hmj_comm_set_timeout_ms(self.h, int(timeout_ms)))
+
+    def comm_get_timeout_ms(self):
+        v = C.c_uint64(0)
+        self._check(self.L.hmj_comm_get_timeout_ms(self.h, C.byref(v)))
+        return int(v.value)
 
     def comm_set_message_bytes(self, max_message_bytes=0, probe_round_bytes=0):
         self._check(self.L.hmj_comm_set_message_bytes(self.h, max_message_bytes, probe_round_bytes))

@@ -44,6 +44,8 @@ typedef struct hmj_ctx hmj_ctx;
 
 #define HMJ_E_RCCL (-6)        /* RCCL (or the host's transport callbacks) failed, or librccl is absent  */
 #define HMJ_E_PEER (-7)        /* a collective call failed on ANOTHER rank; every rank returns together   */
+#define HMJ_E_TIMEOUT (-8)     /* a step of the exchange made no progress within hmj_comm_set_timeout_ms: a peer */
+                               /* never took part (or died).  The communicator is unusable: hmj_comm_destroy it   */
 
 /* flags for hmj_join_* */
 #define HMJ_MATERIALIZE 0x01u /* produce the (key, rval, sval) columns; else count/sums only --   */
@@ -121,10 +123,62 @@ typedef struct {
 #define HMJ_PATH_PRESORTED 0x40000u /* a relation arrived already partitioned (sorted by key): its radix passes were skipped */
 #define HMJ_PATH_SLAB_ONE_PASS 0x80000u /* ... of a ONE-pass plan: the probe kernel reads the pass's worker-private slabs directly */
 #define HMJ_PATH_ORDER_BY_RANK_SORT 0x200000u /* ordered, small build side under a long probe side: rows sorted as (key rank, payload) composites */
+#define HMJ_PATH_RANK_RUNS 0x1000000u /* ... where every key's run of probe rows fits one workgroup: rows partitioned by key rank (two slab passes), each run sorted in LDS */
 #define HMJ_PATH_ORDERED_EXPANSION 0x400000u /* ordered, duplicate build keys: rows written in order partition by partition (no sort of result rows) */
 #define HMJ_PATH_LDS_TABLE 0x800000u /* ... of <= 4096 build rows, count modes: that table in LDS, one copy per workgroup */
 #define HMJ_PATH_GLOBAL_TABLE 0x100000u /* small build side: one global hash table, the probe side streamed unpartitioned */
 #define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
+
+/* How the last join on this ctx was planned, and why (hmj_last_plan).  The planner chooses among the formulations listed
+ * at hmj_join_u64_device from the sizes, the flags, a key sample and what EARLIER JOINS OF THE SAME WORKLOAD taught it:
+ * a fast path that gives up (a slab overflowed on skewed keys, the unique-key write met duplicate build keys, the global
+ * table's walk got too long) is retried on the general path within the same join and then skipped for the next 8 (64)
+ * joins of that workload.  A workload = floor(log2) of both sizes + the mode flags (materialise / ordered / first-wins);
+ * joins of other shapes on the same ctx are not affected (round 5; until then the cool-downs belonged to the ctx).
+ * Tests assert on these fields instead of pinning paths through the environment.  Nothing in the reference corresponds
+ * (its one plan is optimal_partition, radix_hash.h:38-57).                                                         */
+typedef struct {
+  uint32_t struct_size;   /* bytes the library filled in (callers built against an older header get a prefix)      */
+  uint32_t path;          /* HMJ_PATH_* of the attempt that produced the result (= hmj_timing.path)                */
+  int32_t radix_bits, radix_passes, pass_bits[4];
+  int32_t key_prefix_bits, key_window_low;
+  uint32_t n_partitions;  /* 2^radix_bits, or 0 where nothing was partitioned (global / LDS table)                 */
+  uint32_t probe_items;   /* work items of the probe phase ((virtual) partitions x probe slices)                   */
+  uint32_t attempts;      /* plans executed for this join (1 = the first plan held)                                */
+  uint32_t refused;       /* HMJ_REFUSED_*: faster formulations not taken by this join, and why                    */
+  uint32_t cooling;       /* HMJ_COOL_*: fast paths this WORKLOAD is skipping after this join (0 = nothing learnt) */
+  uint64_t workload;      /* the signature the adaptive state is keyed by                                          */
+} hmj_plan_desc;
+#define HMJ_REFUSED_GTABLE_SHAPE 0x0001u        /* global table: build side / flags / sizes outside its window          */
+#define HMJ_REFUSED_GTABLE_COOLING 0x0002u      /* ... skipped: an earlier join of this workload gave up on it          */
+#define HMJ_REFUSED_GTABLE_GAVE_UP 0x0004u      /* ... tried by THIS join and abandoned (duplicate keys, long walks)     */
+#define HMJ_REFUSED_RANK_SORT_MODEL 0x0008u     /* ordered small build side: the cost model preferred partitioning       */
+#define HMJ_REFUSED_RANK_SORT_COOLING 0x0010u
+#define HMJ_REFUSED_RANK_SORT_GAVE_UP 0x0020u
+#define HMJ_REFUSED_SLAB_SHAPE 0x0040u          /* slab partitioning: not a two-pass plan of <= 9-bit passes, sizes below */
+                                                /* the threshold, or probe partitions beyond the pipelined kernels        */
+#define HMJ_REFUSED_SLAB_COOLING 0x0080u
+#define HMJ_REFUSED_SLAB_SORTED_INPUT 0x0100u   /* the sample found a relation in key order (its digits are not mixed)   */
+#define HMJ_REFUSED_SLAB_OVERFLOW 0x0200u       /* tried by this join: a slab overflowed (skewed digits), exact passes    */
+#define HMJ_REFUSED_FAST_WRITE_COOLING 0x0400u  /* unique-key write mode skipped: duplicate build keys seen earlier       */
+#define HMJ_REFUSED_FAST_WRITE_GAVE_UP 0x0800u  /* ... tried by this join: duplicate build keys / an oversized partition  */
+#define HMJ_REFUSED_SLAB_PROBE_COOLING 0x1000u  /* probe-side-only slabs / one-pass slab walk skipped                     */
+#define HMJ_REFUSED_SLAB_PROBE_OVERFLOW 0x2000u
+#define HMJ_REFUSED_PREFIX_VIOLATED 0x4000u     /* a row outside the sampled key prefix: the join re-planned              */
+#define HMJ_REFUSED_EXPANSION_GAVE_UP 0x8000u   /* ordered expansion: a partition beyond the kernel's capacity            */
+#define HMJ_COOL_UNIQ_WRITE 0x001u
+#define HMJ_COOL_SORTED_WRITE 0x002u
+#define HMJ_COOL_GTABLE 0x004u
+#define HMJ_COOL_GTABLE_WRITE 0x008u
+#define HMJ_COOL_RANK_SORT 0x010u
+#define HMJ_COOL_RANK_SORT_SLAB 0x020u
+#define HMJ_COOL_EXPANSION 0x040u
+#define HMJ_COOL_SORT_SLAB 0x080u
+#define HMJ_COOL_SLAB 0x100u
+#define HMJ_COOL_SLAB_PROBE 0x200u
+#define HMJ_COOL_ONE_PASS_WRITE 0x400u
+#define HMJ_COOL_EXACT_PREFIX 0x800u
+#define HMJ_COOL_RANK_RUNS 0x1000u
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* Replaces: nothing in the reference (no device); one ctx per GPU. device_id < 0 = current.     */
@@ -184,6 +238,10 @@ typedef struct {
   float cand_TBps[HMJ_PLACE_MAX_CAND];     /* per candidate: fill rate                                           */
 } hmj_place_info;
 int hmj_placement_info(hmj_ctx* ctx, hmj_place_info* out, int max_entries);
+/* out->struct_size must hold sizeof(hmj_plan_desc) of the CALLER's header on entry; at most that many bytes are written. */
+int hmj_last_plan(hmj_ctx* ctx, hmj_plan_desc* out);
+/* Forget what the ctx has learnt about every workload (all cool-downs, the ordered kernels' adaptive forms).          */
+int hmj_forget_workloads(hmj_ctx* ctx);
 int hmj_set_profiling(hmj_ctx* ctx, int enabled);
 int hmj_last_timing(hmj_ctx* ctx, hmj_timing* out);
 const char* hmj_strerror(int code);
@@ -265,7 +323,9 @@ int hmj_comm_init_rank(hmj_ctx* ctx, int n_ranks, int rank, const void* id128);
 typedef struct hmj_transport {
   void* user;
   int n_ranks, rank;
-  /* every rank contributes `count` values; recv[r * count + i] = rank r's send[i].  Host memory, blocking.  */
+  /* both callbacks return 0 = ok, HMJ_E_TIMEOUT = gave up waiting for a peer (the step then returns HMJ_E_TIMEOUT and
+   * the communicator is marked unusable), anything else = failed (HMJ_E_RCCL).
+   * every rank contributes `count` values; recv[r * count + i] = rank r's send[i].  Host memory, blocking.  */
   int (*allgather_u64)(void* user, const uint64_t* send, uint64_t* recv, int count);
   /* one round of the all-to-all-v on DEVICE memory: send send_bytes[g] bytes at send_ptrs[g] to rank g and
    * receive recv_bytes[g] bytes from it into recv_ptrs[g] (g == own rank: a local copy).  hip_stream
@@ -281,6 +341,20 @@ int hmj_comm_destroy(hmj_ctx* ctx); /* also done by hmj_destroy */
  * probe_round_bytes: target size of a probe-side message (default 128 MiB): the probe side travels in several
  * rounds so that the local partitioning starts on the rows that have arrived.                              */
 int hmj_comm_set_message_bytes(hmj_ctx* ctx, uint64_t max_message_bytes, uint64_t probe_round_bytes);
+/* The deadline of ONE hmj_exchange_join_u64_device call, in milliseconds from its start (default 120 000, or
+ * HMJ_COMM_TIMEOUT_MS in the environment when the communicator is created; 0 = wait for ever).  The reference's
+ * workers all return from the one call that started them (hashjoin.h:56-68 -> radix_hash.h:375-405: pthread_join);
+ * ranks in different processes can lose a peer, so every wait of a step that depends on another rank -- the
+ * all-gathers, the build side's rounds, each probe round -- is a host-side poll (hipEventQuery / hipStreamQuery +
+ * ncclCommGetAsyncError) under this deadline, and a watchdog thread covers a host blocked inside RCCL itself (it calls
+ * ncclCommAbort, which is what makes such a call return).  When the deadline passes the call returns HMJ_E_TIMEOUT, and
+ * so does every later step on this communicator: hmj_comm_destroy it (that is where a communicator whose stream is still
+ * busy is aborted -- RCCL's kernels leave their wait loops, the stream drains -- instead of destroyed) and make a new one
+ * (all ranks).  Each rank notices on its own -- there is nobody left to tell
+ * it -- so a step ends everywhere within the deadline plus about a second.  Callback transports must bound their own
+ * waits by the same number (hmj_comm_get_timeout_ms) and return HMJ_E_TIMEOUT from the callback.  Not during a step. */
+int hmj_comm_set_timeout_ms(hmj_ctx* ctx, uint64_t timeout_ms);
+int hmj_comm_get_timeout_ms(hmj_ctx* ctx, uint64_t* timeout_ms);
 
 /* The distributed join.  Replaces the HashMergeJoin ctor + iteration (hashjoin.h:56-68, :183-191) for
  * relations sharded by rows over the ranks.  The radix fan-out itself is the owner (round 3): every rank runs the

@@ -390,6 +390,15 @@ class Reference:
         return {"n": cnt, "sum": int(sm.value), "pairs": pairs[:cnt], "fnv_r": int(fnv[0]), "fnv_s": int(fnv[1]),
                 "distinct": int(dist.value)}
 
+    def hashmergejoin_strgen_timed(self, words_path, n, threads, reps=3, seed_r=1, seed_s=2):
+        """ref_hashmergejoin_strgen_timed: best seconds of construct + iterate over two create_strvec(n) relations (generation
+        outside the clock, as hashjoin_bench.cc:115-134) and (count, sum, ordered FNV of the pairs)."""
+        out3 = (C.c_uint64 * 3)()
+        self.lib.ref_hashmergejoin_strgen_timed.restype = C.c_double
+        self.lib.ref_hashmergejoin_strgen_timed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_int, _U64P]
+        sec = float(self.lib.ref_hashmergejoin_strgen_timed(words_path.encode(), n, seed_r, seed_s, threads, reps, out3))
+        return sec, (int(out3[0]), int(out3[1]), int(out3[2]))
+
     # opaque PairVec handles so a timed region excludes the AoS->vector conversion
     def pairs_new(self, aos):
         aos = _u64(aos).reshape(-1, 2)

@@ -14,6 +14,7 @@
 // (SURVEY.md D4 / H6).  std::tuple is stored in reverse order by libstdc++, so
 // tuples are always (un)packed with std::get, never memcpy'd.
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <tuple>
@@ -313,6 +314,41 @@ uint64_t ref_hashmergejoin_strgen(const char* words_path, uint64_t n, uint64_t s
   }
   if (sum_out) *sum_out = sum;
   return cnt;
+}
+
+// The same join TIMED as hashjoin_bench.cc:120-134 times it (BM_HashMergeJoin): relations generated before the clock
+// starts (the benchmark pauses its timer for create_strvec), then `reps` x (construct + iterate + reduce), best time
+// returned in seconds; count / sum / ordered FNV of the (rval, sval) pairs of the last repetition in out3[0..2].
+// bench.py's cpu_baseline leg: BASELINE.json configs[0] next to the GPU drop-in on the same relations.
+double ref_hashmergejoin_strgen_timed(const char* words_path, uint64_t n, uint64_t seed_r, uint64_t seed_s, unsigned threads,
+                                      int reps, uint64_t* out3) {
+  const std::vector<std::string> words = hmj_strgen::load_words(words_path);
+  if (words.empty()) return -1.0;
+  KeyValVec r = hmj_strgen::create_strvec((int)n, words, seed_r), s = hmj_strgen::create_strvec((int)n, words, seed_s);
+  double best = 1e30;
+  for (int it = 0; it < reps; it++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HashMergeJoin<KeyValVec::iterator, KeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), threads);
+    uint64_t cnt = 0, sum = 0, fnv = 0xCBF29CE484222325ull;
+    for (auto t : hmj) {
+      const uint64_t w[2] = {*std::get<1>(t), *std::get<2>(t)};
+      sum += w[0] + w[1];
+      cnt++;
+      for (int q = 0; q < 2; q++)
+        for (int b = 0; b < 8; b++) {
+          fnv ^= (w[q] >> (8 * b)) & 0xFF;
+          fnv *= 0x100000001B3ull;
+        }
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (sec < best) best = sec;
+    if (out3) {
+      out3[0] = cnt;
+      out3[1] = sum;
+      out3[2] = fnv;
+    }
+  }
+  return best;
 }
 
 }  // extern "C"

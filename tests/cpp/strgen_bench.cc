@@ -1,0 +1,73 @@
+// BASELINE.json configs[0]: the reference's own benchmark relations -- r = create_strvec(n), s = create_strvec(n),
+// std::string keys (hashjoin_bench.cc:109-143; strgen.cc:27-61 restated in oracle/strgen_restated.h over the word-list
+// fixture) -- through the C++ drop-in, timed as BM_HashMergeJoin times them: construct the join, iterate it, reduce
+// (hashjoin_bench.cc:126-133).  Relation generation is outside the clock (the reference pauses its timer for it, :115-119).
+// The route: std::hash<std::string> of every row on the host, {hash, row} pairs to the GPU, the u64 join there, hash
+// collisions resolved on the host by comparing the strings, iteration over the caller's relations.
+// Prints ONE JSON line: count / sum / ordered FNV of the pairs (= tests/golden "strgen_join", the compiled reference's own
+// output on the same relations) and the times.  Test infrastructure: bench.py runs it for `extra.configs0_strgen_1M_ms`.
+// Usage: strgen_bench <words.txt> [n = 1000000] [reps = 5]
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "hashmergejoin_hip.hpp"
+#include "strgen_restated.h"
+
+typedef std::vector<std::pair<std::string, uint64_t>> StrKeyValVec;
+
+int main(int argc, char** argv) {
+  const char* words_path = argc > 1 ? argv[1] : "tests/golden/words.txt";
+  const int n = argc > 2 ? atoi(argv[2]) : 1000000, reps = argc > 3 ? atoi(argv[3]) : 5;
+  const std::vector<std::string> words = hmj_strgen::load_words(words_path);
+  if (words.empty() || n < 1) {
+    std::printf("{\"error\": \"no words in %s\"}\n", words_path);
+    return 2;
+  }
+  StrKeyValVec r = hmj_strgen::create_strvec(n, words, 1), s = hmj_strgen::create_strvec(n, words, 2);
+  const unsigned threads = std::thread::hardware_concurrency();
+  double best = 1e30, best_ctor = 0, best_iter = 0, first = 0;
+  uint64_t cnt = 0, sum = 0, fnv = 0;
+  typedef HashMergeJoin<StrKeyValVec::iterator, StrKeyValVec::iterator> Join;
+  Join hmj;
+  for (int it = 0; it <= reps; it++) {  // (iteration 0 creates the context and its workspace: reported apart)
+    hmj.clear();
+    const auto t0 = std::chrono::steady_clock::now();
+    hmj = Join(r.begin(), r.end(), s.begin(), s.end(), threads);
+    const auto t1 = std::chrono::steady_clock::now();
+    cnt = sum = 0;
+    fnv = 0xCBF29CE484222325ull;
+    for (auto tuple : hmj) {
+      const uint64_t rv = *std::get<1>(tuple), sv = *std::get<2>(tuple);
+      sum += rv + sv;
+      cnt++;
+      const uint64_t w[2] = {rv, sv};
+      for (int q = 0; q < 2; q++)
+        for (int b = 0; b < 8; b++) {
+          fnv ^= (w[q] >> (8 * b)) & 0xFF;
+          fnv *= 0x100000001B3ull;
+        }
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t2 - t0).count();
+    if (it == 0) {
+      first = ms;
+      continue;
+    }
+    if (ms < best) {
+      best = ms;
+      best_ctor = std::chrono::duration<double, std::milli>(t1 - t0).count();
+      best_iter = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    }
+  }
+  std::printf("{\"n\": %d, \"count\": %llu, \"sum\": %llu, \"fnv\": %llu, \"ms\": %.3f, \"ms_ctor\": %.3f, \"ms_iterate\": %.3f, "
+              "\"ms_first_call\": %.3f, \"host_threads\": %u, \"reps\": %d, \"fnv_r\": %llu, \"fnv_s\": %llu}\n",
+              n, (unsigned long long)cnt, (unsigned long long)sum, (unsigned long long)fnv, best, best_ctor, best_iter, first, threads, reps,
+              (unsigned long long)hmj_strgen::fnv_relation(r), (unsigned long long)hmj_strgen::fnv_relation(s));
+  return 0;
+}

@@ -360,3 +360,132 @@ def test_bench_launches_its_own_ranks():
     assert 0 <= x["exposed"] <= x["total"] + 1e-3
     assert d["probe_phase"]["probe_tuples_per_s_all_ranks"] > 0 and 0 < d["probe_phase"]["per_gpu"]["frac"] < 1
     assert "roofline" in d and "placement" in d
+
+
+# ---- a step cannot hang: deadline inside the library, wall-clock limit in bench.py ------------------------
+STALL_WORKER = r"""
+import os, sys, json, time
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["HMJ_ROOT"])
+import hashmergejoin_amd as H
+from hashmergejoin_amd import dist as hdist
+from hashmergejoin_amd._lib import HmjError
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ex = H.Executor(0)
+hdist.init_comm(ex, timeout_s=float(os.environ["STEP_TIMEOUT_S"]))
+assert ex.comm_get_timeout_ms() == int(float(os.environ["STEP_TIMEOUT_S"]) * 1000)
+n = 200000
+bd, pd = ex.gen_build(n, start=rank * n), ex.gen_probe(n, world * n, start=rank * n)
+loc, glob = ex.exchange_join(bd, pd, 0)          # step 0: everybody takes part
+assert int(glob.n_matches) == world * n
+rec = {"codes": [0], "secs": []}
+if rank == 1:                                    # step 1: this rank never enters it
+    time.sleep(float(os.environ["STALL_S"]))
+    json.dump(rec, open(os.path.join(os.environ["OUT"], "stall%d.json" % rank), "w"))
+    os._exit(3)
+for _ in range(2):                               # the others: the step times out; the communicator is unusable afterwards
+    t0 = time.time()
+    try:
+        ex.exchange_join(bd, pd, 0)
+        rec["codes"].append(0)
+    except HmjError as e:
+        rec["codes"].append(e.code)
+        rec["msg"] = str(e)
+    rec["secs"].append(time.time() - t0)
+# the local join of the same context still works: only the communicator is gone
+rec["local_matches"] = int(ex.join_device(bd, ex.gen_probe(n, n, start=0), 0).n_matches) if rank == 0 else None
+json.dump(rec, open(os.path.join(os.environ["OUT"], "stall%d.json" % rank), "w"))
+ex.close()                                       # (tears the aborted communicator down without blocking)
+os._exit(5)
+"""
+
+
+def test_a_rank_that_never_enters_a_step_times_the_others_out(tmp_path):
+    # the reference's workers all return from the call that started them (hashjoin.h:56-68 -> radix_hash.h:375-405); ranks in
+    # different processes can lose a peer: every other rank must come back with HMJ_E_TIMEOUT within the deadline, and
+    # every process must end (non-zero) instead of waiting in a collective for ever
+    import time
+
+    world, port, step_timeout = 3, free_port(), 4.0
+    procs, t0 = [], time.time()
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HMJ_ROOT=ROOT,
+                   OUT=str(tmp_path), OMP_NUM_THREADS="1", STEP_TIMEOUT_S=str(step_timeout), STALL_S="20")
+        procs.append(subprocess.Popen([sys.executable, "-c", STALL_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert [p.returncode for p in procs] == [5, 3, 5], "\n".join(outs)
+    for r in (0, 2):
+        rec = json.load(open(tmp_path / ("stall%d.json" % r)))
+        assert rec["codes"] == [0, -8, -8], (rec, outs[r])       # HMJ_E_TIMEOUT, then "communicator unusable"
+        assert rec["secs"][0] < step_timeout + 6 and rec["secs"][1] < 1.0, rec
+        assert "no progress within 4000 ms" in rec["msg"] or "unusable" in rec["msg"] or "aborted" in rec["msg"], rec
+    assert json.load(open(tmp_path / "stall0.json"))["local_matches"] == 200000
+    assert time.time() - t0 < 120
+
+
+def test_bench_rehearsal_ends_in_bounded_time_when_a_rank_is_killed_mid_run():
+    # `python bench.py --gpus 2` on this one-GPU box (gloo callbacks); rank 1 is killed before its third step: rank 0's step
+    # times out inside the library, rank 0 prints the error line, the launcher relays it and returns non-zero
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HMJ_BENCH_FAULT"] = "kill:1:2"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "22", "--steps", "3", "--warmup", "1",
+                        "--step-timeout-s", "5", "--timeout-s", "200"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    dt = time.time() - t0
+    assert p.returncode != 0 and dt < 150, (p.returncode, dt, p.stderr.decode()[-2000:])
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "error" in d, d
+    assert "exchange step" in d["error"] or "rank(s) 1 failed" in d["error"], d
+
+
+LOST_SEND_WORKER = r"""
+import os, sys, json, time
+import torch
+sys.path.insert(0, os.environ["HMJ_ROOT"])
+import hashmergejoin_amd as H
+from hashmergejoin_amd import dist as hdist
+from hashmergejoin_amd._lib import HmjError
+
+ex = H.Executor(0)
+hdist.init_comm_single(ex, timeout_s=3.0)        # one rank, RCCL transport, the whole exchange path
+n = 1 << 22
+bd, pd = ex.gen_build(n), ex.gen_probe(n, n)
+rec = {}
+t0 = time.time()
+try:
+    ex.exchange_join(bd, pd, 0)
+    rec["code"] = 0
+except HmjError as e:
+    rec["code"], rec["msg"] = e.code, str(e)
+rec["secs"] = time.time() - t0
+t0 = time.time()
+rec["local_matches"] = int(ex.join_device(bd, pd, 0).n_matches)   # the GPU and the context are fine
+ex.close()
+rec["close_secs"] = time.time() - t0
+json.dump(rec, open(os.path.join(os.environ["OUT"], "lost.json"), "w"))
+"""
+
+
+def test_a_stalled_rccl_round_ends_in_timeout_and_teardown_does_not_block(tmp_path):
+    # RCCL transport on the one GPU of the box.  A peer that stops sending looks, from this rank, like a kernel on the
+    # communication stream that does not finish (RCCL's receive spinning on data that does not come).  One rank cannot make
+    # RCCL itself wait (a self receive without its send is refused as invalid usage), so the test hook HMJ_FAULT_STALL holds
+    # the stream with a kernel that spins for 14 s and exits.  The step must give up at its 3 s deadline with
+    # HMJ_E_TIMEOUT, the context's local join must still run, and close() must come back (ncclCommAbort, which waits for the
+    # communicator's own kernels -- here queued behind the 14 s stand-in; RCCL's kernels leave at the abort flag), exit code 0.
+    env = dict(os.environ, HMJ_ROOT=ROOT, OUT=str(tmp_path), HMJ_FAULT_STALL="1:14000")
+    p = subprocess.run(["timeout", "-k", "10", "120", sys.executable, "-c", LOST_SEND_WORKER], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=200)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    rec = json.load(open(tmp_path / "lost.json"))
+    assert rec["code"] == -8 and 2.5 < rec["secs"] < 8, rec
+    assert "no progress within 3000 ms" in rec["msg"], rec
+    assert rec["local_matches"] == 1 << 22 and rec["close_secs"] < 25, rec

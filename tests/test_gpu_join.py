@@ -466,8 +466,7 @@ def test_every_build_key_duplicated_takes_the_general_materialise_path(ex, H, or
                 assert r.checks() == ck
                 got = ex.columns_to_numpy(r, host=False)
                 assert np.array_equal(got if fl & H.HMJ_ORDERED else sorted_rows(got), rows)
-            for _ in range(8):  # run the cool-down out so the next size tries the single-pass mode again
-                ex.join_device(to_dev(oracle.gen_build(50000)), to_dev(oracle.gen_probe(50000, 50000)), H.HMJ_MATERIALIZE)
+            ex.forget_workloads()  # (cool-downs belong to a workload: every size tries the single-pass mode anyway; belt and braces)
         ex.release_result()
 
 
@@ -911,10 +910,8 @@ def test_sort_as_a_chain_of_slab_passes(H):
         "few_values": rng.integers(0, 5, n).astype(np.uint64) * np.uint64(0x0101010101010101),
         "two_low_bytes": (rng.integers(0, 1 << 40, n).astype(np.uint64) << np.uint64(8)) | (rng.integers(0, 2, n).astype(np.uint64) * np.uint64(0x80)),
     }
-    def drain():  # an overflow leaves the chain alone for 8 sorts: let them pass so that the next case is asked again
-        small = to_dev(np.stack([np.arange(5000, dtype=np.uint64)] * 2, 1))
-        for _ in range(8):
-            ex.sort_device(small)
+    def drain():  # an overflow leaves the chain alone for the next 8 sorts OF THIS SIZE: forget it so that the next case is asked again
+        ex.forget_workloads()
 
     for name, keys in shapes.items():
         a = np.stack([keys, np.arange(n, dtype=np.uint64)], 1)
@@ -981,10 +978,14 @@ def test_full_radix_sort_golden(ex, G, golden_dir):
     assert h == c["non_inplace_T8"]
 
 
-def test_dense_integer_keys_use_the_informative_bits(ex, H, oracle):
+def test_dense_integer_keys_use_the_informative_bits(ex_part, H, oracle):
     # dense keys 0..N-1 all share their top bits (the reference sends them all to
     # partition 0 in pass 1 and reaches the low bits by recursing).  The executor samples the
     # relations and partitions below the shared prefix; ordered output must still be exact.
+    # (ex_part: the count join of 2^20 x 2^20 rows would otherwise take the global table and plan nothing.  Until round 5
+    #  this test passed on the shared executor only because an earlier test's give-up had left the table cooling down
+    #  for ALL shapes.)
+    ex = ex_part
     n = 1 << 20
     rng = np.random.default_rng(11)
     kb = rng.permutation(n).astype(np.uint64)
@@ -1130,6 +1131,73 @@ def test_slab_path_parity_and_fallback(ex_fresh, H, oracle):
     assert t["ms_hist"] > 0.0  # the exact path produced this result
 
 
+def test_what_one_workload_teaches_the_planner_does_not_change_anothers_plan(ex_fresh, H, oracle):
+    # a fast path that overflows was skipped for the context's next 8 joins WHATEVER their shape (BASELINE
+    # configs[4]'s failed slab attempt put a 5 * 10^8-row join after it on the exact path: 21.9 instead of 16.3 ms).  The
+    # cool-downs now belong to a workload (log2 sizes + mode flags): interleaved on one context, each workload plans exactly
+    # as it does alone.  A: 2^22 rows, half of them in one radix digit -> a slab overflows, exact passes, the workload skips
+    # slabs from then on.  B: 2^23 uniform rows -> histogram-free slab passes, every time.
+    ex, L = ex_fresh, H._lib
+    n = 1 << 22
+    keys = oracle.gen_build(n)[:, 0]
+    hot = keys.copy()
+    hot[: n // 2] = (hot[: n // 2] & np.uint64((1 << 50) - 1)) | np.uint64(0xABC << 52)
+    A_b = to_dev(np.stack([hot, np.arange(n, dtype=np.uint64)], 1))
+    A_p = to_dev(np.stack([hot[::-1].copy(), np.arange(n, dtype=np.uint64) + np.uint64(9)], 1))
+    want_a, _ = oracle.equijoin(np.stack([hot, np.arange(n, dtype=np.uint64)], 1),
+                                np.stack([hot[::-1].copy(), np.arange(n, dtype=np.uint64) + np.uint64(9)], 1), cap=0)
+    nb = 1 << 23
+    B_b, B_p = ex.gen_build(nb), ex.gen_probe(nb, nb)
+
+    def run_b():
+        r = ex.join_device(B_b, B_p, 0)
+        assert int(r.n_matches) == nb and int(r.sum_r) == (nb * (nb - 1) // 2) % (1 << 64)
+        return ex.last_plan()
+
+    def run_a():
+        r = ex.join_device(A_b, A_p, 0)
+        assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (want_a["n_matches"], want_a["sum_r"], want_a["sum_s"])
+        return ex.last_plan()
+
+    solo = run_b()
+    assert solo["path"] & H.HMJ_PATH_SLAB and solo["attempts"] == 1 and solo["cooling"] == 0, solo
+    assert solo["radix_bits"] == sum(solo["pass_bits"]) and solo["radix_passes"] == 2 and solo["n_partitions"] == 1 << solo["radix_bits"], solo
+    a1 = run_a()  # the slab attempt overflows inside this join: two plans were executed, the second on exact passes
+    assert a1["attempts"] == 2 and a1["refused"] & L.HMJ_REFUSED_SLAB_OVERFLOW and a1["path"] & H.HMJ_PATH_EXACT, a1
+    assert a1["cooling"] & L.HMJ_COOL_SLAB and a1["workload"] != solo["workload"], a1
+    for _ in range(3):
+        b = run_b()
+        for k in ("path", "radix_bits", "radix_passes", "pass_bits", "attempts", "refused", "cooling", "workload", "key_window_low"):
+            assert b[k] == solo[k], (k, b, solo)
+        a = run_a()  # the workload remembers: straight to the exact passes, one plan
+        assert a["attempts"] == 1 and a["refused"] & L.HMJ_REFUSED_SLAB_COOLING and a["path"] & H.HMJ_PATH_EXACT, a
+    ex.forget_workloads()
+    assert run_a()["attempts"] == 2  # (forgotten: asked again)
+
+
+def test_last_plan_is_versioned_by_size(ex, H):
+    # hmj_last_plan writes at most struct_size bytes: a caller built against an older, shorter hmj_plan_desc is not overrun
+    import ctypes as C
+
+    ex.join_device(ex.gen_build(5000), ex.gen_probe(5000, 5000), 0)
+    buf = (C.c_uint32 * 64)(*([0xDEADBEEF] * 64))
+    buf[0] = 16  # room for struct_size, path, radix_bits, radix_passes only
+    fn = ex.L.hmj_last_plan
+    saved = fn.argtypes
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    try:
+        assert fn(ex.h, C.cast(buf, C.c_void_p)) == 0
+    finally:
+        fn.argtypes = saved
+    assert buf[0] == 16 and buf[4] == 0xDEADBEEF and buf[1] == ex.last_plan()["path"]
+    buf[0] = 4
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    try:
+        assert fn(ex.h, C.cast(buf, C.c_void_p)) == -1  # HMJ_E_ARG
+    finally:
+        fn.argtypes = saved
+
+
 @pytest.mark.parametrize("bits", [17, 18])
 def test_nine_bit_slab_passes_against_the_oracle(ex_fresh, H, oracle, bits):
     # Joins beyond 2^28 * 1.06 rows plan 17 (9 + 8) and 18 (9 + 9) bits; the histogram-free slab kernels run 9-bit
@@ -1184,11 +1252,19 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
         ex = H.Executor(0)
     finally:
         del os.environ["HMJ_GTABLE_SORT_FANOUT"]
+    RR = H.HMJ_PATH_RANK_RUNS
+    # (round 5: where every key's run of probe rows fits one workgroup's LDS sort -- fan-out 16 ... ~1700 -- the rows are
+    #  partitioned by key rank with two slab passes and every run is sorted in LDS, HMJ_PATH_RANK_RUNS: 32-bit keys where a
+    #  run's payloads span < 2^32, 64-bit keys otherwise; a hot key's run does not fit and the composite sort takes over)
     for nb, npb, miss, pay in [(1, 5000, 0, "ids"), (7, 70000, 0, "ids"), (1000, 300001, 3, "offset"), (5000, 700000, 0, "ids"),
                                (60000, 1 << 23, 4, "offset"), (1000, 200000, 0, "wide"), (1000, 400001, 3, "wide"),
+                               (3000, 4500000, 0, "ids"), (3001, 1500000, 5, "wide"), (4000, 1200000, 0, "hot"), (300, 5000, 0, "ids"),
                                (3000, 400000, 2, "dupbuild")]:
         B = oracle.gen_build(nb)
         P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
+        if pay == "hot":  # a third of the probe rows carry one key: its run is beyond any workgroup
+            P[::3, 0] = B[17, 0]
+            P[:, 1] = rng.permutation(npb).astype(np.uint64)
         if pay == "ids":
             P[:, 1] = rng.permutation(npb).astype(np.uint64)
         elif pay == "offset":
@@ -1204,7 +1280,12 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             t = ex.last_timing()
             took = bool(t["path"] & RS)
             # (payloads spanning all 64 bits go as two words: sorted by payload, then stably by rank)
-            assert took == (pay in ("ids", "offset", "wide")), (nb, npb, pay, fl, hex(t["path"]))
+            assert took == (pay in ("ids", "offset", "wide", "hot")), (nb, npb, pay, fl, hex(t["path"]))
+            f = npb / nb
+            runs = pay in ("ids", "offset", "wide") and nb >= 4 and npb >= 1 << 16 and f >= 16 and f + 8 * f ** 0.5 + 24 <= 2048
+            assert bool(t["path"] & RR) == runs, (nb, npb, pay, fl, hex(t["path"]))
+            if pay == "hot":  # tried, a run did not fit, the composite sort delivered; the workload remembers
+                assert ex.last_plan()["cooling"] & H._lib.HMJ_COOL_RANK_RUNS
             assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, pay, fl)
             if fl & H.HMJ_CHECKSUM:
                 assert r.checks() == ck and int(r.sum_probe_all) == int(P[:, 1].sum(dtype=np.uint64))
@@ -1242,10 +1323,11 @@ def test_rank_payload_composites_sorted_by_a_chain_of_slab_passes(H, oracle):
     RS, SL = H.HMJ_PATH_ORDER_BY_RANK_SORT, H.HMJ_PATH_SLAB
     os.environ["HMJ_GTABLE_SORT_FANOUT"] = "1"
     os.environ["HMJ_GTABLE_SORT_SLAB_MIN_LOG2"] = "20"  # (default 2^25 composites: more than the oracle checks in seconds)
+    os.environ["HMJ_RANK_RUNS"] = "0"  # (fan-outs up to ~1700 would partition by rank and sort the runs in LDS: this test is about the composites)
     try:
         ex = H.Executor(0)
     finally:
-        del os.environ["HMJ_GTABLE_SORT_FANOUT"], os.environ["HMJ_GTABLE_SORT_SLAB_MIN_LOG2"]
+        del os.environ["HMJ_GTABLE_SORT_FANOUT"], os.environ["HMJ_GTABLE_SORT_SLAB_MIN_LOG2"], os.environ["HMJ_RANK_RUNS"]
     rng = np.random.default_rng(78)
     for nb, npb, miss, pay, chain in [(1000, (1 << 22) + 5, 0, "ids", True), (33000, 1 << 23, 4, "offset", True), (5, 3000000, 0, "ids", True),
                                       (70000, 5000001, 0, "partial", True), (4097, 1 << 22, 0, "stride", False), (3000, 1 << 22, 0, "hot", False)]:
@@ -1453,24 +1535,35 @@ def test_small_build_side_takes_the_global_table(ex_fresh, H, oracle):
         else:
             B[100:400, 0] = B[50, 0]
         ck, _ = oracle.equijoin(B, P, cap=0)
+        ex.forget_workloads()  # (the case before had the same shape and left the table cooling for it)
         r = ex.join_device(to_dev(B), to_dev(P), H.HMJ_CHECKSUM)
         assert not ex.last_timing()["path"] & GT and r.checks() == ck, case
+        # what the table's give-up taught the planner belongs to THAT workload (round 5): its next 8 joins skip the table ...
+        L = H._lib
+        assert ex.last_plan()["refused"] & L.HMJ_REFUSED_GTABLE_GAVE_UP and ex.last_plan()["cooling"] & L.HMJ_COOL_GTABLE, case
+        ex.join_device(to_dev(B), to_dev(P), 0)
+        assert not ex.last_timing()["path"] & GT and ex.last_plan()["refused"] & L.HMJ_REFUSED_GTABLE_COOLING, case
+        # ... a join of another shape on the same context is not affected
         U, V = oracle.gen_build(1000), oracle.gen_uniform_domain(100000, 1000)
         ex.join_device(to_dev(U), to_dev(V), 0)
-        assert not ex.last_timing()["path"] & GT  # cooling down
-        for _ in range(8):
-            ex.join_device(to_dev(U), to_dev(V), 0)
-        assert ex.last_timing()["path"] & GT
+        assert ex.last_timing()["path"] & GT and ex.last_plan()["cooling"] == 0, case
+        for _ in range(7):
+            ex.join_device(to_dev(B), to_dev(P), 0)
+            assert not ex.last_timing()["path"] & GT
+        ex.join_device(to_dev(B), to_dev(P), 0)  # the ninth join of the workload asks the table again (and is refused again)
+        assert ex.last_plan()["refused"] & L.HMJ_REFUSED_GTABLE_GAVE_UP, case
 
 
-def test_ordered_unique_key_write_mode(ex, H, oracle):
+def test_ordered_unique_key_write_mode(ex_part, H, oracle):
     # Ordered joins with unique build keys take the single-pass write mode (no count pass) on both
     # partition layouts; duplicate build keys make it give up and the count/scan/write passes run.
+    # (ex_part: the unordered materialising joins of <= 2^21 rows below would otherwise take the global table.  Until round 5
+    #  they did not on the shared executor only because an earlier test's duplicate keys had left the table cooling for ALL shapes.)
+    ex = ex_part
     fl = H.HMJ_ORDERED | H.HMJ_CHECKSUM
 
-    def run_out_cooldown():  # after meeting duplicate build keys the executor skips the attempt for 8 joins
-        for _ in range(8):
-            ex.join_device(to_dev(oracle.gen_build(50000)), to_dev(oracle.gen_probe(50000, 50000)), fl)
+    def run_out_cooldown():  # after meeting duplicate build keys the executor skips the attempt for the workload's next 8 joins
+        ex.forget_workloads()
 
     run_out_cooldown()
     for nb, npb, miss in [(300000, 200000, 3), (300000, 400000, 0), ((1 << 22) + 4321, (1 << 22) + 99, 5),
@@ -1547,7 +1640,9 @@ def test_one_pass_ordered_write(ex_part_fresh, H, oracle):
     t = run(B, P)      # from then on: chained output offsets, dense without an epilogue
     assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0
     B2, P2 = oracle.gen_build((1 << 22) + 5), oracle.gen_probe((1 << 22) - 77, (1 << 22) + 5, miss_mod=7)
-    t = run(B2, P2)    # chained, slab layout, 1/7 unmatched
+    t = run(B2, P2)    # another workload (what a context learns is kept per shape): slots + epilogue once more ...
+    assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] > 0.0
+    t = run(B2, P2)    # ... then chained, slab layout, 1/7 unmatched
     assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0
     t = run(oracle.gen_build(1 << 22), oracle.gen_probe(1 << 22, 1 << 22))  # chained, nothing unmatched
     assert t["path"] & H.HMJ_PATH_SORTED_WRITE and t["ms_order"] == 0.0
