@@ -180,6 +180,8 @@ def load_library():
     L.hmj_last_error.argtypes = [vp]
     L.hmj_version.restype = cp
     L.hmj_version.argtypes = []
+    L.hmj_abi_version.restype = i
+    L.hmj_abi_version.argtypes = []
     L.hmj_join_u64_device.restype = i
     L.hmj_join_u64_device.argtypes = [vp, vp, u, vp, u, C.c_uint32, C.POINTER(JoinResult)]
     L.hmj_prepare_build_u64_device.restype = i

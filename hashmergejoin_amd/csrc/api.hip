@@ -2773,7 +2773,8 @@ const char* hmj_strerror(int code) {
 }
 
 const char* hmj_last_error(hmj_ctx* c) { return c ? c->last_error.c_str() : ""; }
-const char* hmj_version(void) { return "hashmergejoin_amd 0.1 (gfx950)"; }
+const char* hmj_version(void) { return "hashmergejoin_amd 0.5 (gfx950)"; }
+int hmj_abi_version(void) { return HMJ_ABI_VERSION; }
 
 int hmj_reserve(hmj_ctx* c, uint64_t n_build, uint64_t n_probe, uint64_t max_matches,
                 uint32_t flags) {

@@ -128,7 +128,7 @@ struct hmj_ctx {
   int gtable_wg_per_cu = 8;        // probe grid (HMJ_GTABLE_WG)
   u32 gtable_slots_per_row = 16;   // table slots per build row (HMJ_GTABLE_SLOTS) ...
   int gtable_max_log_cap = 18;     // ... while the table has at most 2^this slots; beyond, down to 4 per row (HMJ_GTABLE_MAX_LOG_CAP)
-  bool ltable_mode = true;         // build sides <= 4096 rows, count modes: the table in LDS, one copy per workgroup (HMJ_LTABLE=0: the L2-resident table)
+  bool ltable_mode = true;         // build sides <= 2048 rows (1024 with checksums) under >= 2^16 probe rows, count modes: the table in LDS, one copy per workgroup (HMJ_LTABLE=0, developer builds: the L2-resident table)
   bool gtable_sort_mode = true;    // HMJ_GTABLE_SORT=0: ordered joins of a small build side under a long probe side stay partitioned
   u32 gtable_sort_fanout = 128;    // ... from this many probe rows per build row on (HMJ_GTABLE_SORT_FANOUT)
   bool rank_runs_mode = true;      // ordered, small build side, fan-out 16 ... ~1700: partition by rank, sort every rank's run in LDS (HMJ_RANK_RUNS=0: composites)

@@ -125,7 +125,7 @@ typedef struct {
 #define HMJ_PATH_ORDER_BY_RANK_SORT 0x200000u /* ordered, small build side under a long probe side: rows sorted as (key rank, payload) composites */
 #define HMJ_PATH_RANK_RUNS 0x1000000u /* ... where every key's run of probe rows fits one workgroup: rows partitioned by key rank (two slab passes), each run sorted in LDS */
 #define HMJ_PATH_ORDERED_EXPANSION 0x400000u /* ordered, duplicate build keys: rows written in order partition by partition (no sort of result rows) */
-#define HMJ_PATH_LDS_TABLE 0x800000u /* ... of <= 4096 build rows, count modes: that table in LDS, one copy per workgroup */
+#define HMJ_PATH_LDS_TABLE 0x800000u /* ... of <= 2048 build rows (1024 with HMJ_CHECKSUM / HMJ_SUM_PROBE) under >= 2^16 probe rows, count modes: that table in LDS, one copy per workgroup */
 #define HMJ_PATH_GLOBAL_TABLE 0x100000u /* small build side: one global hash table, the probe side streamed unpartitioned */
 #define HMJ_PATH_HOST_PIPELINE 0x4000u /* host entry: build side partitioned while the probe side was uploading   */
 
@@ -223,6 +223,11 @@ int hmj_plan(uint64_t n_build, int* total_bits, int* n_passes, int pass_bits[4])
  * exceeded.  HMJ_PLACE=0: nothing is probed.  One entry per probed buffer of this ctx; returns the number of entries
  * (<= max_entries).  Diagnostic only; nothing in the reference corresponds to it (its buffers are std::vector
  * storage, hashjoin.h:62-63).                                                                                    */
+/* hmj_place_info, hmj_timing and hmj_exchange_info are DIAGNOSTIC structs: they grow between releases of this library and
+ * carry no size field -- build callers against the header of the library they load (hmj_abi_version() == HMJ_ABI_VERSION).
+ * hmj_plan_desc, added later, is size-versioned instead.                                                              */
+#define HMJ_ABI_VERSION 5
+int hmj_abi_version(void);
 #define HMJ_PLACE_MAX_CAND 4
 typedef struct {
   char name[16];      /* slab_a, slab_b_build, slab_b_probe, rbuf0/1, sbuf0/1                                   */
@@ -258,10 +263,16 @@ const char* hmj_version(void);
  * Which formulation runs is the executor's choice (hmj_timing.path says which; results are the same):
  *   - two radix passes + LDS build/probe per partition (the default from ~2^21 rows per side on; histogram-free slab
  *     passes of up to 9 bits, so up to 2^30 rows per side stay at 32 B per row and pass);
- *   - count modes, build side of <= 2^17 rows (or a join of <= 2^21 rows in all): ONE global hash table, the probe side
- *     streamed unpartitioned -- the reference's BM_hash_join_raw formulation (hashjoin_bench.cc:29-63), HMJ_PATH_GLOBAL_TABLE;
- *   - count modes, build side of 2^17 ... 2^21 rows under a probe side >= 8 x larger: one radix pass, the probe side left
- *     in the worker-private slabs of its slab pass and probed there, HMJ_PATH_SLAB_ONE_PASS.                          */
+ *   - count modes and unordered HMJ_MATERIALIZE, build side of <= 2^17 rows (or a join of <= 2^21 rows in all): ONE global
+ *     hash table, the probe side streamed unpartitioned -- the reference's BM_hash_join_raw formulation
+ *     (hashjoin_bench.cc:29-63), HMJ_PATH_GLOBAL_TABLE (count modes, <= 2048 build rows: the table in LDS, HMJ_PATH_LDS_TABLE);
+ *   - the same modes, build side of 2^17 ... 2^21 rows under a probe side >= 8 x larger: one radix pass, the probe side left
+ *     in the worker-private slabs of its slab pass and probed there, HMJ_PATH_SLAB_ONE_PASS;
+ *   - HMJ_ORDERED, small build side under a probe side >= 128 x larger (a cost model over fan-out and size decides): the
+ *     rows ordered through the RANK of their key among the sorted build keys, HMJ_PATH_ORDER_BY_RANK_SORT -- fan-outs up to
+ *     ~1700: partitioned by rank, every rank's run sorted in LDS (HMJ_PATH_RANK_RUNS); beyond: (rank, payload) composites
+ *     sorted by global LSD passes.
+ * hmj_last_plan says which was taken and why the faster ones were not.                                               */
 int hmj_join_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_build,
                         const void* probe_aos_dev, uint64_t n_probe, uint32_t flags,
                         hmj_result* out);
