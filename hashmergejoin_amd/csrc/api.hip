@@ -2196,71 +2196,124 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   int sp = span_begin(c, K_PROBE_COUNT, -1);
   HIP_TRY(hmj::launch_gtable_build(sortedR, nb, c->gtab.p, log_cap, (u64*)c->accum.p, true, c->num_cus, c->stream));
   // ---- 4a. the rank-run form: {rank, sval} rows, two slab passes on the rank's digits, every rank's run sorted in LDS and
-  // written at its offset (gtable.hip).  A slab that overflows or a run beyond the kernel (a hot foreign key) leaves the
-  // table as it is; the composite form below starts over from the emit, and the workload skips this form 8 times.
+  // written at its offset (gtable.hip).  First with the rank lookup INSIDE pass A (radix.hip, radix_slab_a_rank_kernel: the
+  // probe rows are read once, nothing is emitted in between); a probe row without its build row cannot be dropped from the
+  // middle of a tile there, so that attempt gives way to emit + pass A.  A slab that overflows or a run beyond the kernel
+  // (a hot foreign key) leaves the table as it is; the composite form below starts over from the emit, and the workload
+  // skips what gave up for its next 8 joins.
   bool runs_done = false;
   u64 n = 0;
   if (use_runs) {
-    HIP_TRY(hmj::launch_gtable_emit_ranks(S, np, c->gtab.p, log_cap, (u64*)c->accum.p, c->sbuf[0].p, extra, c->num_cus, c->gtable_wg_per_cu, c->stream));
-    span_end(c, sp);
-    HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) return give_up("the table gave up");
-    if (hh[hmj::ACC_PAD] != 0) return give_up("duplicate build keys");
-    n = hh[hmj::ACC_N];
     const int bb = rank_bits / 2, ba = rank_bits - bb;  // LSD: pass A on the low digit, pass B on the high one
     const u32 P = 1u << rank_bits;
-    hmj::SlabGeom g;
-    const bool geom = n > 0 && hmj::slab_geometry((u32)n, ba, bb, &g, 0, 1.0, (double)P / (double)nb);
-    if (geom) {
-      u64* acc = (u64*)c->accum.p;
-      if ((rc = ensure_dev(c, c->slab_a, g.rows_a * 16)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->cnt_a, ((size_t)g.WA << ba) * 4)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->slab_bs, g.rows_b * 16)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * g.KB * 4)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->part_count, (size_t)P * 8)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->part_out_off, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
-      const size_t bytes = (size_t)n * 8;
-      if ((rc = ensure_dev(c, c->out_key, bytes)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return rc;
-      if ((rc = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return rc;
+    u64* acc = (u64*)c->accum.p;
+    const char* why = "";
+    // rows -> partitions (fused: straight from the probe rows) -> offsets -> sorted runs; 0 ok, 1 gave up, < 0 error
+    auto passes = [&](u64 rows, bool fused) -> int {
+      hmj::SlabGeom g;
+      if (rows == 0 || !hmj::slab_geometry((u32)rows, ba, bb, &g, 0, 1.0, (double)P / (double)nb)) {
+        why = "no slab geometry";
+        return 1;
+      }
+      int r2;
+      if ((r2 = ensure_dev(c, c->slab_a, g.rows_a * 16)) != HMJ_OK) return r2;
+      if ((r2 = ensure_dev(c, c->cnt_a, ((size_t)g.WA << ba) * 4)) != HMJ_OK) return r2;
+      if ((r2 = ensure_dev(c, c->slab_bs, g.rows_b * 16)) != HMJ_OK) return r2;
+      if ((r2 = ensure_dev(c, c->cnt_bs, (size_t)P * g.KB * 4)) != HMJ_OK) return r2;
+      if ((r2 = ensure_dev(c, c->part_out_off, ((size_t)P + 1) * 8)) != HMJ_OK) return r2;
+      if ((r2 = ensure_dev(c, c->part_count, ((size_t)P / 1024 + 1) * 8)) != HMJ_OK) return r2;  // (chunk totals of the offsets scan)
+      const size_t bytes = (size_t)rows * 8;
+      if ((r2 = ensure_dev(c, c->out_key, bytes)) != HMJ_OK) return r2;
+      if ((r2 = ensure_dev(c, c->out_rval, bytes)) != HMJ_OK) return r2;
+      if ((r2 = ensure_dev(c, c->out_sval, bytes)) != HMJ_OK) return r2;
+      auto launch = [&](hipError_t e, const char* what) { return e == hipSuccess ? HMJ_OK : fail(c, HMJ_E_HIP, what, e); };
       int s2 = span_begin(c, K_SCATTER, 1, 0);
-      HIP_TRY(hmj::launch_slab_a(c->sbuf[0].p, (u32)n, 0, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->stream));
+      if (fused)
+        r2 = launch(hmj::launch_slab_a_ranks(S, np, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->gtab.p,
+                                             log_cap, extra, c->stream), "launch_slab_a_ranks");
+      else
+        r2 = launch(hmj::launch_slab_a(c->sbuf[0].p, (u32)rows, 0, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4,
+                                       acc, c->stream), "launch_slab_a");
       span_end(c, s2);
+      if (r2 != HMJ_OK) return r2;
       s2 = span_begin(c, K_SCATTER, 1, 1);
-      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, ba, bb, g, c->slab_bs.p, c->slab_bs.cap / 16, (u32*)c->cnt_bs.p,
-                                 c->cnt_bs.cap / 4, acc, c->stream));
+      r2 = launch(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, ba, bb, g, c->slab_bs.p, c->slab_bs.cap / 16, (u32*)c->cnt_bs.p,
+                                     c->cnt_bs.cap / 4, acc, c->stream), "launch_slab_b");
       span_end(c, s2);
+      if (r2 != HMJ_OK) return r2;
       s2 = span_begin(c, K_OUT_SCAN, -1);
-      HIP_TRY(hmj::launch_slab_np((const u32*)c->cnt_bs.p, P, (u64*)c->part_count.p, c->stream));
-      HIP_TRY(hmj::launch_scan_chunked_u64((const u64*)c->part_count.p, (u64*)c->part_out_off.p, P, c->stream));
+      r2 = launch(hmj::launch_slab_offsets((const u32*)c->cnt_bs.p, P, (u64*)c->part_out_off.p, (u64*)c->part_count.p, c->stream), "launch_slab_offsets");
       span_end(c, s2);
+      if (r2 != HMJ_OK) return r2;
       s2 = span_begin(c, K_PROBE_WRITE, -1);
-      HIP_TRY(hmj::launch_rank_sort_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, sortedR, nb,
-                                          (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, acc, extra, c->num_cus, c->stream));
+      r2 = launch(hmj::launch_rank_sort_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, sortedR, nb,
+                                              (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, acc, extra, c->num_cus, c->stream),
+                  "launch_rank_sort_write");
       span_end(c, s2);
+      if (r2 != HMJ_OK) return r2;
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
-      runs_done = !(hh[hmj::ACC_ERR] & (hmj::ERR_SLAB | hmj::ERR_FASTPATH));
-      if (runs_done) {
-        c->timing.bytes_scatter += 2 * 32ull * n;
-        c->timing.path |= HMJ_PATH_SLAB | HMJ_PATH_RANK_RUNS;
-        c->timing.radix_bits = rank_bits;
-        c->timing.radix_passes = 2;
+      if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) return 2;
+      if (hh[hmj::ACC_PAD] != 0) return 3;
+      if (hh[hmj::ACC_ERR] & (hmj::ERR_SLAB | hmj::ERR_FASTPATH)) {
+        why = (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) ? "a slab overflowed" : fused ? "a probe row without its build row, or a run beyond the kernel" : "a run beyond the kernel";
+        return 1;
       }
-    } else if (n == 0) {
-      runs_done = true;  // no probe row matched: an empty result
-    }
-    if (!runs_done) {
-      // start over on the composite form: the table stays, the accumulators and the emit are redone with the payload range
-      c->wm->rank_runs_cooldown = 8;
-      if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: rank-run form gave up (%s) -> composite sort\n", nb, np,
-                                 !geom ? "no slab geometry" : (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) ? "a slab overflowed" : "a run beyond the kernel");
+      c->timing.bytes_scatter += 2 * 32ull * rows - (fused ? 16ull * rows : 0ull);
+      c->timing.path |= HMJ_PATH_SLAB | HMJ_PATH_RANK_RUNS | (fused ? HMJ_PATH_RANK_LOOKUP_IN_PASS : 0u);
+      c->timing.radix_bits = rank_bits;
+      c->timing.radix_passes = 2;
+      return 0;
+    };
+    auto drop_attempt = [&]() {
       std::vector<Span> keep;
       for (const Span& s3 : c->spans)
         if (s3.kind == K_TOTAL || s3.kind == K_H2D) keep.push_back(s3);
       c->spans.swap(keep);
       c->timing.bytes_scatter = 0;
+    };
+    int st = 1;
+    if (c->wm->rank_lookup_cooldown > 0) {
+      c->wm->rank_lookup_cooldown--;
+    } else {
+      span_end(c, sp);  // (the table build)
+      st = passes(np, true);
+      if (st < 0) return st;
+      if (st == 2) return give_up("the table gave up");
+      if (st == 3) return give_up("duplicate build keys");
+      if (st == 1) {
+        c->wm->rank_lookup_cooldown = 8;
+        if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: rank lookup inside pass A gave up (%s) -> emit + pass A\n", nb, np, why);
+        drop_attempt();
+        // (the table stays; the accumulators start over, with the build kernel's verdict -- no duplicates, no give-up -- known)
+        HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+        sp = span_begin(c, K_PROBE_COUNT, -1);
+      } else {
+        n = hh[hmj::ACC_N];
+        runs_done = true;
+      }
+    }
+    if (!runs_done) {
+      HIP_TRY(hmj::launch_gtable_emit_ranks(S, np, c->gtab.p, log_cap, (u64*)c->accum.p, c->sbuf[0].p, extra, c->num_cus, c->gtable_wg_per_cu, c->stream));
+      span_end(c, sp);
+      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hh[hmj::ACC_ERR] & hmj::ERR_GTABLE) return give_up("the table gave up");
+      if (hh[hmj::ACC_PAD] != 0) return give_up("duplicate build keys");
+      n = hh[hmj::ACC_N];
+      if (n == 0) {
+        runs_done = true;  // no probe row matched: an empty result
+      } else {
+        st = passes(n, false);
+        if (st < 0) return st;
+        runs_done = st == 0;
+      }
+    }
+    if (!runs_done) {
+      // start over on the composite form: the table stays, the accumulators and the emit are redone with the payload range
+      c->wm->rank_runs_cooldown = 8;
+      if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: rank-run form gave up (%s) -> composite sort\n", nb, np, why);
+      drop_attempt();
       use_runs = false;
       const u64 init2[2] = {~0ull, 0};
       HIP_TRY(hipMemcpyAsync((u64*)c->offs64.p + 3, init2, sizeof(init2), hipMemcpyHostToDevice, c->stream));

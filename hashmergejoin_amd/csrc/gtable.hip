@@ -25,8 +25,6 @@
 
 namespace hmj {
 
-constexpr u64 GT_EMPTY = ~0ull;
-constexpr int GT_MAXWALK = 64;
 constexpr int GT_THREADS = 256;
 #ifndef HMJ_GT_ROWS
 #define HMJ_GT_ROWS 8
@@ -55,12 +53,6 @@ __device__ __forceinline__ u64 wg_reserve(u32 wave_rows, u64* cursor, u64* s_bas
   return *s_base + (u32)__shfl((int)(wincl - wr), wv, kWave);
 }
 
-__device__ __forceinline__ u32 gt_hash(u64 key, int shift) {
-  u64 h = key * 0x9E3779B97F4A7C15ull;
-  h ^= h >> 32;
-  h *= 0xD6E8FEB86659FD93ull;
-  return (u32)(h >> shift);
-}
 
 template <bool FIRST>
 __global__ __launch_bounds__(GT_THREADS) void gtable_build_kernel(const Tup* __restrict__ R, u32 nb, Tup* __restrict__ tab,
@@ -125,45 +117,24 @@ __global__ __launch_bounds__(GT_THREADS) void gtable_probe_kernel(const Tup* __r
       if (EXTRA && live[r]) acc_p += t[r].val;
       if (t[r].key == GT_EMPTY) live[r] = false;  // never a table key (the build kernel refuses such rows)
     }
-    bool any_live = false;
-#pragma unroll
-    for (int r = 0; r < GT_ROWS; r++) any_live |= live[r];
-    while (any_live) {
-      Tup e[GT_ROWS];
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++)
-        if (live[r]) e[r] = tab[slot[r]];
-      any_live = false;
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++) {
-        if (live[r]) {
-          if (e[r].key == GT_EMPTY) {
-            live[r] = false;
-          } else {
-            if (e[r].key == t[r].key) {
-              if (FIRST) {
-                first_idx[r] = e[r].val < first_idx[r] ? e[r].val : first_idx[r];
-              } else {
-                acc_n++;
-                acc_r += e[r].val;
-                acc_s += t[r].val;
-                if (EXTRA) {
-                  const u64 m = tmix(t[r].key, e[r].val, t[r].val);
-                  acc_x ^= m;
-                  acc_m += m;
-                }
-              }
-            }
-            if (!multi && e[r].key == t[r].key) {
-              live[r] = false;
-            } else {
-              slot[r] = (slot[r] + 1) & mask;
-              any_live = true;
-            }
+    gt_walk<GT_ROWS>(tab, mask, slot, live, [&](int r, const Tup& e) {
+      const bool eq = e.key == t[r].key;
+      if (eq) {
+        if (FIRST) {
+          first_idx[r] = e.val < first_idx[r] ? e.val : first_idx[r];
+        } else {
+          acc_n++;
+          acc_r += e.val;
+          acc_s += t[r].val;
+          if (EXTRA) {
+            const u64 m = tmix(t[r].key, e.val, t[r].val);
+            acc_x ^= m;
+            acc_m += m;
           }
         }
       }
-    }
+      return eq && !multi;  // (duplicate build keys: a walk ends at an empty slot only)
+    });
     if (FIRST) {
 #pragma unroll
       for (int r = 0; r < GT_ROWS; r++) {
@@ -255,45 +226,24 @@ __global__ __launch_bounds__(LT_THREADS) void ltable_probe_kernel(const Tup* __r
       if (EXTRA && live[r]) acc_p += t[r].val;
       if (t[r].key == GT_EMPTY) live[r] = false;
     }
-    bool any_live = false;
-#pragma unroll
-    for (int r = 0; r < GT_ROWS; r++) any_live |= live[r];
-    while (any_live) {
-      Tup e[GT_ROWS];
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++)
-        if (live[r]) e[r] = tab[slot[r]];
-      any_live = false;
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++) {
-        if (live[r]) {
-          if (e[r].key == GT_EMPTY) {
-            live[r] = false;
-          } else {
-            if (e[r].key == t[r].key) {
-              if (FIRST) {
-                first_idx[r] = e[r].val < first_idx[r] ? e[r].val : first_idx[r];
-              } else {
-                acc_n++;
-                acc_r += e[r].val;
-                acc_s += t[r].val;
-                if (EXTRA) {
-                  const u64 m = tmix(t[r].key, e[r].val, t[r].val);
-                  acc_x ^= m;
-                  acc_m += m;
-                }
-              }
-            }
-            if (!multi && e[r].key == t[r].key) {
-              live[r] = false;
-            } else {
-              slot[r] = (slot[r] + 1) & mask;
-              any_live = true;
-            }
+    gt_walk<GT_ROWS>(tab, mask, slot, live, [&](int r, const Tup& e) {
+      const bool eq = e.key == t[r].key;
+      if (eq) {
+        if (FIRST) {
+          first_idx[r] = e.val < first_idx[r] ? e.val : first_idx[r];
+        } else {
+          acc_n++;
+          acc_r += e.val;
+          acc_s += t[r].val;
+          if (EXTRA) {
+            const u64 m = tmix(t[r].key, e.val, t[r].val);
+            acc_x ^= m;
+            acc_m += m;
           }
         }
       }
-    }
+      return eq && !multi;  // (duplicate build keys: a walk ends at an empty slot only)
+    });
     if (FIRST) {
 #pragma unroll
       for (int r = 0; r < GT_ROWS; r++) {
@@ -383,36 +333,14 @@ __global__ __launch_bounds__(GTW_THREADS) void gtable_write_kernel(const Tup* __
       if (EXTRA && live[r]) acc_p += t[r].val;
       if (t[r].key == GT_EMPTY) live[r] = false;
     }
-    bool any_live = false;
-#pragma unroll
-    for (int r = 0; r < GT_ROWS; r++) any_live |= live[r];
-    while (any_live) {
-      Tup e[GT_ROWS];
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++)
-        if (live[r]) e[r] = tab[slot[r]];
-      any_live = false;
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++) {
-        if (live[r]) {
-          if (e[r].key == GT_EMPTY) {
-            live[r] = false;
-          } else {
-            const bool eq = e[r].key == t[r].key;
-            if (eq) {
-              hit |= 1u << r;
-              hitv[r] = (FIRST && e[r].val > hitv[r]) ? hitv[r] : e[r].val;
-            }
-            if (eq && !dups) {
-              live[r] = false;
-            } else {
-              slot[r] = (slot[r] + 1) & mask;
-              any_live = true;
-            }
-          }
-        }
+    gt_walk<GT_ROWS>(tab, mask, slot, live, [&](int r, const Tup& e) {
+      const bool eq = e.key == t[r].key;
+      if (eq) {
+        hit |= 1u << r;
+        hitv[r] = (FIRST && e.val > hitv[r]) ? hitv[r] : e.val;
       }
-    }
+      return eq && !dups;
+    });
     // this wave's output rows: slot r's hits form a run, the runs follow each other
     u32 pre[GT_ROWS], run = 0;
     u64 m[GT_ROWS];
@@ -534,31 +462,14 @@ __global__ __launch_bounds__(GTW_THREADS) void gtable_emit_kernel(const Tup* __r
       if (EXTRA && live[r]) acc_p += t[r].val;
       if (t[r].key == GT_EMPTY) live[r] = false;
     }
-    bool any_live = false;
-#pragma unroll
-    for (int r = 0; r < GT_ROWS; r++) any_live |= live[r];
-    while (any_live) {
-      Tup e[GT_ROWS];
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++)
-        if (live[r]) e[r] = tab[slot[r]];
-      any_live = false;
-#pragma unroll
-      for (int r = 0; r < GT_ROWS; r++) {
-        if (live[r]) {
-          if (e[r].key == GT_EMPTY) {
-            live[r] = false;
-          } else if (e[r].key == t[r].key) {  // (unique build keys: the only hit)
-            hit |= 1u << r;
-            rank[r] = e[r].val;
-            live[r] = false;
-          } else {
-            slot[r] = (slot[r] + 1) & mask;
-            any_live = true;
-          }
-        }
+    gt_walk<GT_ROWS>(tab, mask, slot, live, [&](int r, const Tup& e) {
+      const bool eq = e.key == t[r].key;  // (unique build keys: the only hit)
+      if (eq) {
+        hit |= 1u << r;
+        rank[r] = e.val;
       }
-    }
+      return eq;
+    });
     u32 pre[GT_ROWS], run = 0;
     u64 m[GT_ROWS];
 #pragma unroll
@@ -756,8 +667,10 @@ __device__ __forceinline__ void rs_three_levels(K (&v)[RS_EPT], bool asc) {
   for (int i = 0; i < 8; i += 2) rs_ce(v[i], v[i + 1], asc);
 }
 // Sort s[rs_sw(0 .. N)) ascending; N a power of two in [8, RS_CAP]; threads tid < N / 8 work, all threads pass the barriers.
+// (not inlined: the network is the fallback of the bucket sort below, and its 16 + 16 key registers would otherwise count
+//  against the occupancy of the kernel's common path)
 template <typename K>
-__device__ __forceinline__ void rs_bitonic(K* __restrict__ s, u32 N, int tid) {
+__device__ __attribute__((noinline)) void rs_bitonic(K* __restrict__ s, u32 N, int tid) {
   const bool active = (u32)tid < (N >> 3);
   K v[RS_EPT];
   // phases k = 2, 4, 8: inside a thread's eight consecutive elements
@@ -799,13 +712,113 @@ __device__ __forceinline__ void rs_bitonic(K* __restrict__ s, u32 N, int tid) {
   }
 }
 
+// The cheap sort of a run: payloads of one key are usually spread evenly over their range (row ids, timestamps), so a run of
+// n keys falls into NB >= n value-range buckets of about one key each.  Count the buckets (one LDS atomic per key), scan,
+// move every key to its bucket, let it rank itself among the one to three keys that share the bucket, write it to its
+// final slot: O(n) with ~60 instructions per key where the bitonic network spends ~420 (profiles/r05b_small16_ord_*: the
+// network alone was 0.7 ms of VALU time at 2^26 rows, and a run of 1025 keys paid for 2048).  Payloads that tie or cluster
+// make long buckets: beyond RS_MAXBUCKET keys in one the function returns false and the network sorts the run.
+// tmp: n keys; idx: n 16-bit slots; cnt: NB + 1 words.  On success the i-th smallest key is tmp[idx[i]].  All threads call it.
+constexpr u32 RS_MAXBUCKET = 24;
+template <typename K>
+__device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, u64 range, u32 n, K* __restrict__ tmp, unsigned short* __restrict__ idx,
+                                               u32* __restrict__ cnt, u32* __restrict__ wsc, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  u32 NB = RS_THREADS;
+  while (NB < n) NB <<= 1;
+  const int lg = 31 - __builtin_clz(NB);
+  const int bits = 64 - __builtin_clzll(range);  // (range > 0)
+  const int sh = bits > lg ? bits - lg : 0;
+  for (u32 i = (u32)tid; i <= NB; i += RS_THREADS) cnt[i] = 0;
+  lds_barrier();
+  u32 bk[RS_EPT], ar[RS_EPT];
+#pragma unroll
+  for (int r = 0; r < RS_EPT; r++) {
+    const u32 i = (u32)tid + (u32)r * RS_THREADS;
+    bk[r] = ar[r] = 0;
+    if (i < n) {
+      bk[r] = (u32)((sv[r] - mn) >> sh);
+      ar[r] = atomicAdd(&cnt[bk[r]], 1u);
+    }
+  }
+  lds_barrier();
+  // exclusive scan of the NB counts in place (thread t: entries [t * E, (t + 1) * E)), and the longest bucket
+  const u32 E = NB / RS_THREADS;  // 1 ... 8
+  u32 loc[RS_EPT], sum = 0, big = 0;
+#pragma unroll
+  for (int e = 0; e < RS_EPT; e++) {
+    loc[e] = (u32)e < E ? cnt[(u32)tid * E + (u32)e] : 0u;
+    sum += loc[e];
+    big = loc[e] > big ? loc[e] : big;
+  }
+  u32 incl = sum;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const u32 up = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += up;
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    const u32 b2 = __shfl_xor(big, o, kWave);
+    big = b2 > big ? b2 : big;
+  }
+  if (lane == kWave - 1) wsc[wv] = incl;
+  if (lane == 0) wsc[4 + wv] = big;
+  lds_barrier();
+  u32 before = 0;
+#pragma unroll
+  for (int w = 0; w < RS_THREADS / kWave; w++) {
+    if (w < wv) before += wsc[w];
+    big = wsc[4 + w] > big ? wsc[4 + w] : big;
+  }
+  if (big > RS_MAXBUCKET) {  // (uniform) ties or clustered payloads
+    lds_barrier();
+    return false;
+  }
+  u32 run = before + incl - sum;
+#pragma unroll
+  for (int e = 0; e < RS_EPT; e++)
+    if ((u32)e < E) {
+      cnt[(u32)tid * E + (u32)e] = run;
+      run += loc[e];
+    }
+  if (tid == RS_THREADS - 1) cnt[NB] = n;
+  lds_barrier();
+  // keys to their buckets (arrival order), then every key ranks itself inside its bucket
+#pragma unroll
+  for (int r = 0; r < RS_EPT; r++) {
+    const u32 i = (u32)tid + (u32)r * RS_THREADS;
+    if (i < n) tmp[cnt[bk[r]] + ar[r]] = (K)(sv[r] - mn);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int r = 0; r < RS_EPT; r++) {
+    const u32 i = (u32)tid + (u32)r * RS_THREADS;
+    if (i < n) {
+      const u32 s0 = cnt[bk[r]], e0 = cnt[bk[r] + 1], me = s0 + ar[r];
+      const K key = (K)(sv[r] - mn);
+      u32 rank = 0;
+      for (u32 t = s0; t < e0; t++) {
+        const K kt = tmp[t];
+        rank += (kt < key || (kt == key && t < me)) ? 1u : 0u;
+      }
+      idx[s0 + rank] = (unsigned short)me;
+    }
+  }
+  lds_barrier();
+  return true;
+}
+
 template <bool EXTRA>
-__global__ __launch_bounds__(RS_THREADS) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
+__global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
                                                                      u32 P, const u64* __restrict__ out_off,
                                                                      const Tup* __restrict__ sortedR, u32 nb, u64* __restrict__ out_key,
                                                                      u64* __restrict__ out_rval, u64* __restrict__ out_sval,
                                                                      u64* __restrict__ accum) {
-  __shared__ __attribute__((aligned(16))) u64 keys[RS_CAP];  // 16 KiB: 64-bit keys, or 32-bit keys in its first half
+  __shared__ __attribute__((aligned(16))) u64 keys[RS_CAP];  // 16 KiB: the run's keys (64-bit, or 32-bit in its first half)
+  __shared__ unsigned short sidx[RS_CAP];                    // bucket sort: slot of the i-th smallest key
+  __shared__ u32 bcnt[RS_CAP + 1];
+  __shared__ u32 wsc[2 * (RS_THREADS / kWave)];
   __shared__ u64 red[8];
   __shared__ u64 wmn[RS_THREADS / kWave], wmx[RS_THREADS / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -858,19 +871,35 @@ __global__ __launch_bounds__(RS_THREADS) void rank_sort_write_kernel(const Tup* 
     while (N < n) N <<= 1;
     const Tup b = sortedR[p];
     const u64 off = out_off[p];
-    if (range < 0xFFFFFFFFull) {  // 32-bit keys sval - min; the padding (all ones) is above every real key
+    if (range == 0) {
+      // one payload value in the whole run: nothing to sort
+    } else if (range < 0xFFFFFFFFull) {  // 32-bit keys sval - min
       u32* k32 = reinterpret_cast<u32*>(keys);
+      if (rs_bucket_sort<u32>(sv, mn, range, n, k32, sidx, bcnt, wsc, tid)) {
 #pragma unroll
-      for (int r = 0; r < RS_EPT; r++) {
-        const u32 i = (u32)tid + (u32)r * RS_THREADS;
-        if (i < N) k32[rs_sw(i)] = i < n ? (u32)(sv[r] - mn) : 0xFFFFFFFFu;
+        for (int r = 0; r < RS_EPT; r++) {
+          const u32 i = (u32)tid + (u32)r * RS_THREADS;
+          if (i < n) sv[r] = (u64)k32[sidx[i]] + mn;
+        }
+      } else {  // the padding (all ones) is above every real key
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) {
+          const u32 i = (u32)tid + (u32)r * RS_THREADS;
+          if (i < N) k32[rs_sw(i)] = i < n ? (u32)(sv[r] - mn) : 0xFFFFFFFFu;
+        }
+        lds_barrier();
+        rs_bitonic<u32>(k32, N, tid);
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) {
+          const u32 i = (u32)tid + (u32)r * RS_THREADS;
+          if (i < n) sv[r] = (u64)k32[rs_sw(i)] + mn;
+        }
       }
-      lds_barrier();
-      rs_bitonic<u32>(k32, N, tid);
+    } else if (range != ~0ull && rs_bucket_sort<u64>(sv, mn, range, n, keys, sidx, bcnt, wsc, tid)) {
 #pragma unroll
       for (int r = 0; r < RS_EPT; r++) {
         const u32 i = (u32)tid + (u32)r * RS_THREADS;
-        if (i < n) sv[r] = (u64)k32[rs_sw(i)] + mn;
+        if (i < n) sv[r] = keys[sidx[i]] + mn;
       }
     } else if (range != ~0ull) {
 #pragma unroll
@@ -945,6 +974,82 @@ __global__ __launch_bounds__(1024) void scan_chunked_u64_kernel(const u64* __res
   if (tid == 0) off[n] = all;
 }
 
+// off[p] = rows of the slab partitions 0 .. p - 1 (each partition SLAB_KB piece counts, one 16-byte load), off[P] = all rows.
+// Two small launches over ceil(P / 1024) workgroups: chunk totals, then every workgroup adds up the totals before its chunk
+// (<= 256 values) and scans its 1024 partitions.  (ONE workgroup for the whole array pulled 2 MB through one CU: 0.07-0.11 ms
+// at 2^16 partitions, profiles/r05c / r05d.)
+constexpr u32 SO_CHUNK = 1024;
+__device__ __forceinline__ u64 so_total(const uint4* __restrict__ c4, u32 i, u32 P) {
+  if (i >= P) return 0ull;
+  const uint4 q = c4[i];
+  return (u64)q.x + q.y + q.z + q.w;
+}
+__global__ __launch_bounds__(256) void slab_totals_kernel(const u32* __restrict__ cnt, u32 P, u64* __restrict__ tot) {
+  static_assert(SLAB_KB == 4, "one 16-byte load per partition");
+  __shared__ u64 w4[4];
+  const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(cnt);
+  const u32 b = blockIdx.x * SO_CHUNK + threadIdx.x;
+  u64 s = so_total(c4, b, P) + so_total(c4, b + 256, P) + so_total(c4, b + 512, P) + so_total(c4, b + 768, P);
+  s = wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0) w4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tot[blockIdx.x] = w4[0] + w4[1] + w4[2] + w4[3];
+}
+__global__ __launch_bounds__(256) void slab_offsets_kernel(const u32* __restrict__ cnt, u32 P, const u64* __restrict__ tot, u32 n_chunks,
+                                                           u64* __restrict__ off) {
+  __shared__ u64 w4[4];
+  const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(cnt);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  u64 before = 0, all = 0;  // chunks before this one / all chunks (n_chunks <= 2^22 / 1024: a few values per thread)
+  for (u32 i = (u32)tid; i < n_chunks; i += 256) {
+    const u64 t = tot[i];
+    all += t;
+    if (i < blockIdx.x) before += t;
+  }
+  before = wave_sum_u64(before);
+  all = wave_sum_u64(all);
+  if (lane == 0) w4[wv] = before;
+  __syncthreads();
+  const u64 base = w4[0] + w4[1] + w4[2] + w4[3];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (lane == 0) w4[wv] = all;
+    __syncthreads();
+    if (tid == 0) off[P] = w4[0] + w4[1] + w4[2] + w4[3];
+    __syncthreads();
+  }
+  u64 carry = base;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {  // 256 partitions per step, in order
+    const u32 i = blockIdx.x * SO_CHUNK + (u32)k * 256 + (u32)tid;
+    const u64 v = so_total(c4, i, P);
+    u64 incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const u64 up = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += up;
+    }
+    if (lane == kWave - 1) w4[wv] = incl;
+    __syncthreads();
+    u64 pre = 0, step = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      if (w < wv) pre += w4[w];
+      step += w4[w];
+    }
+    if (i < P) off[i] = carry + pre + incl - v;
+    carry += step;
+    __syncthreads();
+  }
+}
+hipError_t launch_slab_offsets(const u32* cnt, u32 P, u64* off, u64* scratch, hipStream_t st) {
+  if (!cnt || !off || !scratch || P == 0) return hipErrorInvalidValue;
+  const u32 chunks = (P + SO_CHUNK - 1) / SO_CHUNK;
+  hipLaunchKernelGGL(slab_totals_kernel, dim3(chunks), dim3(256), 0, st, cnt, P, scratch);
+  hipLaunchKernelGGL(slab_offsets_kernel, dim3(chunks), dim3(256), 0, st, cnt, P, scratch, chunks, off);
+  return hipGetLastError();
+}
+
 hipError_t launch_scan_chunked_u64(const u64* in, u64* off, u32 n, hipStream_t st) {
   if (!in || !off || n == 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(scan_chunked_u64_kernel, dim3(1), dim3(1024), 0, st, in, off, n);
@@ -956,7 +1061,7 @@ hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u3
                                   u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st) {
   if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0)
     return hipErrorInvalidValue;
-  u32 grid = (u32)num_cus * 8u;  // 16 KiB of LDS and 256 threads per workgroup: eight per CU
+  u32 grid = (u32)num_cus * 5u;  // what is resident at once: 96 registers (launch bounds) and 28 KiB of LDS per 256-thread workgroup
   if (grid > P) grid = P;
   if (extra)
     hipLaunchKernelGGL((rank_sort_write_kernel<true>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,

@@ -52,6 +52,7 @@ struct WorkloadMemo {
   int gtable_sort_cooldown = 0;     // ordered by a sort on (key rank, payload) composites
   int gtable_sort_slab_cooldown = 0;  // ... its passes as a chain of slab passes (after a slab overflowed)
   int rank_runs_cooldown = 0;       // ... the rank-run form (after a slab overflowed or a run did not fit one workgroup's sort)
+  int rank_lookup_cooldown = 0;     // ... its rank lookup inside pass A (after a probe row without a build row)
   int expand_cooldown = 0;          // ordered expansion (after a partition did not fit the kernel)
   int sort_slab_cooldown = 0;       // hmj_sort_u64_device: chain of slab passes (after a slab overflowed: skewed digits)
   int slab_cooldown = 0;            // histogram-free slab partitioning of both sides (after a slab overflowed: skewed keys)

@@ -47,6 +47,46 @@ __device__ __forceinline__ Tup load_stream(const Tup* p) {
 #endif
 }
 
+// ---- the global open-addressing table of gtable.hip (also read by radix.hip's pass A with a rank lookup in front) ----------
+constexpr u64 GT_EMPTY = ~0ull;   // key of an empty slot
+constexpr int GT_MAXWALK = 64;    // a build row that would walk further gives the table up
+__device__ __forceinline__ u32 gt_hash(u64 key, int shift) {
+  u64 h = key * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ull;
+  return (u32)(h >> shift);
+}
+
+// ONE walker for every kernel that looks keys up in that table (the lockstep walk was written out four times,
+// and the copies had begun to differ).  Each lane walks ROWS keys at once -- ROWS independent loads in flight -- from
+// slot[r] on, while live[r]; an empty slot ends a row's walk; on_slot(r, entry) sees every OCCUPIED slot a live row
+// visits and returns true when that row is done (a hit in a table of unique keys; a multi-map walks on to the empty slot).
+// `tab` is anything indexable by a slot number that yields a Tup: the global table, or its copy in LDS.
+template <int ROWS, typename Table, typename OnSlot>
+__device__ __forceinline__ void gt_walk(Table tab, u32 mask, u32 (&slot)[ROWS], bool (&live)[ROWS], OnSlot on_slot) {
+  bool any_live = false;
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) any_live |= live[r];
+  while (any_live) {
+    Tup e[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+      if (live[r]) e[r] = tab[slot[r]];
+    any_live = false;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      if (live[r]) {
+        if (e[r].key == GT_EMPTY || on_slot(r, e[r])) {
+          live[r] = false;
+        } else {
+          slot[r] = (slot[r] + 1) & mask;
+          any_live = true;
+        }
+      }
+    }
+  }
+}
+
 // ---- radix pass geometry (radix.hip) -------------------------------------------------------
 constexpr int RP_THREADS = 512;                  // 8 waves
 constexpr int RP_WAVES = RP_THREADS / kWave;

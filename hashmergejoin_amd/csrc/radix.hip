@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
+
 #include "hmj_dev.h"
 #include "hmj_launch.h"
 
@@ -712,10 +714,13 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 //           (so the pass stays stable); writes slabB[p][k][CB], cntB[p][k] with p = dB << bitsA | dA
 //   probe   partition p = its KB pieces in order (probe.hip, probe_count_slab_kernel)
 // ---------------------------------------------------------------------------------------------
-template <int THREADS, int MAXD, bool HI>
-__global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_a_kernel(
-    const Tup* __restrict__ in, u32 n, int shift, int bits, u32 rows_per_worker, Tup* __restrict__ slab,
-    u32 CA, u32 WA, u32* __restrict__ cnt_out, u64* __restrict__ accum, u32 worker_base) {
+// (Xform: what happens to a tile's rows between the load and the scatter.  NoXform: nothing -- the join's pass A;
+//  RankXform: every probe row becomes {rank of its key, payload} through the global table, radix_slab_a_rank_kernel below.)
+struct NoXform {};
+template <int THREADS, int MAXD, bool HI, typename Xform>
+__device__ __forceinline__ void slab_a_body(const Tup* __restrict__ in, u32 n, int shift, int bits, u32 rows_per_worker,
+                                            Tup* __restrict__ slab, u32 CA, u32 WA, u32* __restrict__ cnt_out,
+                                            u64* __restrict__ accum, u32 worker_base, Xform& xf) {
   typedef WcSmem<THREADS, MAXD> Smem;
   constexpr int TILE = Smem::TILE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -762,6 +767,7 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
           }
         }
       };
+      if constexpr (!std::is_same<Xform, NoXform>::value) xf(t, tile_n, wbase);
       // whole tiles (all but a worker's last) run the predicate-free instantiation
       if (HMJ_WC_FULLTILE && tile_n == (u32)TILE)
         wc_tile<THREADS, MAXD, HI, true, true>(sm, t, tile_n, slab, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
@@ -1227,6 +1233,81 @@ __global__ __launch_bounds__(1024) void key_sample_kernel(const Tup* __restrict_
 // LDS); a 9-bit digit needs 512 carry lines (64 KiB) beside a 4096-row tile and runs 1024 threads, one workgroup per
 // CU (157 + 2 KiB) -- the shape radix_scatter_wc_kernel<1024, 512> has on the exact path.
 template <int THREADS, int MAXD, bool HI>
+__global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_a_kernel(
+    const Tup* __restrict__ in, u32 n, int shift, int bits, u32 rows_per_worker, Tup* __restrict__ slab,
+    u32 CA, u32 WA, u32* __restrict__ cnt_out, u64* __restrict__ accum, u32 worker_base) {
+  NoXform xf;
+  slab_a_body<THREADS, MAXD, HI, NoXform>(in, n, shift, bits, rows_per_worker, slab, CA, WA, cnt_out, accum, worker_base, xf);
+}
+
+// Pass A with the rank lookup in front (the rank-run form of ordered small-build joins, gtable.hip / api.hip): the rows
+// read are PROBE rows, the rows scattered are {rank of the probe key among the sorted build keys, probe payload} -- what
+// gtable_emit_kernel would have written to memory for this pass to read back (32 B per probe row saved).  The table maps
+// key -> rank (gtable_build_kernel<true> over the sorted build rows).  A probe row whose key is not in the table cannot be
+// dropped from the middle of a tile: the kernel raises ERR_FASTPATH and the host takes emit + pass A (foreign keys that
+// all have their dimension row -- the usual case -- never get there).  Sums of the probe payloads as gtable_emit_kernel.
+struct RankXform {
+  const Tup* __restrict__ tab;
+  u32 mask;
+  int hshift;
+  u64 acc_s;
+  bool miss;
+  __device__ __forceinline__ void operator()(Tup (&t)[WC_ITEMS], u32 tile_n, u32 wbase) {
+    u32 slot[WC_ITEMS];
+    bool live[WC_ITEMS], want[WC_ITEMS];
+    u32 found = 0;
+#pragma unroll
+    for (int r = 0; r < WC_ITEMS; r++) {
+      want[r] = wbase + (u32)r * 64 < tile_n;
+      slot[r] = gt_hash(t[r].key, hshift);
+      if (want[r]) acc_s += t[r].val;
+      live[r] = want[r] && t[r].key != GT_EMPTY;  // (the empty marker is never a table key)
+    }
+    u64 rank[WC_ITEMS] = {};
+    gt_walk<WC_ITEMS>(tab, mask, slot, live, [&](int r, const Tup& e) {
+      const bool eq = e.key == t[r].key;
+      if (eq) {
+        rank[r] = e.val;
+        found |= 1u << r;
+      }
+      return eq;
+    });
+#pragma unroll
+    for (int r = 0; r < WC_ITEMS; r++) {
+      miss |= want[r] && !((found >> r) & 1u);
+      t[r].key = rank[r];  // (.val stays the probe payload)
+    }
+  }
+};
+template <int THREADS, int MAXD>
+__global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_a_rank_kernel(
+    const Tup* __restrict__ in, u32 n, int bits, u32 rows_per_worker, Tup* __restrict__ slab, u32 CA, u32 WA,
+    u32* __restrict__ cnt_out, u64* __restrict__ accum, const Tup* __restrict__ tab, int log_cap, bool extra) {
+  // (duplicate build keys or a table that gave up -- the host sees the same words and discards this pass -- need no early
+  //  exit: the table is fully initialised either way, every walk ends at an empty slot, every rank is a build row's index;
+  //  and pass B trusts the counts written below, so they must be written)
+  RankXform xf{tab, (1u << log_cap) - 1, 64 - log_cap, 0ull, false};
+  slab_a_body<THREADS, MAXD, false, RankXform>(in, n, 0, bits, rows_per_worker, slab, CA, WA, cnt_out, accum, 0u, xf);
+  // sums: one set of atomics per workgroup
+  __shared__ u64 wsum[THREADS / kWave];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 ws = wave_sum_u64(xf.acc_s);
+  const bool any_miss = __any(xf.miss);
+  if (lane == 0) wsum[wv] = ws;
+  if (any_miss && lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 tot = 0;
+    for (int w = 0; w < THREADS / kWave; w++) tot += wsum[w];
+    const u64 begin = (u64)blockIdx.x * rows_per_worker;
+    u64 end = begin + rows_per_worker;
+    if (end > n) end = n;
+    if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_SUM_S]), (unsigned long long)tot);
+    if (extra && tot) atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_SUM_P]), (unsigned long long)tot);
+    if (end > begin) atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_N]), (unsigned long long)(end - begin));
+  }
+}
+template <int THREADS, int MAXD, bool HI>
 static hipError_t launch_slab_a_t(const void* in, u32 n, int shift, int bits, u32 rpw, void* slab, u32 CA,
                                   u32 WA, u32* cnt, u64* accum, hipStream_t st, u32 w_begin, u32 w_end) {
   typedef WcSmem<THREADS, MAXD> Smem;
@@ -1337,6 +1418,27 @@ hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabG
   if (bits > 8) return hi ? HMJ_SLAB_A(1024, 512, true) : HMJ_SLAB_A(1024, 512, false);
   return hi ? HMJ_SLAB_A(512, 256, true) : HMJ_SLAB_A(512, 256, false);
 #undef HMJ_SLAB_A
+}
+
+// pass A of the rank-run form with the key -> rank lookup in front (radix_slab_a_rank_kernel): in = PROBE rows
+hipError_t launch_slab_a_ranks(const void* in, u32 n, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
+                               u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, hipStream_t st) {
+  if (bits < 1 || bits > SLAB_MAX_BITS || g.WA == 0 || g.CA == 0 || (u64)g.WA * g.rpw < n || !tab || log_cap < 4 || log_cap > 30)
+    return hipErrorInvalidValue;
+  if (slab_a_rows < ((u64)g.WA << bits) * g.CA || cnt_a_n < ((u64)g.WA << bits)) return hipErrorInvalidValue;
+  if (((u64)g.WA << bits) * g.CA >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+#define HMJ_SLAB_AR(T, M)                                                                                                           \
+  {                                                                                                                                   \
+    typedef WcSmem<T, M> Smem;                                                                                                        \
+    static SmemAttrOnce once;                                                                                                         \
+    if (hipError_t e = ensure_max_smem(once, reinterpret_cast<const void*>(radix_slab_a_rank_kernel<T, M>), sizeof(Smem)); e != hipSuccess) \
+      return e;                                                                                                                       \
+    hipLaunchKernelGGL((radix_slab_a_rank_kernel<T, M>), dim3(g.WA), dim3(T), sizeof(Smem), st, static_cast<const Tup*>(in), n, bits, g.rpw, \
+                       static_cast<Tup*>(slab_a), g.CA, g.WA, cnt_a, accum, static_cast<const Tup*>(tab), log_cap, extra);             \
+  }
+  if (bits > 8) HMJ_SLAB_AR(1024, 512) else HMJ_SLAB_AR(512, 256)
+#undef HMJ_SLAB_AR
+  return hipGetLastError();
 }
 
 hipError_t launch_slab_b(const void* slab_a, const u32* cnt_a, int bits_a, int shift, int bits,

@@ -129,6 +129,25 @@ inline const void* relation_rows(Iter begin, std::size_t n, StagedRows& stage) {
 // equal (eq(r_row, s_row)); inside a run of equal hashes the pairs are ordered by key (less(r_row_a,
 // r_row_b)), as the reference's sort does (radix_hash.h:86-109 breaks hash ties on the key).  Fills the
 // matching row indices in iteration order.
+// fn(begin, end) over [0, n) on up to `threads` host threads (the caller's thread takes the last share)
+template <typename Fn>
+inline void parallel_ranges(std::size_t n, unsigned threads, Fn fn) {
+  if (threads > 64) threads = 64;
+  if (threads < 2 || n < 65536) {
+    fn((std::size_t)0, n);
+    return;
+  }
+  const std::size_t per = (n + threads - 1) / threads;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t + 1 < threads; t++) {
+    const std::size_t b = (std::size_t)t * per, e = b + per < n ? b + per : n;
+    if (b < e) th.emplace_back(fn, b, e);
+  }
+  const std::size_t b = (std::size_t)(threads - 1) * per;
+  if (b < n) fn(b, n);
+  for (auto& x : th) x.join();
+}
+
 template <typename Eq, typename Less>
 inline void join_hashed_rows(const std::vector<std::pair<std::uint64_t, std::uint64_t>>& hr,
                              const std::vector<std::pair<std::uint64_t, std::uint64_t>>& hs, unsigned num_threads,
@@ -142,6 +161,30 @@ inline void join_hashed_rows(const std::vector<std::pair<std::uint64_t, std::uin
   std::shared_ptr<hmj_rows> guard(rows, hmj_rows_free);
   // rows are (hash, r index, s index) in ascending hash
   const std::size_t n = (std::size_t)res.n_matches;
+  ri.clear();
+  si.clear();
+  // The usual case -- no two different keys share a 64-bit hash, so every pair the GPU found is a pair of equal keys and no
+  // hash value occurs twice among the results -- is verified on all host threads (each pair costs two cache misses into the
+  // caller's relations: 10^6 pairs took 80 ms on one thread, configs[0]); then the GPU's columns ARE the answer.
+  bool simple = true;
+  {
+    std::vector<char> bad_flag(1, 0);
+    char* bad = bad_flag.data();
+    parallel_ranges(n, num_threads, [&, bad](std::size_t b, std::size_t e) {
+      bool any = false;
+      for (std::size_t k = b; k < e && !any; k++) {
+        if (!eq(res.rval[k], res.sval[k])) any = true;                 // a hash collision between different keys
+        if (k + 1 < n && res.key[k + 1] == res.key[k]) any = true;     // several result rows share a hash value
+      }
+      if (any) *bad = 1;  // (benign race: every writer stores the same value)
+    });
+    simple = *bad == 0;
+  }
+  if (simple) {
+    ri.assign(res.rval, res.rval + n);
+    si.assign(res.sval, res.sval + n);
+    return;
+  }
   ri.reserve(n);
   si.reserve(n);
   std::size_t i = 0;
@@ -324,6 +367,17 @@ class HashMergeJoin<RIter, SIter, false> {
         hr, hs, num_threads,
         [&](std::uint64_t r, std::uint64_t q) { return r_begin[r].first == s_begin[q].first; },
         [&](std::uint64_t x, std::uint64_t y) { return r_begin[x].first < r_begin[y].first; }, _ri, _si);
+    // The payloads of the result rows are copied into the join object, in iteration order -- the reference's iterator
+    // walks its own sorted copies too (hashjoin.h:168-173) -- so that iterating does not miss the cache twice per row in
+    // the caller's relations (10^6 rows: 126 ms of a 239 ms join, configs[0]); the copy runs on all host threads.
+    _rv.resize(_ri.size());
+    _sv.resize(_ri.size());
+    hmj_detail::parallel_ranges(_ri.size(), num_threads, [&](std::size_t b, std::size_t e) {
+      for (std::size_t k = b; k < e; k++) {
+        _rv[k] = r_begin[_ri[k]].second;
+        _sv[k] = s_begin[_si[k]].second;
+      }
+    });
   }
 
   class iterator : public std::iterator<std::input_iterator_tag, std::tuple<Key*, RValue*, SValue*>> {
@@ -341,10 +395,9 @@ class HashMergeJoin<RIter, SIter, false> {
     bool operator==(iterator other) const { return _pos == other._pos; }
     bool operator!=(iterator other) const { return _pos != other._pos; }
     std::tuple<Key*, RValue*, SValue*>& operator*() {
+      // (the key's ADDRESS in the caller's relation -- nothing of the row is read unless the caller dereferences it)
       const typename std::iterator_traits<RIter>::value_type& rr = _owner->_r[_owner->_ri[_pos]];
-      const typename std::iterator_traits<SIter>::value_type& ss = _owner->_s[_owner->_si[_pos]];
-      tmp_val = std::make_tuple(const_cast<Key*>(&rr.first), const_cast<RValue*>(&rr.second),
-                                const_cast<SValue*>(&ss.second));
+      tmp_val = std::make_tuple(const_cast<Key*>(&rr.first), &_owner->_rv[_pos], &_owner->_sv[_pos]);
       return tmp_val;
     }
 
@@ -359,6 +412,8 @@ class HashMergeJoin<RIter, SIter, false> {
   void clear() {
     _ri.clear();
     _si.clear();
+    _rv.clear();
+    _sv.clear();
   }
   std::size_t size() const { return _ri.size(); }
 
@@ -366,6 +421,8 @@ class HashMergeJoin<RIter, SIter, false> {
   RIter _r;
   SIter _s;
   std::vector<std::uint64_t> _ri, _si;  // matching row indices into the caller's relations
+  std::vector<RValue> _rv;              // the result rows' payloads, in iteration order
+  std::vector<SValue> _sv;
 };
 
 // ---------------------------------------------------------------------------------------------------

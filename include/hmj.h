@@ -124,6 +124,7 @@ typedef struct {
 #define HMJ_PATH_SLAB_ONE_PASS 0x80000u /* ... of a ONE-pass plan: the probe kernel reads the pass's worker-private slabs directly */
 #define HMJ_PATH_ORDER_BY_RANK_SORT 0x200000u /* ordered, small build side under a long probe side: rows sorted as (key rank, payload) composites */
 #define HMJ_PATH_RANK_RUNS 0x1000000u /* ... where every key's run of probe rows fits one workgroup: rows partitioned by key rank (two slab passes), each run sorted in LDS */
+#define HMJ_PATH_RANK_LOOKUP_IN_PASS 0x2000000u /* ... with the key -> rank lookup inside the first slab pass (every probe row had its build row) */
 #define HMJ_PATH_ORDERED_EXPANSION 0x400000u /* ordered, duplicate build keys: rows written in order partition by partition (no sort of result rows) */
 #define HMJ_PATH_LDS_TABLE 0x800000u /* ... of <= 2048 build rows (1024 with HMJ_CHECKSUM / HMJ_SUM_PROBE) under >= 2^16 probe rows, count modes: that table in LDS, one copy per workgroup */
 #define HMJ_PATH_GLOBAL_TABLE 0x100000u /* small build side: one global hash table, the probe side streamed unpartitioned */

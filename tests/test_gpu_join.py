@@ -1284,6 +1284,9 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             f = npb / nb
             runs = pay in ("ids", "offset", "wide") and nb >= 4 and npb >= 1 << 16 and f >= 16 and f + 8 * f ** 0.5 + 24 <= 2048
             assert bool(t["path"] & RR) == runs, (nb, npb, pay, fl, hex(t["path"]))
+            # every probe row has its build row (miss == 0): the rank lookup runs inside the first slab pass; unmatched
+            # probe rows make that attempt give way to emit + pass A (and the workload remembers)
+            assert bool(t["path"] & H._lib.HMJ_PATH_RANK_LOOKUP_IN_PASS) == (runs and miss == 0), (nb, npb, pay, miss, hex(t["path"]))
             if pay == "hot":  # tried, a run did not fit, the composite sort delivered; the workload remembers
                 assert ex.last_plan()["cooling"] & H._lib.HMJ_COOL_RANK_RUNS
             assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, pay, fl)
