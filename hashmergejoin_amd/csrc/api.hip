@@ -2103,9 +2103,16 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     //  where the table leaves the L2 -- profiles/r04p_side_rank_sort_slab_chain.txt)
     const bool chain = c->gtable_sort_slab && c->slab_mode && c->wm->gtable_sort_slab_cooldown == 0 && n_probe >= c->gtable_sort_slab_min;
     // (round 5: runs that fit one workgroup's LDS sort -- fan-out up to ~1700 -- are partitioned by rank with two slab passes
-    //  and sorted run by run, rank_runs_fit below: ~0.040 ns per probe row whatever the payloads' width)
-    const double rank_ns = (rank_runs_fit(c, n_build, n_probe) ? 0.040 : chain ? 0.060 : 0.072) + (n_build > c->gtable_max_rows ? 0.02 : 0.0);
-    if (c->gtable_sort_fanout > 1 && 0.65 + rank_ns * rows >= 0.15 + part_ns * rows) {
+    //  and sorted run by run, rank_runs_fit, whatever the payloads' width;
+    //  measured over 2^12 ... 2^18 build x 2^22 ... 2^28 probe rows, profiles/r05k_sweep_ordered_small_build.txt: 0.25 ms of
+    //  launches and read-backs + 0.0215 ns per probe row + 7.5 ns per RUN -- a workgroup's load -> sort -> store chain per key.
+    //  Longer runs stay with the composites: cutting a run by the position of the payload in the payloads' range was tried
+    //  and dropped -- row ids and timestamps are monotone in the row's POSITION, so every worker of a slab pass sees one
+    //  bucket only and its slab for that digit overflows, whichever digit the bucket bits go into)
+    const bool runs = rank_runs_fit(c, n_build, n_probe);
+    const double rank_ns = (chain ? 0.060 : 0.072) + (n_build > c->gtable_max_rows ? 0.02 : 0.0);
+    const double rank_ms = runs ? 0.25 + 0.0215 * rows + 0.0075 * (double)n_build * 1e-3 : 0.65 + rank_ns * rows;
+    if (c->gtable_sort_fanout > 1 && rank_ms >= 0.15 + part_ns * rows) {
       c->plan.refused |= HMJ_REFUSED_RANK_SORT_MODEL;
       return HMJ_OK;
     }
