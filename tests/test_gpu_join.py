@@ -579,6 +579,51 @@ def test_full_size_closed_form(ex, H, G, log2n, bits):
         ex.set_radix_bits(None)
 
 
+@pytest.mark.parametrize("log2b,log2p,wide", [(16, 26, False), (16, 26, True), (18, 26, False), (12, 26, False), (14, 24, True)])
+def test_full_size_ordered_small_build_side(ex_fresh, H, log2b, log2p, wide):
+    # The operator's mode for a dimension table under a fact table at sizes no CPU oracle reaches in seconds (the bench's
+    # small_build_2p16_x_2p26_ordered entry): checked ROW BY ROW on the device through the generators' own arithmetic.
+    # Every result row must pair the build row and the probe row it names (rval is the build row's index, sval identifies
+    # the probe row), every probe row must appear exactly once, keys must ascend and, inside a key, probe payloads must
+    # ascend (unsigned) -- that is HashMergeJoin's iteration order for unique build keys (hashjoin.h:104-154).
+    # (16 / 18, 26): rank runs (fan-out 1024 / 256); wide: payloads spanning 64 bits; (12, 26): runs of 16384 rows -> composites.
+    import torch
+
+    from hashmergejoin_amd.join import _memcpy_d2d
+
+    ex = ex_fresh
+    nb, npb = 1 << log2b, 1 << log2p
+    bd, pd = ex.gen_build(nb), ex.gen_uniform_domain(npb, nb)
+    ODD, INV = 0x9E3779B97F4A7C15, pow(0x9E3779B97F4A7C15, -1, 1 << 64)
+    as_i64 = lambda v: v - (1 << 64) if v >= 1 << 63 else v
+    if wide:
+        pd[:, 1] = pd[:, 1] * as_i64(ODD)  # a bijection of the 64-bit payloads: they now span the whole range
+    r = ex.join_device(bd, pd, H.HMJ_ORDERED | H.HMJ_CHECKSUM)
+    t = ex.last_timing()
+    assert int(r.n_matches) == npb
+    assert t["path"] & H.HMJ_PATH_ORDER_BY_RANK_SORT, hex(t["path"])
+    assert bool(t["path"] & H.HMJ_PATH_RANK_RUNS) == (log2p - log2b <= 10), hex(t["path"])
+    cols = []
+    for ptr in (r.key, r.rval, r.sval):
+        c = torch.empty(npb, dtype=torch.int64, device="cuda")
+        _memcpy_d2d(torch, c, ptr, npb * 8)
+        cols.append(c)
+    k, rv, sv = cols
+    sign = torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
+    vx = torch.tensor(VAL_XOR - (1 << 64), dtype=torch.int64, device="cuda")
+    assert bool(((rv >= 0) & (rv < nb)).all())
+    assert bool((bd[rv, 0] == k).all()) and bool((bd[rv, 1] == rv).all())  # the build row each result row names carries its key
+    j = ((sv * as_i64(INV)) if wide else sv) ^ vx                            # the probe row each result row names ...
+    assert bool(((j >= 0) & (j < npb)).all())
+    assert bool((pd[j, 0] == k).all()) and bool((pd[j, 1] == sv).all())      # ... carries its key and payload
+    assert bool((torch.sort(j).values == torch.arange(npb, device="cuda")).all())  # every probe row exactly once
+    ks, ss = k ^ sign, sv ^ sign
+    assert bool((ks[1:] >= ks[:-1]).all())                                   # ascending keys ...
+    assert bool(((ks[1:] > ks[:-1]) | (ss[1:] > ss[:-1])).all())             # ... and inside a key ascending payloads
+    assert int(r.sum_s) == int(pd[:, 1].sum().item()) & M64 and int(r.sum_r) == int(rv.sum().item()) & M64
+    ex.release_result()
+
+
 def _full_size_checks(ex, H, G, bd, pd, n, log2n, bits):
     r = ex.join_device(bd, pd, 0)
     assert int(r.n_matches) == n
