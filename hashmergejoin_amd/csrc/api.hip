@@ -2060,11 +2060,11 @@ static int slab_chain(hmj_ctx* c, const void* dense_in, u32 n, const ChainDigit*
 // shapes: 2^16 x 2^26 rows 14-22 ms, 2^10 x 2^22 6 ms.  Anything else -- duplicate build keys, payloads too wide, a table
 // that gives up -- leaves *done false and the partitioned paths run (8 joins of cool-down).
 // ns per probe row of the partitioned one-pass ordered foreign-key write at fan-out f (profiles/r04u_side_fk_payload_buckets.txt)
-static double ordered_part_ns(double f) {
-  if (f > 700.0) return 0.25;  // (runs beyond the kernel's partitions: write + order epilogue)
-  const double lin = 0.030 + 0.00023 * f;
+static double ordered_part_ns(const OrderedCostModel& m, double f) {
+  if (f > 700.0) return m.part_epilogue_ns;  // (runs beyond the kernel's partitions: write + order epilogue)
+  const double lin = m.part_ns + m.part_ns_per_f * f;
   if (f < 24.0) return lin;
-  const double bucketed = 0.043 + (f > 128.0 ? 0.0001 * (f - 128.0) : 0.0);
+  const double bucketed = m.part_bucket_ns + (f > 128.0 ? m.part_bucket_ns_per_f * (f - 128.0) : 0.0);
   return lin < bucketed ? lin : bucketed;
 }
 // The rank-run form (gtable.hip): every rank's run of probe rows must fit one workgroup's LDS sort with room for its
@@ -2098,7 +2098,8 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     // (later in round 4 the one-pass write learned to rank inside (build rank, payload position) buckets from fan-out 24 on:
     //  0.043 ns per row up to fan-out ~130, + 0.0001 per further probe row per key -- 2^18 x 2^26: 7.5 -> 3.9 ms, 2^20 x 2^28:
     //  29.3 -> 15.8 -- so this path is now for fan-outs beyond ~500 and for runs the kernel's partitions cannot hold)
-    const double part_ns = ordered_part_ns(f);
+    const OrderedCostModel& m = c->ordered_model;
+    const double part_ns = ordered_part_ns(m, f);
     // (round 4, later: 0.060 where the composites' passes are the chain of slab passes below, 0.072 on exact passes, + 0.02
     //  where the table leaves the L2 -- profiles/r04p_side_rank_sort_slab_chain.txt)
     const bool chain = c->gtable_sort_slab && c->slab_mode && c->wm->gtable_sort_slab_cooldown == 0 && n_probe >= c->gtable_sort_slab_min;
@@ -2110,9 +2111,9 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     //  and dropped -- row ids and timestamps are monotone in the row's POSITION, so every worker of a slab pass sees one
     //  bucket only and its slab for that digit overflows, whichever digit the bucket bits go into)
     const bool runs = rank_runs_fit(c, n_build, n_probe);
-    const double rank_ns = (chain ? 0.060 : 0.072) + (n_build > c->gtable_max_rows ? 0.02 : 0.0);
-    const double rank_ms = runs ? 0.25 + 0.0215 * rows + 0.0075 * (double)n_build * 1e-3 : 0.65 + rank_ns * rows;
-    if (c->gtable_sort_fanout > 1 && rank_ms >= 0.15 + part_ns * rows) {
+    const double rank_ns = (chain ? m.comp_ns_chain : m.comp_ns_exact) + (n_build > c->gtable_max_rows ? m.comp_ns_beyond_l2 : 0.0);
+    const double rank_ms = runs ? m.runs_fixed_ms + m.runs_ns * rows + m.runs_ns_per_run * (double)n_build * 1e-6 : m.comp_fixed_ms + rank_ns * rows;
+    if (c->gtable_sort_fanout > 1 && rank_ms >= m.part_fixed_ms + part_ns * rows) {
       c->plan.refused |= HMJ_REFUSED_RANK_SORT_MODEL;
       return HMJ_OK;
     }
@@ -2171,8 +2172,9 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   bool wide = rank_bits + range_bits > 64;
   if (wide && c->gtable_sort_fanout > 1) {  // (ten passes instead of four or five: about 1.6 x the time per row)
     const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
-    const double part_ns = ordered_part_ns(f);
-    if (0.65 + 0.145 * rows >= 0.15 + part_ns * rows) {
+    const OrderedCostModel& m = c->ordered_model;
+    const double part_ns = ordered_part_ns(m, f);
+    if (m.comp_fixed_ms + m.comp_ns_wide * rows >= m.part_fixed_ms + part_ns * rows) {
       c->wm->gtable_sort_cooldown = 8;
       return HMJ_OK;
     }
@@ -2661,6 +2663,28 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_SPLIT")) c->split_mode = atoi(e) != 0;
   if (const char* e = getenv("HMJ_SCATTER")) c->scatter_variant = (std::strcmp(e, "plain") == 0) ? 0 : 1;
   if (const char* e = getenv("HMJ_DEBUG_ABLATE")) c->dev_ablate = (u32)atoi(e);
+  if (const char* e = getenv("HMJ_ORDERED_MODEL")) {  // "runs_ns=0.03,comp_fixed_ms=0.5": single constants of the ordered cost model
+    struct { const char* name; double* v; } f[] = {
+        {"part_fixed_ms", &c->ordered_model.part_fixed_ms}, {"part_ns", &c->ordered_model.part_ns},
+        {"part_ns_per_f", &c->ordered_model.part_ns_per_f}, {"part_bucket_ns", &c->ordered_model.part_bucket_ns},
+        {"part_bucket_ns_per_f", &c->ordered_model.part_bucket_ns_per_f}, {"part_epilogue_ns", &c->ordered_model.part_epilogue_ns},
+        {"comp_fixed_ms", &c->ordered_model.comp_fixed_ms}, {"comp_ns_chain", &c->ordered_model.comp_ns_chain},
+        {"comp_ns_exact", &c->ordered_model.comp_ns_exact}, {"comp_ns_wide", &c->ordered_model.comp_ns_wide},
+        {"comp_ns_beyond_l2", &c->ordered_model.comp_ns_beyond_l2}, {"runs_fixed_ms", &c->ordered_model.runs_fixed_ms},
+        {"runs_ns", &c->ordered_model.runs_ns}, {"runs_ns_per_run", &c->ordered_model.runs_ns_per_run}};
+    std::string spec(e);
+    size_t pos = 0;
+    while (pos < spec.size()) {
+      size_t end = spec.find(',', pos);
+      if (end == std::string::npos) end = spec.size();
+      const std::string item = spec.substr(pos, end - pos);
+      const size_t eq = item.find('=');
+      if (eq != std::string::npos)
+        for (auto& x : f)
+          if (item.compare(0, eq, x.name) == 0 && std::strlen(x.name) == eq) *x.v = atof(item.c_str() + eq + 1);
+      pos = end + 1;
+    }
+  }
 #endif
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;

@@ -570,18 +570,12 @@ __global__ __launch_bounds__(1024) void piece_offsets_kernel(const u32* __restri
   }
 }
 
-// a wave walks a contiguous range of pieces (counts and offsets fetched 64 at a time, one per lane, handed out by readlane)
-template <bool EXTRA>
-__global__ __launch_bounds__(256) void gtable_expand_pieces_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt,
-                                                                   const u64* __restrict__ off, u32 n_pieces, u32 cap, u32 ppw,
-                                                                   const Tup* __restrict__ sortedR, u64 svmin, int range_bits,
-                                                                   u64* __restrict__ out_key, u64* __restrict__ out_rval,
-                                                                   u64* __restrict__ out_sval, u64* __restrict__ accum) {
-  __shared__ u64 red[8];
-  if (threadIdx.x < 8) red[threadIdx.x] = 0;
+// A wave walks a contiguous range of pieces -- counts and offsets fetched 64 at a time, one per lane, handed out by readlane --
+// and calls row(piece, r, first result row of the piece) for every row r of every piece, lanes over the rows.  ONE walker
+// for the kernels that consume a chain's last pass (the walk was written out twice).
+template <typename OnRow>
+__device__ __forceinline__ void walk_pieces(const u32* __restrict__ cnt, const u64* __restrict__ off, u32 n_pieces, u32 ppw, OnRow on_row) {
   const int lane = threadIdx.x & 63;
-  const u64 lowmask = range_bits >= 64 ? ~0ull : ((1ull << range_bits) - 1);
-  u64 acc_r = 0, acc_x = 0, acc_m = 0;
   const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6);
   const u64 p0 = (u64)wave * ppw;
   const u32 p1 = p0 + ppw < n_pieces ? (u32)(p0 + ppw) : n_pieces;
@@ -592,23 +586,35 @@ __global__ __launch_bounds__(256) void gtable_expand_pieces_kernel(const Tup* __
     for (u32 pi = 0; pi < pe; pi++) {
       const u32 c = (u32)__builtin_amdgcn_readlane((int)c_l, (int)pi);
       const u64 o = ((u64)(u32)__builtin_amdgcn_readlane((int)(o_l >> 32), (int)pi) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)o_l, (int)pi);
-      const Tup* __restrict__ base = slabs + (pb + pi) * cap;
-      for (u32 r = (u32)lane; r < c; r += kWave) {
-        const u64 comp = load_stream(&base[r]).key;
-        const Tup b = sortedR[range_bits >= 64 ? 0ull : comp >> range_bits];
-        const u64 sv = (comp & lowmask) + svmin;
-        out_key[o + r] = b.key;
-        out_rval[o + r] = b.val;
-        out_sval[o + r] = sv;
-        acc_r += b.val;
-        if (EXTRA) {
-          const u64 mx = tmix(b.key, b.val, sv);
-          acc_x ^= mx;
-          acc_m += mx;
-        }
-      }
+      for (u32 r = (u32)lane; r < c; r += kWave) on_row(pb + pi, r, o);
     }
   }
+}
+
+template <bool EXTRA>
+__global__ __launch_bounds__(256) void gtable_expand_pieces_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt,
+                                                                   const u64* __restrict__ off, u32 n_pieces, u32 cap, u32 ppw,
+                                                                   const Tup* __restrict__ sortedR, u64 svmin, int range_bits,
+                                                                   u64* __restrict__ out_key, u64* __restrict__ out_rval,
+                                                                   u64* __restrict__ out_sval, u64* __restrict__ accum) {
+  __shared__ u64 red[8];
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
+  const u64 lowmask = range_bits >= 64 ? ~0ull : ((1ull << range_bits) - 1);
+  u64 acc_r = 0, acc_x = 0, acc_m = 0;
+  walk_pieces(cnt, off, n_pieces, ppw, [&](u64 piece, u32 r, u64 o) {
+    const u64 comp = load_stream(&slabs[piece * cap + r]).key;
+    const Tup b = sortedR[range_bits >= 64 ? 0ull : comp >> range_bits];
+    const u64 sv = (comp & lowmask) + svmin;
+    out_key[o + r] = b.key;
+    out_rval[o + r] = b.val;
+    out_sval[o + r] = sv;
+    acc_r += b.val;
+    if (EXTRA) {
+      const u64 mx = tmix(b.key, b.val, sv);
+      acc_x ^= mx;
+      acc_m += mx;
+    }
+  });
   __syncthreads();
   const u64 v[6] = {0, acc_r, 0, acc_x, acc_m, 0};
   block_accumulate(red, accum, v, 1u << ACC_XOR);
@@ -618,21 +624,7 @@ __global__ __launch_bounds__(256) void gtable_expand_pieces_kernel(const Tup* __
 __global__ __launch_bounds__(256) void pieces_compact_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt,
                                                              const u64* __restrict__ off, u32 n_pieces, u32 cap, u32 ppw,
                                                              Tup* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const u64 p0 = (u64)wave * ppw;
-  const u32 p1 = p0 + ppw < n_pieces ? (u32)(p0 + ppw) : n_pieces;
-  for (u64 pb = p0; pb < p1; pb += kWave) {
-    const u32 c_l = pb + lane < p1 ? cnt[pb + lane] : 0u;
-    const u64 o_l = pb + lane < p1 ? off[pb + lane] : 0ull;
-    const u32 pe = p1 - pb < (u64)kWave ? (u32)(p1 - pb) : (u32)kWave;
-    for (u32 pi = 0; pi < pe; pi++) {
-      const u32 c = (u32)__builtin_amdgcn_readlane((int)c_l, (int)pi);
-      const u64 o = ((u64)(u32)__builtin_amdgcn_readlane((int)(o_l >> 32), (int)pi) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)o_l, (int)pi);
-      const Tup* __restrict__ base = slabs + (pb + pi) * cap;
-      for (u32 r = (u32)lane; r < c; r += kWave) store_stream(&out[o + r], load_stream(&base[r]));
-    }
-  }
+  walk_pieces(cnt, off, n_pieces, ppw, [&](u64 piece, u32 r, u64 o) { store_stream(&out[o + r], load_stream(&slabs[piece * cap + r])); });
 }
 
 // ---- the rank-run form (round 5): ordered result of a small build side under a probe side of fan-out ~32 ... ~1700 ------

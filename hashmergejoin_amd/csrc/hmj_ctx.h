@@ -65,6 +65,29 @@ struct WorkloadMemo {
 
 }  // namespace hmj_host
 
+namespace hmj_host {
+// The constants of the cost model that chooses, for an ordered join of a small build side under a long probe side, between
+// the partitioned one-pass ordered write and the forms that order through the key's rank (api.hip, try_small_build_ordered).
+// ALL of them are fits to sweeps on MI355X boxes (profiles/r04i_*, r04l_*, r04p_*, r04u_*, r05k_*): ms per join =
+// fixed + ns_per_row * probe rows / 10^6 (+ per-run term).  One struct, so that a port to another part re-measures one place
+// (they were literals in three functions); HMJ_ORDERED_MODEL="name=value,..." overrides single fields at
+// hmj_create (developer builds).
+struct OrderedCostModel {
+  // partitioned one-pass ordered write at fan-out f (probe rows per build row)
+  double part_fixed_ms = 0.15;
+  double part_ns = 0.030, part_ns_per_f = 0.00023;                // whole-run ranking: linear in the run (f < 24, or cheaper than the buckets)
+  double part_bucket_ns = 0.043, part_bucket_ns_per_f = 0.0001;  // (build rank, payload position) buckets from f = 24; + per f beyond 128
+  double part_epilogue_ns = 0.25;                                 // f > 700: runs beyond the kernel's partitions, write + order epilogue
+  // (rank, payload) composites sorted by global LSD passes
+  double comp_fixed_ms = 0.65;
+  double comp_ns_chain = 0.060, comp_ns_exact = 0.072;  // passes as a chain of slab passes / exact passes
+  double comp_ns_wide = 0.145;                          // rank and payload as two words (payloads spanning > 64 - rank bits)
+  double comp_ns_beyond_l2 = 0.02;                      // + where the key -> rank table leaves an XCD's L2
+  // rank runs: two slab passes on the rank + an LDS sort per run
+  double runs_fixed_ms = 0.25, runs_ns = 0.0215, runs_ns_per_run = 7.5;
+};
+}  // namespace hmj_host
+
 struct hmj_ctx {
   using DevBuf = hmj_host::DevBuf;
   using HostBuf = hmj_host::HostBuf;
@@ -88,6 +111,7 @@ struct hmj_ctx {
   WorkloadMemo* wm = &memo_init;
   uint64_t wm_sig = 0;
   hmj_plan_desc plan;       // hmj_last_plan: how the last join was planned and why
+  hmj_host::OrderedCostModel ordered_model;
   int force_bits = -1;
   int prefix_bits = -1;  // top key bits known to be constant; -1 = sample the relations (default)
   int min_prefix_bits = 0;  // with sampling: the partition window starts at or below this many top bits (internal: exchange rounds)
