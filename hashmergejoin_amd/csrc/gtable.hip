@@ -935,37 +935,6 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
   block_accumulate(red, accum, v, 1u << ACC_XOR);
 }
 
-// off[i] = in[0] + ... + in[i - 1], off[n] = total: ONE workgroup, a contiguous share per thread (two passes over values that
-// stay in L2) -- 2^16 ... 2^18 partition totals in ~20 us (scan_u64_kernel walks them 1024 at a time behind three barriers
-// each: 0.19 ms for 2^17, profiles/r05a_fk22_ord_summary.txt)
-__global__ __launch_bounds__(1024) void scan_chunked_u64_kernel(const u64* __restrict__ in, u64* __restrict__ off, u32 n) {
-  __shared__ u64 wtot[16];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const u32 per = (n + 1023u) / 1024u, b = (u32)tid * per, e = b + per < n ? b + per : n;
-  u64 s = 0;
-  for (u32 i = b; i < e; i++) s += in[i];
-  u64 incl = s;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    const u64 up = __shfl_up(incl, o, kWave);
-    if (lane >= o) incl += up;
-  }
-  if (lane == kWave - 1) wtot[wv] = incl;
-  __syncthreads();
-  u64 before = 0, all = 0;
-  for (int w2 = 0; w2 < 16; w2++) {
-    if (w2 < wv) before += wtot[w2];
-    all += wtot[w2];
-  }
-  u64 run = before + incl - s;
-  for (u32 i = b; i < e; i++) {
-    const u64 v = in[i];
-    off[i] = run;
-    run += v;
-  }
-  if (tid == 0) off[n] = all;
-}
-
 // off[p] = rows of the slab partitions 0 .. p - 1 (each partition SLAB_KB piece counts, one 16-byte load), off[P] = all rows.
 // Two small launches over ceil(P / 1024) workgroups: chunk totals, then every workgroup adds up the totals before its chunk
 // (<= 256 values) and scans its 1024 partitions.  (ONE workgroup for the whole array pulled 2 MB through one CU: 0.07-0.11 ms
@@ -1039,12 +1008,6 @@ hipError_t launch_slab_offsets(const u32* cnt, u32 P, u64* off, u64* scratch, hi
   const u32 chunks = (P + SO_CHUNK - 1) / SO_CHUNK;
   hipLaunchKernelGGL(slab_totals_kernel, dim3(chunks), dim3(256), 0, st, cnt, P, scratch);
   hipLaunchKernelGGL(slab_offsets_kernel, dim3(chunks), dim3(256), 0, st, cnt, P, scratch, chunks, off);
-  return hipGetLastError();
-}
-
-hipError_t launch_scan_chunked_u64(const u64* in, u64* off, u32 n, hipStream_t st) {
-  if (!in || !off || n == 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(scan_chunked_u64_kernel, dim3(1), dim3(1024), 0, st, in, off, n);
   return hipGetLastError();
 }
 
