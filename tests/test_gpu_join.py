@@ -1220,6 +1220,66 @@ def test_what_one_workload_teaches_the_planner_does_not_change_anothers_plan(ex_
     assert run_a()["attempts"] == 2  # (forgotten: asked again)
 
 
+def test_configs4_shaped_and_uniform_joins_interleaved_keep_their_solo_plans(ex_fresh, H):
+    # VERDICT r4 #3, literally: BASELINE configs[4]'s shape scaled down (a Zipf(0.9) build side of 2^20 rows over 2^20 values, 2^26
+    # probe rows uniform over the domain: count and first-wins) interleaved on ONE context with the 5 * 10^8 x 5 * 10^8 shape
+    # scaled down (2^23 x 2^23 uniform rows).  Each workload's plan -- every field of hmj_last_plan -- must equal the one it
+    # gets alone on a fresh context, whatever the other one did in between, and the results must be right every time (closed
+    # forms in the generators' rank domain, tools/closed_forms.py; the uniform join's by construction).
+    import torch
+
+    from tools.closed_forms import config5_checks
+
+    nb, npb, theta, nu = 1 << 20, 1 << 26, 0.9, 1 << 23
+    w = 1.0 / np.arange(1, nb + 1, dtype=np.float64) ** theta
+    cdf = np.cumsum(w) / w.sum()
+    thr = np.empty(nb, np.uint64)
+    big = cdf >= 1.0 - 2.0 ** -53
+    thr[~big] = (cdf[~big] * 2.0 ** 64).astype(np.uint64)
+    thr[big] = np.uint64(M64)
+    thr[-1] = np.uint64(M64)
+    thr_dev = torch.from_numpy(thr.view(np.int64).copy()).cuda()
+    want = config5_checks(torch, nb, npb, nb, thr_dev)
+    fields = ("path", "radix_bits", "radix_passes", "pass_bits", "attempts", "refused", "cooling", "workload", "key_window_low", "n_partitions")
+
+    def run(ex, which):
+        if which == "zipf":
+            r = ex.join_device(ex._z[0], ex._z[1], 0)
+            assert {k: int(getattr(r, k)) for k in ("n_matches", "sum_r", "sum_s")} == want["cross"]
+        elif which == "zipf_first":
+            r = ex.join_device(ex._z[0], ex._z[1], H.HMJ_FIRST_WINS | H.HMJ_SUM_PROBE)
+            assert {k: int(getattr(r, k)) for k in ("n_matches", "sum_r", "sum_s")} == want["first_wins"]
+            assert int(r.sum_probe_all) == want["sum_probe_all"]
+        else:
+            r = ex.join_device(ex._u[0], ex._u[1], 0)
+            assert int(r.n_matches) == nu and int(r.sum_r) == (nu * (nu - 1) // 2) % (1 << 64)
+        p = ex.last_plan()
+        return {k: p[k] for k in fields}
+
+    def prepare(ex):
+        ex._z = (ex.gen_from_cdf(nb, thr_dev), ex.gen_uniform_domain(npb, nb))
+        ex._u = (ex.gen_build(nu), ex.gen_probe(nu, nu))
+
+    solo = {}
+    for which in ("zipf", "zipf_first", "uniform"):  # each workload alone, twice (the second run: what it has learnt about itself)
+        os.environ["HMJ_SLAB_MIN_LOG2"] = "22"
+        try:
+            e = H.Executor(0)
+        finally:
+            del os.environ["HMJ_SLAB_MIN_LOG2"]
+        prepare(e)
+        solo[which] = [run(e, which), run(e, which)]
+        e.close()
+    ex = ex_fresh
+    prepare(ex)
+    seen = {k: 0 for k in solo}
+    for which in ("zipf", "uniform", "zipf_first", "uniform", "zipf", "zipf_first", "uniform", "zipf"):
+        got = run(ex, which)
+        want_plan = solo[which][min(seen[which], 1)]
+        assert got == want_plan, (which, seen[which], got, want_plan)
+        seen[which] += 1
+
+
 def test_last_plan_is_versioned_by_size(ex, H):
     # hmj_last_plan writes at most struct_size bytes: a caller built against an older, shorter hmj_plan_desc is not overrun
     import ctypes as C
