@@ -1364,12 +1364,21 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
     for nb, npb, miss, pay in [(1, 5000, 0, "ids"), (7, 70000, 0, "ids"), (1000, 300001, 3, "offset"), (5000, 700000, 0, "ids"),
                                (60000, 1 << 23, 4, "offset"), (1000, 200000, 0, "wide"), (1000, 400001, 3, "wide"),
                                (3000, 4500000, 0, "ids"), (3001, 1500000, 5, "wide"), (4000, 1200000, 0, "hot"), (300, 5000, 0, "ids"),
+                               (2000, 700000, 0, "ties7"), (2000, 600001, 3, "const"), (1500, 500000, 0, "extremes"),
                                (3000, 400000, 2, "dupbuild")]:
         B = oracle.gen_build(nb)
         P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
         if pay == "hot":  # a third of the probe rows carry one key: its run is beyond any workgroup
             P[::3, 0] = B[17, 0]
             P[:, 1] = rng.permutation(npb).astype(np.uint64)
+        if pay == "ties7":  # seven payload values: every bucket of the run's cheap sort overflows -> the bitonic network sorts the run
+            P[:, 1] = rng.integers(0, 7, size=npb, dtype=np.uint64) * np.uint64(0x0123456789ABCDEF)
+        elif pay == "const":  # one payload value: nothing to sort inside a run
+            P[:, 1] = np.uint64(0xFFFFFFFFFFFFFFF0)
+        elif pay == "extremes":  # 0 and 2^64 - 1 inside the runs: no value is free for the network's padding -> composites
+            P[:, 1] = rng.integers(0, 1 << 62, size=npb, dtype=np.uint64)
+            P[::5, 1] = np.uint64(0)
+            P[1::5, 1] = np.uint64(M64)
         if pay == "ids":
             P[:, 1] = rng.permutation(npb).astype(np.uint64)
         elif pay == "offset":
@@ -1385,9 +1394,9 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             t = ex.last_timing()
             took = bool(t["path"] & RS)
             # (payloads spanning all 64 bits go as two words: sorted by payload, then stably by rank)
-            assert took == (pay in ("ids", "offset", "wide", "hot")), (nb, npb, pay, fl, hex(t["path"]))
+            assert took == (pay in ("ids", "offset", "wide", "hot", "ties7", "const", "extremes")), (nb, npb, pay, fl, hex(t["path"]))
             f = npb / nb
-            runs = pay in ("ids", "offset", "wide") and nb >= 4 and npb >= 1 << 16 and f >= 16 and f + 8 * f ** 0.5 + 24 <= 2048
+            runs = pay in ("ids", "offset", "wide", "ties7", "const") and nb >= 4 and npb >= 1 << 16 and f >= 16 and f + 8 * f ** 0.5 + 24 <= 2048
             assert bool(t["path"] & RR) == runs, (nb, npb, pay, fl, hex(t["path"]))
             # every probe row has its build row (miss == 0): the rank lookup runs inside the first slab pass; unmatched
             # probe rows make that attempt give way to emit + pass A (and the workload remembers)
