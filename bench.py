@@ -282,7 +282,9 @@ def extra_runs(ex, H, torch):
         assert bool(((k[1:] ^ top) >= (k[:-1] ^ top)).all()) and int(o[:, 1].sum()) == int(a[:, 1].sum()), name
         out["sort_2p28_%s_keys_ms" % name] = ms
         roof("sort_2p28_%s_keys_ms" % name, ms, 1 << 28, 0, sort=True)
-        out["sort_2p28_%s_path" % name] = "chain of slab passes + compaction" if ex.last_timing()["path"] & H.HMJ_PATH_SLAB else "exact passes"
+        tp = ex.last_timing()["path"]
+        out["sort_2p28_%s_path" % name] = ("MSD: two slab passes on the top %d varying bits + an LDS sort per partition" % ex.last_timing()["radix_bits"] if tp & H._lib.HMJ_PATH_SORT_MSD
+                                           else "chain of slab passes + compaction" if tp & H.HMJ_PATH_SLAB else "exact passes")
         del a, o, k
         torch.cuda.empty_cache()
     # duplicate keys on BOTH sides (outside the reference's domain: its iterator drops matches there): 2^24 rows per side

@@ -65,7 +65,7 @@ uint32_t WorkloadMemo::cooling() const {
          (gtable_sort_slab_cooldown ? HMJ_COOL_RANK_SORT_SLAB : 0u) | (expand_cooldown ? HMJ_COOL_EXPANSION : 0u) |
          (sort_slab_cooldown ? HMJ_COOL_SORT_SLAB : 0u) | (slab_cooldown ? HMJ_COOL_SLAB : 0u) | (slab_probe_cooldown ? HMJ_COOL_SLAB_PROBE : 0u) |
          (one_pass_write_cooldown ? HMJ_COOL_ONE_PASS_WRITE : 0u) | (exact_prefix_joins ? HMJ_COOL_EXACT_PREFIX : 0u) |
-         (rank_runs_cooldown ? HMJ_COOL_RANK_RUNS : 0u);
+         (rank_runs_cooldown ? HMJ_COOL_RANK_RUNS : 0u) | (sort_msd_cooldown ? HMJ_COOL_SORT_MSD : 0u);
 }
 
 int wait_arrival(hmj_ctx* c, hipEvent_t ev) {
@@ -2596,6 +2596,11 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_RANK_RUNS")) c->rank_runs_mode = atoi(e) != 0;  // 0: ordered small-build joins always sort composites
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
+  if (const char* e = getenv("HMJ_SORT_MSD")) c->sort_msd = atoi(e) != 0;  // 0: hmj_sort_u64_device never takes its MSD form (two slab passes + an LDS sort per partition)
+  if (const char* e = getenv("HMJ_SORT_MSD_MIN_LOG2")) {
+    const int l = atoi(e);
+    if (l >= 16 && l <= 32) c->sort_msd_min = 1ull << l;
+  }
   if (const char* e = getenv("HMJ_SORT_SLAB_MIN_LOG2")) {
     const int l = atoi(e);
     if (l >= 12 && l <= 32) c->sort_slab_min = 1ull << l;
@@ -3186,6 +3191,82 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
   // are sized for the share of its values in use; digits that are not evenly filled overflow a slab -> the exact passes below
   // (the input is untouched: the chain writes only its own buffers), and the chain is left alone for the next 8 sorts.
   bool chained = false;
+  // Round 5, out-of-place sorts from 2^22 rows on: MSD.  The join's two slab passes partition the rows on the TOP 12 ... 18
+  // varying key bits, one workgroup per partition sorts its run on the remaining bits in LDS and writes it at the partition's
+  // offset (gtable.hip, sort_runs_write_kernel): 3 x 32 B per row whatever the key width, against one 32-byte pass per varying
+  // digit + a compaction in the chain below (uniform 64-bit keys: 9 x 32 B).  The window's top is the highest bit in which
+  // keys differ (exact), or bit 63 when only the sample is known; partitions hold ~1000 rows and at most 2048.  Keys that
+  // crowd into few partitions, or runs with many equal keys, raise an error word: the input is untouched, the chain runs,
+  // and this size is left alone for 8 sorts.
+  if (c->wm->sort_msd_cooldown > 0) c->wm->sort_msd_cooldown--;
+  else if (c->sort_msd && c->slab_mode && out_aos_dev != in_aos_dev && n >= c->sort_msd_min && n < 0xFFFFFFF0ull) {
+    const bool exact = diff != ~0ull;
+    const int hi = exact ? (diff ? 64 - __builtin_clzll(diff) : 0) : 64;  // keys agree in every bit from `hi` up
+    // how much of the window's top digit is in use: exact -> from the extremes; sampled -> a top bit the sample never saw
+    // varying halves it (63-bit keys)
+    // the narrowest window whose partitions average <= 1200 rows, counting that the keys may fill only part of it
+    int TB = 1;
+    double dens = 1.0, mean = (double)n;
+    do {
+      TB++;
+      if (TB > hi) break;
+      if (exact) {
+        const u64 in_use = (kmax >> (hi - TB)) - (kmin >> (hi - TB)) + 1;
+        dens = std::ldexp(1.0, TB) / (double)in_use;
+      } else if (sdiff != ~0ull) {
+        dens = std::ldexp(1.0, __builtin_clzll(sdiff));  // (the sample's top varying bit is below bit 63)
+        if (dens > 64.0) dens = 64.0;
+      }
+      mean = dens * (double)n / std::ldexp(1.0, TB);
+    } while (TB < 18 && mean > 1200.0);
+    if (TB > hi) TB = 0;
+    const int bb = TB / 2, ba = TB - bb, shift_a = hi - TB, shift_b = shift_a + ba;
+    hmj::SlabGeom g;
+    if (TB >= 2 && ba <= hmj::SLAB_MAX_BITS && mean + 8.0 * std::sqrt(mean) + 24.0 <= (double)hmj::rank_sort_max_run() &&
+        hmj::slab_geometry((u32)n, ba, bb, &g, 0, 1.0, dens)) {
+      const u32 P = 1u << TB;
+      if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+      if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->slab_a, g.rows_a * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_a, ((size_t)g.WA << ba) * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->slab_bs, g.rows_b * 16)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->cnt_bs, (size_t)P * g.KB * 4)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->part_out_off, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
+      if ((rc = ensure_dev(c, c->part_count, ((size_t)P / 1024 + 1) * 8)) != HMJ_OK) return rc;
+      u64* acc = (u64*)c->accum.p;
+      u64* hh = (u64*)c->h_accum.p;
+      HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+      int sp = span_begin(c, K_SCATTER, -1, 0);
+      HIP_TRY(hmj::launch_slab_a(in_aos_dev, (u32)n, shift_a, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->stream));
+      span_end(c, sp);
+      sp = span_begin(c, K_SCATTER, -1, 1);
+      HIP_TRY(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, shift_b, bb, g, c->slab_bs.p, c->slab_bs.cap / 16, (u32*)c->cnt_bs.p,
+                                 c->cnt_bs.cap / 4, acc, c->stream));
+      span_end(c, sp);
+      HIP_TRY(hmj::launch_slab_offsets((const u32*)c->cnt_bs.p, P, (u64*)c->part_out_off.p, (u64*)c->part_count.p, c->stream));
+      sp = span_begin(c, K_ORDER, -1);
+      HIP_TRY(hmj::launch_sort_runs_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, out_aos_dev, acc, c->num_cus,
+                                          c->stream));
+      span_end(c, sp);
+      HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (hh[hmj::ACC_ERR] & (hmj::ERR_SLAB | hmj::ERR_FASTPATH)) {
+        c->wm->sort_msd_cooldown = 8;
+        HIP_TRY(hipMemsetAsync((u64*)c->accum.p + hmj::ACC_ERR, 0, sizeof(u64), c->stream));
+        std::vector<Span> keep;
+        c->spans.swap(keep);
+        if (c->trace) std::fprintf(stderr, "[hmj] sort n=%llu: MSD form gave up (%s) -> chain of LSD passes\n", (unsigned long long)n,
+                                   (hh[hmj::ACC_ERR] & hmj::ERR_SLAB) ? "a slab overflowed" : "a run beyond the kernel, or many equal keys");
+      } else {
+        c->timing.bytes_scatter += 2 * 32ull * n;
+        c->timing.path |= HMJ_PATH_SLAB | HMJ_PATH_SORT_MSD;
+        c->timing.radix_bits = TB;
+        c->timing.radix_passes = 2;
+        if (c->profiling) spans_collect(c);
+        return HMJ_OK;
+      }
+    }
+  }
   if (c->wm->sort_slab_cooldown > 0) c->wm->sort_slab_cooldown--;
   else if (k >= 2 && c->slab_mode && c->sort_slab && n >= c->sort_slab_min && n < 0xFFFFFFF0ull) {
     // exact: `diff` holds every bit in which keys differ (digits are trimmed to them).  Otherwise the sample saw all eight

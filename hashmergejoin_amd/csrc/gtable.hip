@@ -711,10 +711,14 @@ __device__ __attribute__((noinline)) void rs_bitonic(K* __restrict__ s, u32 N, i
 // network alone was 0.7 ms of VALU time at 2^26 rows, and a run of 1025 keys paid for 2048).  Payloads that tie or cluster
 // make long buckets: beyond RS_MAXBUCKET keys in one the function returns false and the network sorts the run.
 // tmp: n keys; idx: n 16-bit slots; cnt: NB + 1 words.  On success the i-th smallest key is tmp[idx[i]].  All threads call it.
+// STABLE: equal keys keep the order of their positions i in the run (oidx: n 16-bit slots; without it ties are broken by
+// the order the atomics happened to number them -- fine where only the keys are of interest).  slot_out[r]: where the
+// thread's r-th key was put in tmp (the caller moves the keys' payloads through the same slots).
 constexpr u32 RS_MAXBUCKET = 24;
-template <typename K>
+template <typename K, bool STABLE = false>
 __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, u64 range, u32 n, K* __restrict__ tmp, unsigned short* __restrict__ idx,
-                                               u32* __restrict__ cnt, u32* __restrict__ wsc, int tid) {
+                                               u32* __restrict__ cnt, u32* __restrict__ wsc, int tid, unsigned short* __restrict__ oidx = nullptr,
+                                               u32* slot_out = nullptr) {
   const int lane = tid & 63, wv = tid >> 6;
   u32 NB = RS_THREADS;
   while (NB < n) NB <<= 1;
@@ -780,7 +784,12 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
 #pragma unroll
   for (int r = 0; r < RS_EPT; r++) {
     const u32 i = (u32)tid + (u32)r * RS_THREADS;
-    if (i < n) tmp[cnt[bk[r]] + ar[r]] = (K)(sv[r] - mn);
+    if (i < n) {
+      const u32 me = cnt[bk[r]] + ar[r];
+      tmp[me] = (K)(sv[r] - mn);
+      if (STABLE) oidx[me] = (unsigned short)i;
+      if (slot_out) slot_out[r] = me;
+    }
   }
   lds_barrier();
 #pragma unroll
@@ -792,7 +801,8 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
       u32 rank = 0;
       for (u32 t = s0; t < e0; t++) {
         const K kt = tmp[t];
-        rank += (kt < key || (kt == key && t < me)) ? 1u : 0u;
+        const bool before = STABLE ? (u32)oidx[t] < i : t < me;
+        rank += (kt < key || (kt == key && before)) ? 1u : 0u;
       }
       idx[s0 + rank] = (unsigned short)me;
     }
@@ -1008,6 +1018,140 @@ hipError_t launch_slab_offsets(const u32* cnt, u32 P, u64* off, u64* scratch, hi
   const u32 chunks = (P + SO_CHUNK - 1) / SO_CHUNK;
   hipLaunchKernelGGL(slab_totals_kernel, dim3(chunks), dim3(256), 0, st, cnt, P, scratch);
   hipLaunchKernelGGL(slab_offsets_kernel, dim3(chunks), dim3(256), 0, st, cnt, P, scratch, chunks, off);
+  return hipGetLastError();
+}
+
+// ---- hmj_sort_u64_device, round 5: two MSD slab passes + this kernel -------------------------------------------------------
+// The LSD chain moves every row through one pass per varying digit (nine passes of 32 B for uniform 64-bit keys).  The
+// reference's own sort is MSD (radix_hash.h:202-292: partition on the top bits, recurse into the buckets, insertion-sort the
+// small ones); so is this: the join's two slab passes partition the rows on the top 12 ... 18 varying key bits (LSD inside
+// that window, so partition p = the window's value, pieces in input order), and one workgroup per partition sorts its run
+// of <= 2048 rows on the REMAINING low bits in LDS -- the bucket-rank sort above, stable (ties by position in the run = input
+// order, as the passes are stable), 32-bit keys where the run spans < 2^32 -- and writes the rows at the partition's offset:
+// 3 x 32 B per row whatever the key width.  A run beyond the kernel or a bucket of > 24 equal / clustered keys raises
+// ERR_FASTPATH: the output is garbage, the host runs the chain from the untouched input (out-of-place calls only).
+__global__ __launch_bounds__(RS_THREADS, 4) void sort_runs_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap, u32 P,
+                                                                        const u64* __restrict__ out_off, Tup* __restrict__ out,
+                                                                        u64* __restrict__ accum) {
+  __shared__ __attribute__((aligned(16))) u64 keys[RS_CAP];  // the run's keys by bucket slot, later its payloads by the same slots
+  __shared__ unsigned short sidx[RS_CAP], oidx[RS_CAP];
+  __shared__ u32 bcnt[RS_CAP + 1];
+  __shared__ u32 wsc[2 * (RS_THREADS / kWave)];
+  __shared__ u64 wmn[RS_THREADS / kWave], wmx[RS_THREADS / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  bool bad = false;
+  for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
+    const u32* q = cnt + (u64)p * SLAB_KB;
+    const u32 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+    const u32 n = c0 + c1 + c2 + c3;
+    if (n == 0) continue;
+    if (n > (u32)RS_CAP || c0 > cap || c1 > cap || c2 > cap || c3 > cap) {  // (uniform)
+      bad = true;
+      continue;
+    }
+    const Tup* __restrict__ base = slabs + (u64)p * SLAB_KB * cap;
+    u64 kv[RS_EPT], pv[RS_EPT];
+    u64 mn = ~0ull, mx = 0;
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+      const u32 i = (u32)tid + (u32)r * RS_THREADS;
+      kv[r] = pv[r] = 0;
+      if (i < n) {
+        const u32 k = i < c0 ? 0u : i < c0 + c1 ? 1u : i < c0 + c1 + c2 ? 2u : 3u;
+        const u32 start = k == 0 ? 0u : k == 1 ? c0 : k == 2 ? c0 + c1 : c0 + c1 + c2;
+        const Tup t = load_stream(&base[(u64)k * cap + (i - start)]);
+        kv[r] = t.key;
+        pv[r] = t.val;
+        mn = kv[r] < mn ? kv[r] : mn;
+        mx = kv[r] > mx ? kv[r] : mx;
+      }
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      const u64 a2 = __shfl_xor(mn, o, kWave), b2 = __shfl_xor(mx, o, kWave);
+      mn = a2 < mn ? a2 : mn;
+      mx = b2 > mx ? b2 : mx;
+    }
+    if (lane == 0) {
+      wmn[wv] = mn;
+      wmx[wv] = mx;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int w = 0; w < RS_THREADS / kWave; w++) {
+      mn = wmn[w] < mn ? wmn[w] : mn;
+      mx = wmx[w] > mx ? wmx[w] : mx;
+    }
+    const u64 range = mx - mn;
+    const u64 off = out_off[p];
+    u32 slot[RS_EPT];
+    bool sorted_ok = true;
+    if (range == 0) {  // one key in the whole run: input order is the sorted order
+#pragma unroll
+      for (int r = 0; r < RS_EPT; r++) {
+        const u32 i = (u32)tid + (u32)r * RS_THREADS;
+        if (i < n) {
+          Tup t;
+          t.key = kv[r];
+          t.val = pv[r];
+          store_stream(&out[off + i], t);
+        }
+      }
+      lds_barrier();
+      continue;
+    } else if (range < 0xFFFFFFFFull) {
+      u32* k32 = reinterpret_cast<u32*>(keys);
+      sorted_ok = rs_bucket_sort<u32, true>(kv, mn, range, n, k32, sidx, bcnt, wsc, tid, oidx, slot);
+      if (sorted_ok) {
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) {
+          const u32 i = (u32)tid + (u32)r * RS_THREADS;
+          if (i < n) kv[r] = (u64)k32[sidx[i]] + mn;
+        }
+      }
+    } else {
+      sorted_ok = rs_bucket_sort<u64, true>(kv, mn, range, n, keys, sidx, bcnt, wsc, tid, oidx, slot);
+      if (sorted_ok) {
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) {
+          const u32 i = (u32)tid + (u32)r * RS_THREADS;
+          if (i < n) kv[r] = keys[sidx[i]] + mn;
+        }
+      }
+    }
+    if (!sorted_ok) {  // (uniform) ties or clustered keys: the host takes the chain
+      bad = true;
+      continue;
+    }
+    lds_barrier();  // every thread has read its sorted keys: the array now carries the payloads, by the same slots
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+      const u32 i = (u32)tid + (u32)r * RS_THREADS;
+      if (i < n) keys[slot[r]] = pv[r];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+      const u32 i = (u32)tid + (u32)r * RS_THREADS;
+      if (i < n) {
+        Tup t;
+        t.key = kv[r];
+        t.val = keys[sidx[i]];
+        store_stream(&out[off + i], t);
+      }
+    }
+    lds_barrier();
+  }
+  if (bad && tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
+}
+
+hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, void* out, u64* accum, int num_cus,
+                                  hipStream_t st) {
+  if (!slabs || !cnt || !out_off || !out || !accum || P == 0 || cap == 0) return hipErrorInvalidValue;
+  u32 grid = (u32)num_cus * 4u;  // what is resident at once (launch bounds; 32 KiB of LDS per workgroup)
+  if (grid > P) grid = P;
+  hipLaunchKernelGGL(sort_runs_write_kernel, dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
+                     static_cast<Tup*>(out), accum);
   return hipGetLastError();
 }
 

@@ -55,6 +55,7 @@ struct WorkloadMemo {
   int rank_lookup_cooldown = 0;     // ... its rank lookup inside pass A (after a probe row without a build row)
   int expand_cooldown = 0;          // ordered expansion (after a partition did not fit the kernel)
   int sort_slab_cooldown = 0;       // hmj_sort_u64_device: chain of slab passes (after a slab overflowed: skewed digits)
+  int sort_msd_cooldown = 0;        // ... its MSD form (after keys crowded into few partitions, or runs of equal keys)
   int slab_cooldown = 0;            // histogram-free slab partitioning of both sides (after a slab overflowed: skewed keys)
   int slab_probe_cooldown = 0;      // ... of the probe side only (probe-heavy count joins, one-pass slab walk)
   int one_pass_write_cooldown = 0;  // materialising on the one-pass slab walk (after duplicate build keys)
@@ -164,6 +165,8 @@ struct hmj_ctx {
   u32 expand_fk_fanout = 0;        // ordered foreign-key joins (unique build keys) take the expansion from this fan-out on (HMJ_EXPAND_FK_FANOUT; 0: never)
   bool expand_allow_rebits = true;  // (false during the retry that already took one more bit)
   int expand_rebits = 0;            // the bits that retry plans         // ordered joins to keep on write + sort after a partition did not fit the expansion kernel
+  bool sort_msd = true;            // hmj_sort_u64_device, out of place: two MSD slab passes + an LDS sort per partition (HMJ_SORT_MSD=0: the LSD chain)
+  u64 sort_msd_min = 1ull << 22;   // ... from this many rows on (HMJ_SORT_MSD_MIN_LOG2)
   bool sort_slab = true;           // hmj_sort_u64_device: LSD passes as a chain of slab passes + one compaction (HMJ_SORT_SLAB=0: exact passes)
   u64 sort_slab_min = 1ull << 25;  // ... from this many rows on (HMJ_SORT_SLAB_MIN_LOG2)
   int slab_mode = 1;      // 1 = try the histogram-free slab path for plain count joins (HMJ_SLAB=0 disables)

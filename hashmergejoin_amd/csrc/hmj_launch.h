@@ -161,6 +161,10 @@ hipError_t launch_gtable_swap(const void* in, void* out, u64 n, int num_cus, hip
 hipError_t launch_gtable_emit_ranks(const void* S, u32 np, const void* tab, int log_cap, u64* accum, void* pairs, bool extra, int num_cus,
                                     int wg_per_cu, hipStream_t st);
 int rank_sort_max_run();
+// hmj_sort_u64_device's MSD form: the rows partitioned on their top varying key bits by two slab passes (partition p = four
+// pieces of `cap` rows, counts cnt[p * 4 ..]), every partition sorted on the remaining bits in LDS (stable) and written at out_off[p]
+hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, void* out, u64* accum, int num_cus,
+                                  hipStream_t st);
 hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb,
                                   u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st);
 hipError_t launch_slab_a_ranks(const void* in, u32 n, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,

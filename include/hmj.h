@@ -125,6 +125,7 @@ typedef struct {
 #define HMJ_PATH_ORDER_BY_RANK_SORT 0x200000u /* ordered, small build side under a long probe side: rows sorted as (key rank, payload) composites */
 #define HMJ_PATH_RANK_RUNS 0x1000000u /* ... where every key's run of probe rows fits one workgroup: rows partitioned by key rank (two slab passes), each run sorted in LDS */
 #define HMJ_PATH_RANK_LOOKUP_IN_PASS 0x2000000u /* ... with the key -> rank lookup inside the first slab pass (every probe row had its build row) */
+#define HMJ_PATH_SORT_MSD 0x4000000u /* hmj_sort_u64_device: two slab passes on the top varying key bits + an LDS sort of every partition */
 #define HMJ_PATH_ORDERED_EXPANSION 0x400000u /* ordered, duplicate build keys: rows written in order partition by partition (no sort of result rows) */
 #define HMJ_PATH_LDS_TABLE 0x800000u /* ... of <= 2048 build rows (1024 with HMJ_CHECKSUM / HMJ_SUM_PROBE) under >= 2^16 probe rows, count modes: that table in LDS, one copy per workgroup */
 #define HMJ_PATH_GLOBAL_TABLE 0x100000u /* small build side: one global hash table, the probe side streamed unpartitioned */
@@ -180,6 +181,7 @@ typedef struct {
 #define HMJ_COOL_ONE_PASS_WRITE 0x400u
 #define HMJ_COOL_EXACT_PREFIX 0x800u
 #define HMJ_COOL_RANK_RUNS 0x1000u
+#define HMJ_COOL_SORT_MSD 0x2000u
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* Replaces: nothing in the reference (no device); one ctx per GPU. device_id < 0 = current.     */
@@ -482,9 +484,12 @@ int hmj_partition_u64_device(hmj_ctx* ctx, const void* in_aos_dev, uint64_t n, i
 /* ---- full radix sort ------------------------------------------------------------ */
 /* Replaces radix_int_non_inplace<uint64_t,uint64_t>(begin, end, dst, num_threads)
  * (radix_sort.h:452-522) -- the call radix_bench_par.cc:126-127 times: rows sorted by key, ascending,
- * out of place.  Stable LSD passes over the 8-bit digits in which keys differ (write-combining scatter; from
- * 2^25 rows on histogram-free slab passes chained one into the next + one compaction); equal keys keep their
- * input order (the reference is stable in pass 1 only, so on duplicate keys its payload order may
+ * out of place.  From 2^22 rows on (out != in): MSD, as the reference's own sort is (radix_hash.h:202-292) -- two
+ * histogram-free slab passes on the top 12 ... 18 varying key bits, every partition sorted on the remaining bits in LDS
+ * (HMJ_PATH_SORT_MSD: 3 x 32 B per row whatever the key width); otherwise, or where the keys crowd into few partitions:
+ * stable LSD passes over the 8-bit digits in which keys differ (write-combining scatter; from 2^25 rows on
+ * histogram-free slab passes chained one into the next + one compaction).  Equal keys keep their
+ * input order in every form (the reference is stable in pass 1 only, so on duplicate keys its payload order may
  * differ; the key column and the multiset of rows are identical).  in/out: n x {key,val}, device.
  * out == in sorts in place -- the replacement of radix_int_inplace<uint64_t,uint64_t>(begin, n,
  * num_threads) (radix_sort.h:333-398; radix_bench_par.cc:96), which is unstable: same key column, same

@@ -926,6 +926,50 @@ def test_sort_skips_the_digits_no_key_differs_in(ex, shape):
     assert np.array_equal(to_np(ex.sort_device(d, inplace=True)), want)
 
 
+def test_sort_msd_two_slab_passes_and_an_lds_sort_per_partition(H):
+    # hmj_sort_u64_device out of place, from 2^22 rows on (round 5): the rows are partitioned on their top varying key bits by
+    # the join's two slab passes and every partition (~1000 rows) is sorted on the remaining bits in LDS, stably
+    # (HMJ_PATH_SORT_MSD).  Against numpy's stable sort: uniform 64-bit keys, 63-bit keys (half of the top digit), a
+    # permutation of 0 .. n - 1 and the same with a large offset (the window sits on the bits that vary), ~2 and ~16 rows per
+    # key (equal keys keep their input order), keys from five values / all equal / sorted input (partitions or slabs overflow,
+    # or nothing to partition on: the chain or the exact passes answer, same rows), then the workload remembers.
+    ex = H.Executor(0)
+    MSD = H.HMJ_PATH_SORT_MSD
+    rng = np.random.default_rng(17)
+    n = (1 << 22) + 4099
+    shapes = {
+        "uniform": (rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64), True),
+        "63bit": (rng.integers(0, 1 << 63, n, dtype=np.uint64), True),
+        "dense": (rng.permutation(n).astype(np.uint64), True),
+        "dense_offset": (rng.permutation(n).astype(np.uint64) + np.uint64(0x123456789A000000), True),
+        "duplicates": (rng.integers(0, 1 << 63, 1 << 21, dtype=np.uint64)[rng.integers(0, 1 << 21, n)], True),
+        "many_duplicates": (rng.integers(0, 1 << 63, 1 << 18, dtype=np.uint64)[rng.integers(0, 1 << 18, n)], None),  # ~16 rows per key, some keys > 24:
+        # a bucket of the in-run sort overflows somewhere -> the chain answers (either way: the same rows, equal keys in input order)
+        "few_values": (rng.integers(0, 5, n).astype(np.uint64) * np.uint64(0x0101010101010101), False),
+        "all_equal": (np.full(n, 0xABCDEF, dtype=np.uint64), False),
+        "sorted": (np.sort(rng.integers(0, 1 << 63, n, dtype=np.uint64)), None),  # (a worker sees one digit only: its slab overflows)
+    }
+    for name, (keys, msd) in shapes.items():
+        ex.forget_workloads()
+        a = np.stack([keys, np.arange(n, dtype=np.uint64)], 1)
+        want = a[np.argsort(keys, kind="stable")]
+        got = to_np(ex.sort_device(to_dev(a)))
+        took = bool(ex.last_timing()["path"] & MSD)
+        if msd is not None:
+            assert took == msd, (name, hex(ex.last_timing()["path"]))
+        assert np.array_equal(got, want), name
+        if msd is False and name == "few_values":  # the size remembers: no second attempt for its next sorts
+            got = to_np(ex.sort_device(to_dev(a)))
+            assert not ex.last_timing()["path"] & MSD and np.array_equal(got, want)
+    # in place (radix_int_inplace's replacement) keeps the chain: the MSD form reads its input while it writes the output
+    a = np.stack([shapes["uniform"][0], np.arange(n, dtype=np.uint64)], 1)
+    d = to_dev(a)
+    ex.sort_device(d, inplace=True)
+    assert not ex.last_timing()["path"] & MSD
+    assert np.array_equal(to_np(d)[:, 0], np.sort(a[:, 0]))
+    ex.close()
+
+
 def test_sort_as_a_chain_of_slab_passes(H):
     # hmj_sort_u64_device from 2^25 rows on (here: from 2^20, HMJ_SORT_SLAB_MIN_LOG2): its LSD passes are histogram-free
     # slab passes chained one into the next, the last pass's pieces compacted into the output.  Uniform 64-bit keys (eight
@@ -935,10 +979,11 @@ def test_sort_as_a_chain_of_slab_passes(H):
     # passes, same order, and the
     # chain is left alone for 8 sorts.
     os.environ["HMJ_SORT_SLAB_MIN_LOG2"] = "20"
+    os.environ["HMJ_SORT_MSD"] = "0"  # (out-of-place sorts of this size take the MSD form since round 5: this test is about the chain)
     try:
         ex = H.Executor(0)
     finally:
-        del os.environ["HMJ_SORT_SLAB_MIN_LOG2"]
+        del os.environ["HMJ_SORT_SLAB_MIN_LOG2"], os.environ["HMJ_SORT_MSD"]
     SL = H.HMJ_PATH_SLAB
     rng = np.random.default_rng(13)
     n = (1 << 22) + 4099
