@@ -2060,24 +2060,55 @@ static int slab_chain(hmj_ctx* c, const void* dense_in, u32 n, const ChainDigit*
 // shapes: 2^16 x 2^26 rows 14-22 ms, 2^10 x 2^22 6 ms.  Anything else -- duplicate build keys, payloads too wide, a table
 // that gives up -- leaves *done false and the partitioned paths run (8 joins of cool-down).
 // ns per probe row of the partitioned one-pass ordered foreign-key write at fan-out f (profiles/r04u_side_fk_payload_buckets.txt)
-static double ordered_part_ns(const OrderedCostModel& m, double f) {
+static double ordered_part_ns(const OrderedCostModel& m, double f, double n_probe) {
   if (f > 700.0) return m.part_epilogue_ns;  // (runs beyond the kernel's partitions: write + order epilogue)
+  // ... and so are a few keys too many in one partition of the finest plan there is (18 bits): 2^19 x 2^28 rows -- two keys
+  // of 512 probe rows per partition on average, twelve in the fullest of 2^18 -- overflowed the write's 6144-row shape,
+  // the exact path took over with the order epilogue: 137 ms, against 19 ms on the composites and 15 ms for 2^20 x 2^28
+  // (profiles/r05s_*).  The plan's own estimate of the fullest partition (fk_probe_rows_hi) says when.
+  const double P18 = (double)(1u << (2 * hmj::SLAB_MAX_BITS));
+  if (fk_probe_rows_hi(n_probe / P18, f, P18) > 6144.0) return m.part_epilogue_ns;
   const double lin = m.part_ns + m.part_ns_per_f * f;
   if (f < 24.0) return lin;
   const double bucketed = m.part_bucket_ns + (f > 128.0 ? m.part_bucket_ns_per_f * (f - 128.0) : 0.0);
   return lin < bucketed ? lin : bucketed;
 }
-// The rank-run form (gtable.hip): every rank's run of probe rows must fit one workgroup's LDS sort with room for its
-// spread (mean + 8 sigma of a run of a uniform foreign key), both digits of the rank must be slab passes, and the runs
-// must be long enough for a workgroup per rank to pay.
-static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe) {
-  if (!c->rank_runs_mode || !c->slab_mode || c->wm->rank_runs_cooldown > 0 || n_build < 4 || n_probe > 0xFFFFFFFFull ||
+// The rank-run form (gtable.hip): every partition of probe rows must fit one workgroup's LDS sort with room for its
+// spread (mean + 8 sigma of a run of a uniform foreign key), both digits of the partition number must be slab passes, and
+// the partitions must be long enough for a workgroup each to pay.  A partition is a rank's whole run up to fan-outs of
+// ~1700 (*tb = 0); beyond, a run is cut into 2^tb partitions by the position of the payload in the payloads' range.
+static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe, int* tb) {
+  *tb = 0;
+  if (!c->rank_runs_mode || !c->slab_mode || n_build < 4 || n_probe > 0xFFFFFFFFull ||
       n_probe < (1u << 16))  // (a slab pass wants a few dozen tiles of rows)
     return false;
   const int rank_bits = 64 - __builtin_clzll(n_build - 1);
   if (rank_bits < 2 || rank_bits > 2 * hmj::SLAB_MAX_BITS) return false;
-  const double f = (double)n_probe / (double)n_build;
-  return f >= 16.0 && f + 8.0 * std::sqrt(f) + 24.0 <= (double)hmj::rank_sort_max_run();
+  double f = (double)n_probe / (double)n_build;
+  if (f < 16.0) return false;
+  int t = 0;
+  while (f + 8.0 * std::sqrt(f) + 24.0 > (double)hmj::rank_sort_max_run()) {
+    f *= 0.5;
+    t++;
+  }
+  if (t > c->rank_runs_max_cut || rank_bits + t > 2 * hmj::SLAB_MAX_BITS) return false;
+  if (t > 0) {
+    // Payloads that grow with the row's position (row ids, timestamps): a worker of pass A reads `places` chunks from all
+    // over the probe side (radix.hip, slab_a_body's strided form), each inside ONE piece; the fullest of its slabs must
+    // still be within a slab's capacity (slab_geometry: mean + 8 sqrt(mean) + 24), or the attempt is known to overflow.
+    const int TB = rank_bits + t, ba = TB - TB / 2;
+    const double tile = ba > 8 ? 4096.0 : 2048.0, tiles = std::ceil((double)n_probe / tile), tpw = std::ceil(tiles / 2048.0);
+    const double rpw = tpw * tile, places = rpw / (double)hmj::RANK_PASS_CHUNK_ROWS, pieces = (double)(1u << t);
+    const double skew = places >= pieces ? std::ceil(places / pieces) / (places / pieces) : pieces / places;
+    const double mean = rpw / (double)(1u << ba);
+    if (skew * mean + 4.0 * std::sqrt(skew * mean) > mean + 8.0 * std::sqrt(mean) + 24.0) return false;
+  }
+  *tb = t;
+  return true;
+}
+// (what a workload's memo says on top: the form rests after it gave up; cut runs exist only with the lookup inside pass A)
+static bool rank_runs_rested(const hmj_ctx* c, int tb) {
+  return c->wm->rank_runs_cooldown == 0 && (tb == 0 || c->wm->rank_lookup_cooldown == 0);
 }
 
 int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
@@ -2099,7 +2130,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     //  0.043 ns per row up to fan-out ~130, + 0.0001 per further probe row per key -- 2^18 x 2^26: 7.5 -> 3.9 ms, 2^20 x 2^28:
     //  29.3 -> 15.8 -- so this path is now for fan-outs beyond ~500 and for runs the kernel's partitions cannot hold)
     const OrderedCostModel& m = c->ordered_model;
-    const double part_ns = ordered_part_ns(m, f);
+    const double part_ns = ordered_part_ns(m, f, (double)n_probe);
     // (round 4, later: 0.060 where the composites' passes are the chain of slab passes below, 0.072 on exact passes, + 0.02
     //  where the table leaves the L2 -- profiles/r04p_side_rank_sort_slab_chain.txt)
     const bool chain = c->gtable_sort_slab && c->slab_mode && c->wm->gtable_sort_slab_cooldown == 0 && n_probe >= c->gtable_sort_slab_min;
@@ -2107,12 +2138,17 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     //  and sorted run by run, rank_runs_fit, whatever the payloads' width;
     //  measured over 2^12 ... 2^18 build x 2^22 ... 2^28 probe rows, profiles/r05k_sweep_ordered_small_build.txt: 0.25 ms of
     //  launches and read-backs + 0.0215 ns per probe row + 7.5 ns per RUN -- a workgroup's load -> sort -> store chain per key.
-    //  Longer runs stay with the composites: cutting a run by the position of the payload in the payloads' range was tried
-    //  and dropped -- row ids and timestamps are monotone in the row's POSITION, so every worker of a slab pass sees one
-    //  bucket only and its slab for that digit overflows, whichever digit the bucket bits go into)
-    const bool runs = rank_runs_fit(c, n_build, n_probe);
+    //  Longer runs are cut into 2^tb pieces by the position of the payload in the payloads' range.  Row ids and timestamps
+    //  are monotone in the row's POSITION, so a worker of a slab pass that reads one contiguous range of the probe side sees
+    //  one piece only and its slab for that digit overflows, whichever digit the piece bits go into: the pass with the
+    //  lookup reads 4 KiB chunks from all over the relation instead (radix.hip, RankXform::kStrided); + one pass over the
+    //  payloads for their range)
+    int run_tb = 0;
+    const bool runs = rank_runs_fit(c, n_build, n_probe, &run_tb) && rank_runs_rested(c, run_tb);
     const double rank_ns = (chain ? m.comp_ns_chain : m.comp_ns_exact) + (n_build > c->gtable_max_rows ? m.comp_ns_beyond_l2 : 0.0);
-    const double rank_ms = runs ? m.runs_fixed_ms + m.runs_ns * rows + m.runs_ns_per_run * (double)n_build * 1e-6 : m.comp_fixed_ms + rank_ns * rows;
+    const double rank_ms = runs ? m.runs_fixed_ms + (m.runs_ns + (run_tb ? m.runs_range_ns : 0.0)) * rows +
+                                      m.runs_ns_per_run * (double)(n_build << run_tb) * 1e-6
+                                : m.comp_fixed_ms + rank_ns * rows;
     if (c->gtable_sort_fanout > 1 && rank_ms >= m.part_fixed_ms + part_ns * rows) {
       c->plan.refused |= HMJ_REFUSED_RANK_SORT_MODEL;
       return HMJ_OK;
@@ -2153,17 +2189,26 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   };
   // ---- 1. which 8-bit digits the build keys differ in, and -- for the composite form -- the range of the probe payloads
   // (one read-back)
-  bool use_runs = rank_runs_fit(c, n_build, n_probe);
+  int run_tb = 0;
+  bool use_runs = rank_runs_fit(c, n_build, n_probe, &run_tb);
+  if (use_runs && !rank_runs_rested(c, run_tb)) {
+    if (c->wm->rank_runs_cooldown > 0)
+      c->wm->rank_runs_cooldown--;
+    else
+      c->wm->rank_lookup_cooldown--;
+    use_runs = false;
+  }
+  bool have_range = !use_runs || run_tb > 0;
   {
     const u64 init[5] = {0, ~0ull, 0, ~0ull, 0};
     HIP_TRY(hipMemcpyAsync(c->offs64.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hmj::launch_key_exact(R, nb, nullptr, 0u, 0, (u64*)c->offs64.p, c->num_cus, c->stream, true));
-    if (!use_runs) HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
+    if (have_range) HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
     HIP_TRY(hipMemcpyAsync(hh, c->offs64.p, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   const u64 key_diff = hh[0];
-  u64 svmin = (np && !use_runs) ? hh[3] : 0, svmax = (np && !use_runs) ? hh[4] : 0;
+  u64 svmin = (np && have_range) ? hh[3] : 0, svmax = (np && have_range) ? hh[4] : 0;
   int range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
   const int rank_bits = nb > 1 ? 32 - __builtin_clz(nb - 1) : 0;
   // rank and payload in ONE word where they fit; else as two (payloads that are hashes, doubles, pointers): sorted by the
@@ -2173,7 +2218,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   if (wide && c->gtable_sort_fanout > 1) {  // (ten passes instead of four or five: about 1.6 x the time per row)
     const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
     const OrderedCostModel& m = c->ordered_model;
-    const double part_ns = ordered_part_ns(m, f);
+    const double part_ns = ordered_part_ns(m, f, (double)n_probe);
     if (m.comp_fixed_ms + m.comp_ns_wide * rows >= m.part_fixed_ms + part_ns * rows) {
       c->wm->gtable_sort_cooldown = 8;
       return HMJ_OK;
@@ -2213,14 +2258,18 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   bool runs_done = false;
   u64 n = 0;
   if (use_runs) {
-    const int bb = rank_bits / 2, ba = rank_bits - bb;  // LSD: pass A on the low digit, pass B on the high one
-    const u32 P = 1u << rank_bits;
+    // the partition number: rank << tb | piece of the run (hmj_dev.h, rank_run_bucket)
+    const int TB = rank_bits + run_tb;
+    const int bb = TB / 2, ba = TB - bb;  // LSD: pass A on the low digit, pass B on the high one
+    const u32 P = 1u << TB;
+    const int pre = range_bits > 32 ? range_bits - 32 : 0;
+    const u64 mult = run_tb ? ((u64)1 << (run_tb + 32)) / (((svmax - svmin) >> pre) + 1) : 0;
     u64* acc = (u64*)c->accum.p;
     const char* why = "";
     // rows -> partitions (fused: straight from the probe rows) -> offsets -> sorted runs; 0 ok, 1 gave up, < 0 error
     auto passes = [&](u64 rows, bool fused) -> int {
       hmj::SlabGeom g;
-      if (rows == 0 || !hmj::slab_geometry((u32)rows, ba, bb, &g, 0, 1.0, (double)P / (double)nb)) {
+      if (rows == 0 || !hmj::slab_geometry((u32)rows, ba, bb, &g, 0, 1.0, (double)(1u << rank_bits) / (double)nb)) {
         why = "no slab geometry";
         return 1;
       }
@@ -2239,7 +2288,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       int s2 = span_begin(c, K_SCATTER, 1, 0);
       if (fused)
         r2 = launch(hmj::launch_slab_a_ranks(S, np, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->gtab.p,
-                                             log_cap, extra, c->stream), "launch_slab_a_ranks");
+                                             log_cap, extra, run_tb, svmin, pre, mult, c->stream), "launch_slab_a_ranks");
       else
         r2 = launch(hmj::launch_slab_a(c->sbuf[0].p, (u32)rows, 0, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4,
                                        acc, c->stream), "launch_slab_a");
@@ -2256,7 +2305,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       if (r2 != HMJ_OK) return r2;
       s2 = span_begin(c, K_PROBE_WRITE, -1);
       r2 = launch(hmj::launch_rank_sort_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, sortedR, nb,
-                                              (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, acc, extra, c->num_cus, c->stream),
+                                              run_tb, (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, acc, extra, c->num_cus, c->stream),
                   "launch_rank_sort_write");
       span_end(c, s2);
       if (r2 != HMJ_OK) return r2;
@@ -2270,7 +2319,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       }
       c->timing.bytes_scatter += 2 * 32ull * rows - (fused ? 16ull * rows : 0ull);
       c->timing.path |= HMJ_PATH_SLAB | HMJ_PATH_RANK_RUNS | (fused ? HMJ_PATH_RANK_LOOKUP_IN_PASS : 0u);
-      c->timing.radix_bits = rank_bits;
+      c->timing.radix_bits = TB;
       c->timing.radix_passes = 2;
       return 0;
     };
@@ -2302,7 +2351,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
         runs_done = true;
       }
     }
-    if (!runs_done) {
+    if (!runs_done && run_tb == 0) {  // (cut runs: the emit below writes ranks, not partition numbers -- on to the composites)
       HIP_TRY(hmj::launch_gtable_emit_ranks(S, np, c->gtab.p, log_cap, (u64*)c->accum.p, c->sbuf[0].p, extra, c->num_cus, c->gtable_wg_per_cu, c->stream));
       span_end(c, sp);
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -2324,15 +2373,18 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       if (c->trace) std::fprintf(stderr, "[hmj] join nb=%u np=%u ordered: rank-run form gave up (%s) -> composite sort\n", nb, np, why);
       drop_attempt();
       use_runs = false;
-      const u64 init2[2] = {~0ull, 0};
-      HIP_TRY(hipMemcpyAsync((u64*)c->offs64.p + 3, init2, sizeof(init2), hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
-      HIP_TRY(hipMemcpyAsync(hh, (u64*)c->offs64.p + 3, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      svmin = np ? hh[0] : 0;
-      svmax = np ? hh[1] : 0;
-      range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
-      wide = rank_bits + range_bits > 64;
+      if (!have_range) {
+        const u64 init2[2] = {~0ull, 0};
+        HIP_TRY(hipMemcpyAsync((u64*)c->offs64.p + 3, init2, sizeof(init2), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
+        HIP_TRY(hipMemcpyAsync(hh, (u64*)c->offs64.p + 3, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        svmin = np ? hh[0] : 0;
+        svmax = np ? hh[1] : 0;
+        range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
+        wide = rank_bits + range_bits > 64;
+        have_range = true;
+      }
       HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
       sp = span_begin(c, K_PROBE_COUNT, -1);
     }
@@ -2594,6 +2646,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_ONE_PASS_SLAB")) c->one_pass_slab = atoi(e) != 0;  // 0: mid-size build sides keep the exact one-pass plan
   if (const char* e = getenv("HMJ_GTABLE")) c->gtable_mode = atoi(e) != 0;  // 0: small build sides are partitioned too
   if (const char* e = getenv("HMJ_RANK_RUNS")) c->rank_runs_mode = atoi(e) != 0;  // 0: ordered small-build joins always sort composites
+  if (const char* e = getenv("HMJ_RANK_RUNS_MAX_CUT")) c->rank_runs_max_cut = atoi(e) < 0 ? 0 : atoi(e) > 16 ? 16 : atoi(e);
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
   if (const char* e = getenv("HMJ_SORT_MSD")) c->sort_msd = atoi(e) != 0;  // 0: hmj_sort_u64_device never takes its MSD form (two slab passes + an LDS sort per partition)
@@ -2676,7 +2729,8 @@ int hmj_create(hmj_ctx** out, int device_id) {
         {"comp_fixed_ms", &c->ordered_model.comp_fixed_ms}, {"comp_ns_chain", &c->ordered_model.comp_ns_chain},
         {"comp_ns_exact", &c->ordered_model.comp_ns_exact}, {"comp_ns_wide", &c->ordered_model.comp_ns_wide},
         {"comp_ns_beyond_l2", &c->ordered_model.comp_ns_beyond_l2}, {"runs_fixed_ms", &c->ordered_model.runs_fixed_ms},
-        {"runs_ns", &c->ordered_model.runs_ns}, {"runs_ns_per_run", &c->ordered_model.runs_ns_per_run}};
+        {"runs_ns", &c->ordered_model.runs_ns}, {"runs_ns_per_run", &c->ordered_model.runs_ns_per_run},
+        {"runs_range_ns", &c->ordered_model.runs_range_ns}};
     std::string spec(e);
     size_t pos = 0;
     while (pos < spec.size()) {

@@ -814,7 +814,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
 template <bool EXTRA>
 __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
                                                                      u32 P, const u64* __restrict__ out_off,
-                                                                     const Tup* __restrict__ sortedR, u32 nb, u64* __restrict__ out_key,
+                                                                     const Tup* __restrict__ sortedR, u32 nb, int tb, u64* __restrict__ out_key,
                                                                      u64* __restrict__ out_rval, u64* __restrict__ out_sval,
                                                                      u64* __restrict__ accum) {
   __shared__ __attribute__((aligned(16))) u64 keys[RS_CAP];  // 16 KiB: the run's keys (64-bit, or 32-bit in its first half)
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
     const u32 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
     const u32 n = c0 + c1 + c2 + c3;
     if (n == 0) continue;
-    if (n > (u32)RS_CAP || p >= nb || c0 > cap || c1 > cap || c2 > cap || c3 > cap) {  // (uniform) a run beyond the kernel, or counts no slab pass wrote
+    if (n > (u32)RS_CAP || (p >> tb) >= nb || c0 > cap || c1 > cap || c2 > cap || c3 > cap) {  // (uniform) a run beyond the kernel, or counts no slab pass wrote
       bad = true;
       continue;
     }
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
     const u64 range = mx - mn;
     u32 N = 8;
     while (N < n) N <<= 1;
-    const Tup b = sortedR[p];
+    const Tup b = sortedR[p >> tb];  // (tb > 0: a key's run is cut into 2^tb partitions by the position of the payload in the payloads' range)
     const u64 off = out_off[p];
     if (range == 0) {
       // one payload value in the whole run: nothing to sort
@@ -1156,18 +1156,18 @@ hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u3
 }
 
 int rank_sort_max_run() { return RS_CAP; }
-hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb,
+hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb, int tb,
                                   u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st) {
-  if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0)
+  if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0 || tb < 0 || tb > 16)
     return hipErrorInvalidValue;
   u32 grid = (u32)num_cus * 5u;  // what is resident at once: 96 registers (launch bounds) and 28 KiB of LDS per 256-thread workgroup
   if (grid > P) grid = P;
   if (extra)
     hipLaunchKernelGGL((rank_sort_write_kernel<true>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
-                       static_cast<const Tup*>(sortedR), nb, out_key, out_rval, out_sval, accum);
+                       static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum);
   else
     hipLaunchKernelGGL((rank_sort_write_kernel<false>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
-                       static_cast<const Tup*>(sortedR), nb, out_key, out_rval, out_sval, accum);
+                       static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum);
   return hipGetLastError();
 }
 

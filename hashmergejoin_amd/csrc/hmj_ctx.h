@@ -86,6 +86,7 @@ struct OrderedCostModel {
   double comp_ns_beyond_l2 = 0.02;                      // + where the key -> rank table leaves an XCD's L2
   // rank runs: two slab passes on the rank + an LDS sort per run
   double runs_fixed_ms = 0.25, runs_ns = 0.0215, runs_ns_per_run = 7.5;
+  double runs_range_ns = 0.002;  // cut runs: one more pass over the probe side for the range of its payloads
 };
 }  // namespace hmj_host
 
@@ -157,7 +158,8 @@ struct hmj_ctx {
   bool ltable_mode = true;         // build sides <= 2048 rows (1024 with checksums) under >= 2^16 probe rows, count modes: the table in LDS, one copy per workgroup (HMJ_LTABLE=0, developer builds: the L2-resident table)
   bool gtable_sort_mode = true;    // HMJ_GTABLE_SORT=0: ordered joins of a small build side under a long probe side stay partitioned
   u32 gtable_sort_fanout = 128;    // ... from this many probe rows per build row on (HMJ_GTABLE_SORT_FANOUT)
-  bool rank_runs_mode = true;      // ordered, small build side, fan-out 16 ... ~1700: partition by rank, sort every rank's run in LDS (HMJ_RANK_RUNS=0: composites)
+  bool rank_runs_mode = true;      // ordered, small build side, fan-out from 16: partition by rank, sort every rank's run in LDS (HMJ_RANK_RUNS=0: composites)
+  int rank_runs_max_cut = 10;       // ... runs beyond ~1700 rows cut into up to 2^this pieces by payload position (HMJ_RANK_RUNS_MAX_CUT; 0: such joins sort composites)
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)

@@ -57,6 +57,16 @@ __device__ __forceinline__ u32 gt_hash(u64 key, int shift) {
   return (u32)(h >> shift);
 }
 
+// The rank-run form cuts a key's run by the position of the payload in the payloads' range: bucket = floor(off * 2^tb /
+// (range + 1)) for off = sval - svmin, computed as ((off >> pre) * mult) >> 32 with pre = max(0, bits(range) - 32) and
+// mult = floor(2^(tb + 32) / ((range >> pre) + 1)) (host: api.hip).  Monotone in sval, < 2^tb, and even over ANY range -- the
+// top tb bits of the range would leave up to half of the buckets empty when the range is not a power of two.
+#ifndef HMJ_RANK_PASS_CHUNK_ROWS
+#define HMJ_RANK_PASS_CHUNK_ROWS 64  // (64 / 128 / 256 measure the same, profiles/r05s_*; 64 reaches the longest runs)
+#endif
+constexpr int RANK_PASS_CHUNK_ROWS = HMJ_RANK_PASS_CHUNK_ROWS;  // the pass with the rank lookup reads chunks of this many rows from all over the probe side (radix.hip)
+__device__ __forceinline__ u64 rank_run_bucket(u64 off, int pre, u64 mult) { return ((off >> pre) * mult) >> 32; }
+
 // ONE walker for every kernel that looks keys up in that table (the lockstep walk was written out four times,
 // and the copies had begun to differ).  Each lane walks ROWS keys at once -- ROWS independent loads in flight -- from
 // slot[r] on, while live[r]; an empty slot ends a row's walk; on_slot(r, entry) sees every OCCUPIED slot a live row

@@ -716,7 +716,9 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 // ---------------------------------------------------------------------------------------------
 // (Xform: what happens to a tile's rows between the load and the scatter.  NoXform: nothing -- the join's pass A;
 //  RankXform: every probe row becomes {rank of its key, payload} through the global table, radix_slab_a_rank_kernel below.)
-struct NoXform {};
+struct NoXform {
+  static constexpr bool kStrided = false;
+};
 template <int THREADS, int MAXD, bool HI, typename Xform>
 __device__ __forceinline__ void slab_a_body(const Tup* __restrict__ in, u32 n, int shift, int bits, u32 rows_per_worker,
                                             Tup* __restrict__ slab, u32 CA, u32 WA, u32* __restrict__ cnt_out,
@@ -743,7 +745,52 @@ __device__ __forceinline__ void slab_a_body(const Tup* __restrict__ in, u32 n, i
 #ifdef HMJ_STAMPS
   WcStamps stamps = {};
 #endif
-  if (begin < end) {
+  if constexpr (Xform::kStrided) {
+    // STRIDED chunks: a tile is made of chunks of RANK_PASS_CHUNK_ROWS rows, and a worker's chunks are c, c + WA, c + 2 WA, ... --
+    // places all over the relation instead of one contiguous range.  Digits that are correlated with a row's POSITION (the
+    // piece of a run a payload falls into, when payloads are row ids or timestamps) then spread evenly over a worker's
+    // slabs instead of filling one of them.  The price: a (digit, worker) slab is no longer a contiguous range of the
+    // input in order, so the pass is not stable -- used only where equal keys are equal rows (radix_slab_a_rank_kernel).
+    // A tile's valid rows are still a prefix of it: chunk numbers grow with the wave, and only the last chunk is ragged.
+    constexpr u32 CH = RANK_PASS_CHUNK_ROWS, IPC = CH / 64, CPT = TILE / CH;  // items of a thread per chunk; chunks per tile
+    static_assert(WC_ITEMS % IPC == 0 && IPC >= 1, "a wave's rows of a tile are whole chunks");
+    const u64 n_chunks = ((u64)n + CH - 1) / CH, whole_chunks = n / CH;
+    const u32 tail = n % CH;
+    // Which chunk of a stride a worker takes is scrambled (a multiplier coprime to WA, near WA / golden ratio): pass B's
+    // worker k gathers the slabs of a RANGE of workers, and with chunk = worker a piece shorter than a stride would sit in
+    // the slabs of one range only.
+    const u32 slot = (u32)(((u64)worker * xf.slot_mult) % WA);
+    const u64 my_whole = whole_chunks > slot ? (whole_chunks - slot + WA - 1) / WA : 0;  // this worker's whole chunks
+    auto chunk_of = [&](u64 k, u32 c) { return (k * CPT + c) * WA + slot; };  // chunk c of the worker's tile k
+    auto rows_of = [&](u64 k) {
+      const u64 first = k * CPT;
+      const u32 nv = my_whole > first ? (u32)((my_whole - first < CPT) ? my_whole - first : CPT) : 0u;
+      return nv * CH + ((nv < CPT && tail && chunk_of(k, nv) == whole_chunks) ? tail : 0u);
+    };
+    if (chunk_of(0, 0) < n_chunks) {
+      Tup t[WC_ITEMS];
+      auto load_tile = [&](u64 k) {
+#pragma unroll
+        for (int r = 0; r < WC_ITEMS; r++) {
+          const u64 q = chunk_of(k, (u32)w * (WC_ITEMS / IPC) + r / IPC) * CH + (r % IPC) * 64 + lane;
+          t[r] = load_stream(&in[q < n ? q : n - 1]);  // clamped, unpredicated: loads issue back to back
+        }
+      };
+      load_tile(0);
+      for (u64 k = 0; chunk_of(k, 0) < n_chunks; k++) {
+        const u32 tile_n = rows_of(k);
+        auto prefetch = [&]() {
+          if (chunk_of(k + 1, 0) < n_chunks) load_tile(k + 1);
+        };
+        xf(t, tile_n, wbase);
+        if (HMJ_WC_FULLTILE && tile_n == (u32)TILE)
+          wc_tile<THREADS, MAXD, HI, true, true>(sm, t, tile_n, slab, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
+        else
+          wc_tile<THREADS, MAXD, HI, false, true>(sm, t, tile_n, slab, shift, mask, D, prefetch, limit, &ovf WC_STAMP_PASS);
+      }
+      wc_flush_carry(sm, slab, D);
+    }
+  } else if (begin < end) {
     Tup t[WC_ITEMS];
     {
       const u32 tn = (u32)((end - begin < TILE) ? end - begin : TILE);
@@ -1246,11 +1293,20 @@ __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) v
 // key -> rank (gtable_build_kernel<true> over the sorted build rows).  A probe row whose key is not in the table cannot be
 // dropped from the middle of a tile: the kernel raises ERR_FASTPATH and the host takes emit + pass A (foreign keys that
 // all have their dimension row -- the usual case -- never get there).  Sums of the probe payloads as gtable_emit_kernel.
+// CUT: runs beyond one workgroup's sort are cut into 2^tb pieces by the position of the payload in the payloads' range, and
+// the pass reads chunks from all over the probe side (slab_a_body's strided form) so that payloads which grow with the
+// row's position do not land a worker's rows in one piece.
+template <bool CUT>
 struct RankXform {
+  static constexpr bool kStrided = CUT;
+  u32 slot_mult;  // (strided form: worker w reads the chunks w * slot_mult mod WA of every stride)
   const Tup* __restrict__ tab;
   u32 mask;
   int hshift;
+  int tb, pre;  // runs beyond one workgroup: the partition key is rank << tb | rank_run_bucket(sval - svmin, pre, mult) (hmj_dev.h)
+  u64 svmin, mult;
   u64 acc_s;
+  u64 n_rows;
   bool miss;
   __device__ __forceinline__ void operator()(Tup (&t)[WC_ITEMS], u32 tile_n, u32 wbase) {
     u32 slot[WC_ITEMS];
@@ -1261,6 +1317,7 @@ struct RankXform {
       want[r] = wbase + (u32)r * 64 < tile_n;
       slot[r] = gt_hash(t[r].key, hshift);
       if (want[r]) acc_s += t[r].val;
+      if (want[r]) n_rows++;
       live[r] = want[r] && t[r].key != GT_EMPTY;  // (the empty marker is never a table key)
     }
     u64 rank[WC_ITEMS] = {};
@@ -1275,36 +1332,40 @@ struct RankXform {
 #pragma unroll
     for (int r = 0; r < WC_ITEMS; r++) {
       miss |= want[r] && !((found >> r) & 1u);
-      t[r].key = rank[r];  // (.val stays the probe payload)
+      t[r].key = CUT ? (rank[r] << tb) | rank_run_bucket(t[r].val - svmin, pre, mult) : rank[r];  // (.val stays the probe payload)
     }
   }
 };
-template <int THREADS, int MAXD>
+template <int THREADS, int MAXD, bool CUT>
 __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_a_rank_kernel(
     const Tup* __restrict__ in, u32 n, int bits, u32 rows_per_worker, Tup* __restrict__ slab, u32 CA, u32 WA,
-    u32* __restrict__ cnt_out, u64* __restrict__ accum, const Tup* __restrict__ tab, int log_cap, bool extra) {
+    u32* __restrict__ cnt_out, u64* __restrict__ accum, const Tup* __restrict__ tab, int log_cap, bool extra, int tb, u64 svmin, int pre,
+    u64 mult, u32 slot_mult) {
   // (duplicate build keys or a table that gave up -- the host sees the same words and discards this pass -- need no early
   //  exit: the table is fully initialised either way, every walk ends at an empty slot, every rank is a build row's index;
   //  and pass B trusts the counts written below, so they must be written)
-  RankXform xf{tab, (1u << log_cap) - 1, 64 - log_cap, 0ull, false};
-  slab_a_body<THREADS, MAXD, false, RankXform>(in, n, 0, bits, rows_per_worker, slab, CA, WA, cnt_out, accum, 0u, xf);
+  RankXform<CUT> xf{slot_mult, tab, (1u << log_cap) - 1, 64 - log_cap, tb, pre, svmin, mult, 0ull, 0ull, false};
+  slab_a_body<THREADS, MAXD, false, RankXform<CUT>>(in, n, 0, bits, rows_per_worker, slab, CA, WA, cnt_out, accum, 0u, xf);
   // sums: one set of atomics per workgroup
-  __shared__ u64 wsum[THREADS / kWave];
+  __shared__ u64 wsum[THREADS / kWave], wrows[THREADS / kWave];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const u64 ws = wave_sum_u64(xf.acc_s);
+  const u64 ws = wave_sum_u64(xf.acc_s), wr = wave_sum_u64(xf.n_rows);
   const bool any_miss = __any(xf.miss);
-  if (lane == 0) wsum[wv] = ws;
+  if (lane == 0) {
+    wsum[wv] = ws;
+    wrows[wv] = wr;
+  }
   if (any_miss && lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
   __syncthreads();
   if (threadIdx.x == 0) {
-    u64 tot = 0;
-    for (int w = 0; w < THREADS / kWave; w++) tot += wsum[w];
-    const u64 begin = (u64)blockIdx.x * rows_per_worker;
-    u64 end = begin + rows_per_worker;
-    if (end > n) end = n;
+    u64 tot = 0, rows = 0;
+    for (int w = 0; w < THREADS / kWave; w++) {
+      tot += wsum[w];
+      rows += wrows[w];
+    }
     if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_SUM_S]), (unsigned long long)tot);
     if (extra && tot) atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_SUM_P]), (unsigned long long)tot);
-    if (end > begin) atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_N]), (unsigned long long)(end - begin));
+    if (rows) atomicAdd(reinterpret_cast<unsigned long long*>(&accum[ACC_N]), (unsigned long long)rows);
   }
 }
 template <int THREADS, int MAXD, bool HI>
@@ -1374,7 +1435,12 @@ bool slab_geometry(u32 n, int bits_a, int bits_b, SlabGeom* g, u32 kb, double fa
   if (g->WA < kb || (g->WA + kb - 1) / kb > (u32)SLAB_MAXSEG) return false;
   if (fan < 1.0) fan = 1.0;
   if (density < 1.0) density = 1.0;  // keys that fill 1 / density of the partitions: those hold density x the mean
-  g->CA = slab_cap(density * (double)g->rpw / (double)(1u << bits_a), fan);
+  // (pass A: a worker's rows are a SAMPLE of the relation, rpw of n rows, so a digit's share of them varies with the
+  //  sampling -- mean -- and with the digit's share of the KEYS, n / fan / 2^bits_a of them: variance mean * (1 + rpw * fan
+  //  / n), four times that term for safety.  Until round 5 this was `fan` as for pass B: 2^19 x 2^28 rows, fan-out 512,
+  //  asked for 54 GiB of pass-A slabs for 4 GiB of rows.)
+  const double fan_a = 1.0 + 4.0 * (double)g->rpw * fan / (double)(n ? n : 1);
+  g->CA = slab_cap(density * (double)g->rpw / (double)(1u << bits_a), fan_a < fan ? fan_a : fan);
   g->CB = slab_cap(density * (double)n / (double)(1u << bits_a) / (double)kb / (double)(1u << bits_b), fan);
   const u64 rows_a = (u64)(1u << bits_a) * g->WA * g->CA;
   const u64 rows_b = (u64)(1u << (bits_a + bits_b)) * kb * g->CB;
@@ -1422,21 +1488,42 @@ hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabG
 
 // pass A of the rank-run form with the key -> rank lookup in front (radix_slab_a_rank_kernel): in = PROBE rows
 hipError_t launch_slab_a_ranks(const void* in, u32 n, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
-                               u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, hipStream_t st) {
-  if (bits < 1 || bits > SLAB_MAX_BITS || g.WA == 0 || g.CA == 0 || (u64)g.WA * g.rpw < n || !tab || log_cap < 4 || log_cap > 30)
+                               u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, int tb, u64 svmin, int pre, u64 mult,
+                               hipStream_t st) {
+  if (bits < 1 || bits > SLAB_MAX_BITS || g.WA == 0 || g.CA == 0 || (u64)g.WA * g.rpw < n || !tab || log_cap < 4 || log_cap > 30 || tb < 0 ||
+      tb > 16 || pre < 0 || pre > 32)
     return hipErrorInvalidValue;
   if (slab_a_rows < ((u64)g.WA << bits) * g.CA || cnt_a_n < ((u64)g.WA << bits)) return hipErrorInvalidValue;
   if (((u64)g.WA << bits) * g.CA >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
-#define HMJ_SLAB_AR(T, M)                                                                                                           \
+  u32 slot_mult = 1;
+  if (tb > 0 && g.WA > 2) {
+    auto gcd = [](u32 a, u32 b) {
+      while (b) {
+        const u32 t = a % b;
+        a = b;
+        b = t;
+      }
+      return a;
+    };
+    slot_mult = (u32)((double)g.WA * 0.6180339887498949);
+    if (slot_mult < 1) slot_mult = 1;
+    while (gcd(slot_mult, g.WA) != 1) slot_mult++;
+  }
+#define HMJ_SLAB_AR(T, M, C)                                                                                                          \
   {                                                                                                                                   \
     typedef WcSmem<T, M> Smem;                                                                                                        \
     static SmemAttrOnce once;                                                                                                         \
-    if (hipError_t e = ensure_max_smem(once, reinterpret_cast<const void*>(radix_slab_a_rank_kernel<T, M>), sizeof(Smem)); e != hipSuccess) \
+    if (hipError_t e = ensure_max_smem(once, reinterpret_cast<const void*>(radix_slab_a_rank_kernel<T, M, C>), sizeof(Smem)); e != hipSuccess) \
       return e;                                                                                                                       \
-    hipLaunchKernelGGL((radix_slab_a_rank_kernel<T, M>), dim3(g.WA), dim3(T), sizeof(Smem), st, static_cast<const Tup*>(in), n, bits, g.rpw, \
-                       static_cast<Tup*>(slab_a), g.CA, g.WA, cnt_a, accum, static_cast<const Tup*>(tab), log_cap, extra);             \
+    hipLaunchKernelGGL((radix_slab_a_rank_kernel<T, M, C>), dim3(g.WA), dim3(T), sizeof(Smem), st, static_cast<const Tup*>(in), n, bits, g.rpw, \
+                       static_cast<Tup*>(slab_a), g.CA, g.WA, cnt_a, accum, static_cast<const Tup*>(tab), log_cap, extra, tb, svmin, pre, mult, \
+                       slot_mult);                                                                                                    \
   }
-  if (bits > 8) HMJ_SLAB_AR(1024, 512) else HMJ_SLAB_AR(512, 256)
+  if (tb > 0) {
+    if (bits > 8) HMJ_SLAB_AR(1024, 512, true) else HMJ_SLAB_AR(512, 256, true)
+  } else {
+    if (bits > 8) HMJ_SLAB_AR(1024, 512, false) else HMJ_SLAB_AR(512, 256, false)
+  }
 #undef HMJ_SLAB_AR
   return hipGetLastError();
 }

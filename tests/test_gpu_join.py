@@ -579,14 +579,42 @@ def test_full_size_closed_form(ex, H, G, log2n, bits):
         ex.set_radix_bits(None)
 
 
-@pytest.mark.parametrize("log2b,log2p,wide", [(16, 26, False), (16, 26, True), (18, 26, False), (12, 26, False), (14, 24, True)])
+def _rank_runs_cut(nb, npb, chunk_rows=64, max_run=2048, max_cut=10):
+    """The host's rank_runs_fit (api.hip): None where the rank-run form does not apply, else log2 of the pieces a key's run is cut into."""
+    if nb < 4 or npb < 1 << 16 or npb >= 1 << 32:
+        return None
+    rank_bits = (nb - 1).bit_length()
+    f = npb / nb
+    if rank_bits < 2 or rank_bits > 18 or f < 16:
+        return None
+    t = 0
+    while f + 8 * f ** 0.5 + 24 > max_run:
+        f, t = f / 2, t + 1
+    if t > max_cut or rank_bits + t > 18:
+        return None
+    if t:
+        tb = rank_bits + t
+        ba = tb - tb // 2
+        tile = 4096 if ba > 8 else 2048
+        tpw = -(-(-(-npb // tile)) // 2048)
+        rpw = tpw * tile
+        places, pieces, mean = rpw / chunk_rows, 1 << t, rpw / (1 << ba)
+        skew = -(-places // pieces) / (places / pieces) if places >= pieces else pieces / places
+        if skew * mean + 4 * (skew * mean) ** 0.5 > mean + 8 * mean ** 0.5 + 24:
+            return None
+    return t
+
+
+@pytest.mark.parametrize("log2b,log2p,wide", [(16, 26, False), (16, 26, True), (18, 26, False), (12, 26, False), (10, 26, True), (14, 24, True)])
 def test_full_size_ordered_small_build_side(ex_fresh, H, log2b, log2p, wide):
     # The operator's mode for a dimension table under a fact table at sizes no CPU oracle reaches in seconds (the bench's
     # small_build_2p16_x_2p26_ordered entry): checked ROW BY ROW on the device through the generators' own arithmetic.
     # Every result row must pair the build row and the probe row it names (rval is the build row's index, sval identifies
     # the probe row), every probe row must appear exactly once, keys must ascend and, inside a key, probe payloads must
     # ascend (unsigned) -- that is HashMergeJoin's iteration order for unique build keys (hashjoin.h:104-154).
-    # (16 / 18, 26): rank runs (fan-out 1024 / 256); wide: payloads spanning 64 bits; (12, 26): runs of 16384 rows -> composites.
+    # (16 / 18, 26): rank runs (fan-out 1024 / 256); wide: payloads spanning 64 bits; (12 / 10, 26): runs of 16384 / 65536 rows,
+    # cut into 16 / 64 pieces by the position of the payload in the payloads' range (the generator's payloads are row ids:
+    # pieces and row positions go together, the case the strided pass A is for).
     import torch
 
     from hashmergejoin_amd.join import _memcpy_d2d
@@ -602,7 +630,8 @@ def test_full_size_ordered_small_build_side(ex_fresh, H, log2b, log2p, wide):
     t = ex.last_timing()
     assert int(r.n_matches) == npb
     assert t["path"] & H.HMJ_PATH_ORDER_BY_RANK_SORT, hex(t["path"])
-    assert bool(t["path"] & H.HMJ_PATH_RANK_RUNS) == (log2p - log2b <= 10), hex(t["path"])
+    assert _rank_runs_cut(nb, npb) == {16: 0, 18: 0, 14: 0, 12: 4, 10: 6}[log2b]
+    assert t["path"] & H.HMJ_PATH_RANK_RUNS and t["path"] & H._lib.HMJ_PATH_RANK_LOOKUP_IN_PASS, hex(t["path"])
     cols = []
     for ptr in (r.key, r.rval, r.sval):
         c = torch.empty(npb, dtype=torch.int64, device="cuda")
@@ -1410,7 +1439,12 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
                                (60000, 1 << 23, 4, "offset"), (1000, 200000, 0, "wide"), (1000, 400001, 3, "wide"),
                                (3000, 4500000, 0, "ids"), (3001, 1500000, 5, "wide"), (4000, 1200000, 0, "hot"), (300, 5000, 0, "ids"),
                                (2000, 700000, 0, "ties7"), (2000, 600001, 3, "const"), (1500, 500000, 0, "extremes"),
-                               (3000, 400000, 2, "dupbuild")]:
+                               (3000, 400000, 2, "dupbuild"),
+                               # runs beyond one workgroup's sort, cut by payload position: random and position-ordered payloads,
+                               # 64-bit payloads, a ragged last chunk, probe rows without a build row (-> composites), payloads
+                               # of seven values (pieces that cannot be even -> composites)
+                               (300, 1 << 22, 0, "ids"), (300, (1 << 22) - 77, 0, "rowid"), (500, 3000001, 0, "wide"),
+                               (37, 1 << 20, 0, "rowid"), (300, 1 << 22, 3, "offset"), (100, 1 << 21, 0, "ties7")]:
         B = oracle.gen_build(nb)
         P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
         if pay == "hot":  # a third of the probe rows carry one key: its run is beyond any workgroup
@@ -1426,6 +1460,8 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             P[1::5, 1] = np.uint64(M64)
         if pay == "ids":
             P[:, 1] = rng.permutation(npb).astype(np.uint64)
+        elif pay == "rowid":  # grows with the row's position, like a fact table's row ids or timestamps
+            P[:, 1] = np.uint64(0x0000123400000000) + np.arange(npb, dtype=np.uint64) * np.uint64(3)
         elif pay == "offset":
             P[:, 1] = np.uint64(0xFEDCBA9800000000) + rng.integers(0, 1 << 30, size=npb, dtype=np.uint64)  # (ties among payloads too)
         elif pay == "wide":
@@ -1439,14 +1475,15 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             t = ex.last_timing()
             took = bool(t["path"] & RS)
             # (payloads spanning all 64 bits go as two words: sorted by payload, then stably by rank)
-            assert took == (pay in ("ids", "offset", "wide", "hot", "ties7", "const", "extremes")), (nb, npb, pay, fl, hex(t["path"]))
-            f = npb / nb
-            runs = pay in ("ids", "offset", "wide", "ties7", "const") and nb >= 4 and npb >= 1 << 16 and f >= 16 and f + 8 * f ** 0.5 + 24 <= 2048
+            assert took == (pay in ("ids", "rowid", "offset", "wide", "hot", "ties7", "const", "extremes")), (nb, npb, pay, fl, hex(t["path"]))
+            cut = _rank_runs_cut(nb, npb)
+            # (cut runs exist only with the lookup inside pass A, and their pieces are even only where the payloads are spread)
+            runs = pay in ("ids", "rowid", "offset", "wide", "ties7", "const") and cut is not None and (cut == 0 or (miss == 0 and pay != "ties7"))
             assert bool(t["path"] & RR) == runs, (nb, npb, pay, fl, hex(t["path"]))
             # every probe row has its build row (miss == 0): the rank lookup runs inside the first slab pass; unmatched
             # probe rows make that attempt give way to emit + pass A (and the workload remembers)
             assert bool(t["path"] & H._lib.HMJ_PATH_RANK_LOOKUP_IN_PASS) == (runs and miss == 0), (nb, npb, pay, miss, hex(t["path"]))
-            if pay == "hot":  # tried, a run did not fit, the composite sort delivered; the workload remembers
+            if pay == "hot" or (cut and not runs):  # tried, a run did not fit, the composite sort delivered; the workload remembers
                 assert ex.last_plan()["cooling"] & H._lib.HMJ_COOL_RANK_RUNS
             assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (nb, npb, pay, fl)
             if fl & H.HMJ_CHECKSUM:
