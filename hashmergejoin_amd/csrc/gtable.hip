@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void pieces_compact_kernel(const Tup* __restri
   walk_pieces(cnt, off, n_pieces, ppw, [&](u64 piece, u32 r, u64 o) { store_stream(&out[o + r], load_stream(&slabs[piece * cap + r])); });
 }
 
-// ---- the rank-run form (round 5): ordered result of a small build side under a probe side of fan-out ~32 ... ~1700 ------
+// ---- the rank-run form (round 5): ordered result of a small build side under a probe side of fan-out 16 and more -------
 // With unique build keys the operator's order (key, rval, sval) is: the probe rows grouped by the RANK of their key, every
 // group sorted by sval.  The composite form above sorts (rank, sval - svmin) with 4-10 global LSD passes of 32 B per row
 // each (2^16 x 2^26 rows: 4.7 ms = 0.07 of the HBM peak, 8.8 ms when the payloads span 64 bits: profiles/r05a_small16_ord*).
@@ -635,7 +635,9 @@ __global__ __launch_bounds__(256) void pieces_compact_kernel(const Tup* __restri
 // two digits, so partition p = the rows of rank p, in four slab pieces), and one workgroup per rank sorts its run of svals
 // in LDS -- a register-tiled bitonic network on 32-bit keys sval - min (or the 64-bit svals where a run spans more) -- and
 // writes (key, rval, sval) at the rank's offset.  Two global passes instead of five, no payload range needed, payload
-// width irrelevant.  Runs beyond RS_CAP rows (a hot key, fan-out > ~1700) raise ERR_FASTPATH: the composite form runs.
+// width irrelevant.  Fan-outs beyond ~1700: the host cuts every run into 2^tb pieces by payload position (partition =
+// rank << tb | piece, api.hip / radix.hip RankXform<true>).  Partitions beyond RS_CAP rows (a hot key) raise ERR_FASTPATH: the
+// composite form runs.
 constexpr int RS_THREADS = 256, RS_EPT = 8, RS_CAP = RS_THREADS * RS_EPT;  // 2048 rows per rank at most
 // LDS position of element i: the low three index bits XORed with bits 5..7, so that the eight consecutive elements a
 // thread takes in the stride-1 steps fall into different banks than its neighbours' (16-way conflicts otherwise)

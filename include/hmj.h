@@ -123,7 +123,7 @@ typedef struct {
 #define HMJ_PATH_PRESORTED 0x40000u /* a relation arrived already partitioned (sorted by key): its radix passes were skipped */
 #define HMJ_PATH_SLAB_ONE_PASS 0x80000u /* ... of a ONE-pass plan: the probe kernel reads the pass's worker-private slabs directly */
 #define HMJ_PATH_ORDER_BY_RANK_SORT 0x200000u /* ordered, small build side under a long probe side: rows sorted as (key rank, payload) composites */
-#define HMJ_PATH_RANK_RUNS 0x1000000u /* ... where every key's run of probe rows fits one workgroup: rows partitioned by key rank (two slab passes), each run sorted in LDS */
+#define HMJ_PATH_RANK_RUNS 0x1000000u /* ... rows partitioned by key rank -- longer runs: by (rank, piece of the payloads' range) -- with two slab passes, each partition sorted in LDS */
 #define HMJ_PATH_RANK_LOOKUP_IN_PASS 0x2000000u /* ... with the key -> rank lookup inside the first slab pass (every probe row had its build row) */
 #define HMJ_PATH_SORT_MSD 0x4000000u /* hmj_sort_u64_device: two slab passes on the top varying key bits + an LDS sort of every partition */
 #define HMJ_PATH_ORDERED_EXPANSION 0x400000u /* ordered, duplicate build keys: rows written in order partition by partition (no sort of result rows) */
@@ -272,9 +272,10 @@ const char* hmj_version(void);
  *   - the same modes, build side of 2^17 ... 2^21 rows under a probe side >= 8 x larger: one radix pass, the probe side left
  *     in the worker-private slabs of its slab pass and probed there, HMJ_PATH_SLAB_ONE_PASS;
  *   - HMJ_ORDERED, small build side under a probe side >= 128 x larger (a cost model over fan-out and size decides): the
- *     rows ordered through the RANK of their key among the sorted build keys, HMJ_PATH_ORDER_BY_RANK_SORT -- fan-outs up to
- *     ~1700: partitioned by rank, every rank's run sorted in LDS (HMJ_PATH_RANK_RUNS); beyond: (rank, payload) composites
- *     sorted by global LSD passes.
+ *     rows ordered through the RANK of their key among the sorted build keys, HMJ_PATH_ORDER_BY_RANK_SORT -- partitioned
+ *     by rank (runs beyond ~1700 rows: by rank and the position of the payload in the payloads' range), every partition
+ *     sorted in LDS (HMJ_PATH_RANK_RUNS); where that does not apply (more than 2^18 partitions, probe rows without a
+ *     build row in a cut run, a hot key): (rank, payload) composites sorted by global LSD passes.
  * hmj_last_plan says which was taken and why the faster ones were not.                                               */
 int hmj_join_u64_device(hmj_ctx* ctx, const void* build_aos_dev, uint64_t n_build,
                         const void* probe_aos_dev, uint64_t n_probe, uint32_t flags,
