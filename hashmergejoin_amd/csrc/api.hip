@@ -2198,24 +2198,27 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       c->wm->rank_lookup_cooldown--;
     use_runs = false;
   }
-  bool have_range = !use_runs || run_tb > 0;
+  bool have_range = !use_runs;  // (the exact range; cut runs take a sample's: rows outside it go to the end pieces)
+  const u32 range_every = (use_runs && run_tb > 0 && np >= (1u << 18)) ? ((np >> 17) | 1u) : 1u;
   {
     const u64 init[5] = {0, ~0ull, 0, ~0ull, 0};
     HIP_TRY(hipMemcpyAsync(c->offs64.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hmj::launch_key_exact(R, nb, nullptr, 0u, 0, (u64*)c->offs64.p, c->num_cus, c->stream, true));
-    if (have_range) HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream));
+    if (have_range || run_tb > 0) HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream, range_every));
     HIP_TRY(hipMemcpyAsync(hh, c->offs64.p, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   const u64 key_diff = hh[0];
-  u64 svmin = (np && have_range) ? hh[3] : 0, svmax = (np && have_range) ? hh[4] : 0;
+  const bool any_range = have_range || (use_runs && run_tb > 0);
+  u64 svmin = (np && any_range) ? hh[3] : 0, svmax = (np && any_range) ? hh[4] : 0;
+  have_range = have_range || (any_range && range_every == 1);
   int range_bits = svmax > svmin ? 64 - __builtin_clzll(svmax - svmin) : 0;
   const int rank_bits = nb > 1 ? 32 - __builtin_clz(nb - 1) : 0;
   // rank and payload in ONE word where they fit; else as two (payloads that are hashes, doubles, pointers): sorted by the
   // payload's varying digits first, then stably by the rank -- up to 8 + 3 passes instead of 4-5, still well under the
   // partitioned paths' run ranking at these fan-outs (a wide-payload join needs twice the fan-out to take this path)
   bool wide = rank_bits + range_bits > 64;
-  if (wide && c->gtable_sort_fanout > 1) {  // (ten passes instead of four or five: about 1.6 x the time per row)
+  if (wide && !use_runs && c->gtable_sort_fanout > 1) {  // (ten passes instead of four or five: about 1.6 x the time per row; the rank-run form does not care)
     const double f = (double)n_probe / (double)n_build, rows = (double)n_probe * 1e-6;
     const OrderedCostModel& m = c->ordered_model;
     const double part_ns = ordered_part_ns(m, f, (double)n_probe);
@@ -2288,7 +2291,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       int s2 = span_begin(c, K_SCATTER, 1, 0);
       if (fused)
         r2 = launch(hmj::launch_slab_a_ranks(S, np, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->gtab.p,
-                                             log_cap, extra, run_tb, svmin, pre, mult, c->stream), "launch_slab_a_ranks");
+                                             log_cap, extra, run_tb, svmin, svmax - svmin, pre, mult, c->stream), "launch_slab_a_ranks");
       else
         r2 = launch(hmj::launch_slab_a(c->sbuf[0].p, (u32)rows, 0, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4,
                                        acc, c->stream), "launch_slab_a");

@@ -384,11 +384,21 @@ __global__ __launch_bounds__(GTW_THREADS) void gtable_write_kernel(const Tup* __
 // its key's run, linear in the run: 2^16 x 2^26 rows ordered 14-22 ms, 2^10 x 2^22 6 ms (an 18-bit plan of 2^18 partitions).
 // (one atomic pair per WORKGROUP and four loads in flight per thread: with one pair per wave of a 2048-workgroup grid, the
 //  16 384 same-address atomics were half of the kernel's 0.38 ms at 2^26 rows -- profiles/r05a_small16_ord_summary.txt)
-__global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__ S, u32 np, u64* __restrict__ out) {
+// every > 1: a SAMPLE, the rows 0, every, 2 every, ... (np counts the sampled rows) -- the rank-run form's pieces only need a
+// range that nearly all payloads lie in (rows outside it go to the first / last piece, api.hip), not a pass over the relation.
+__global__ __launch_bounds__(256) void sval_range_kernel(const Tup* __restrict__ S0, u32 np, u32 every, u64* __restrict__ out) {
   __shared__ u64 wmn[4], wmx[4];
   u64 mn = ~0ull, mx = 0;
   const u64 stride = (u64)gridDim.x * 256;
   u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (every > 1) {  // (uniform)
+    for (; i < np; i += stride) {
+      const u64 v = S0[i * every].val;
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+  }
+  const Tup* __restrict__ S = S0;
   for (; i + 3 * stride < np; i += 4 * stride) {
     const u64 v0 = load_stream(&S[i]).val, v1 = load_stream(&S[i + stride]).val, v2 = load_stream(&S[i + 2 * stride]).val,
               v3 = load_stream(&S[i + 3 * stride]).val;
@@ -1263,11 +1273,13 @@ hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_c
   return hipGetLastError();
 }
 
-hipError_t launch_sval_range(const void* S, u32 np, u64* out2, int num_cus, hipStream_t st) {
-  u64 grid = ((u64)np + 1023) / 1024;  // (a workgroup per 1024 rows at most: a tiny relation does not launch 2048 of them)
+hipError_t launch_sval_range(const void* S, u32 np, u64* out2, int num_cus, hipStream_t st, u32 every) {
+  if (every < 1) every = 1;
+  const u32 rows = (u32)(((u64)np + every - 1) / every);
+  u64 grid = ((u64)rows + 1023) / 1024;  // (a workgroup per 1024 rows at most: a tiny relation does not launch 2048 of them)
   if (grid > (u64)num_cus * 8) grid = (u64)num_cus * 8;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(sval_range_kernel, dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(S), np, out2);
+  hipLaunchKernelGGL(sval_range_kernel, dim3((u32)grid), dim3(256), 0, st, static_cast<const Tup*>(S), rows, every, out2);
   return hipGetLastError();
 }
 

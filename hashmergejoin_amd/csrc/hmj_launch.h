@@ -152,7 +152,8 @@ hipError_t launch_gtable_write(const void* S, u32 np, const void* tab, int log_c
 // tiny build sides (<= ltable_max_rows()): the table in LDS, one copy per workgroup; count modes (FIRST: R's payload of the first row)
 hipError_t launch_ltable_probe(const void* R, u32 nb, const void* S, u32 np, u64* accum, bool first, bool extra, int num_cus, hipStream_t st);
 int ltable_max_rows();
-hipError_t launch_sval_range(const void* S, u32 np, u64* out2 /* {min, max}; caller: {~0, 0} */, int num_cus, hipStream_t st);
+hipError_t launch_sval_range(const void* S, u32 np, u64* out2 /* {min, max}; caller: {~0, 0} */, int num_cus, hipStream_t st,
+                             u32 every = 1 /* > 1: of the rows 0, every, 2 every, ... only */);
 // (wide: rank and payload as two words -- {payload, rank} emitted, sorted by payload, swapped, sorted by rank, expanded)
 hipError_t launch_gtable_emit(const void* S, u32 np, const void* tab, int log_cap, u64 svmin, int range_bits, u64* accum,
                               void* pairs, bool extra, bool wide, int num_cus, int wg_per_cu, hipStream_t st);
@@ -168,8 +169,8 @@ hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u3
 hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb, int tb,
                                   u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st);
 hipError_t launch_slab_a_ranks(const void* in, u32 n, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
-                               u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, int tb, u64 svmin, int pre, u64 mult,
-                               hipStream_t st);
+                               u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, int tb, u64 svmin, u64 svrange, int pre,
+                               u64 mult, hipStream_t st);
 hipError_t launch_slab_offsets(const u32* cnt /* P x SLAB_KB piece counts */, u32 P, u64* off /* P + 1 */, u64* scratch /* ceil(P / 1024) */,
                                hipStream_t st);
 hipError_t launch_gtable_expand(const void* pairs, u64 n, const void* sortedR, u64 svmin, int range_bits, u64* out_key,

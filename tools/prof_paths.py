@@ -4,7 +4,8 @@ the join paths that only had wall-clock sweeps.  Prints one JSON
 (wall clock, best of reps), the algorithmic minimum bytes of the call and the fraction of the 8 TB/s peak.
 
 Names: small16_count small16_mat small16_ord small11_count mid20_count dup8_ord fk22_ord sort28 fk24_ord
-       small16_ord64 (payloads spanning 64 bits) headline
+       small16_ord64 (payloads spanning 64 bits) headline small12_ord (runs of 16384 rows: cut into 16 pieces)
+       small10_ord28 (2^10 x 2^28: 256 pieces per run)
 Algorithmic bytes: every input row read once (16 B), every result row written once (24 B; 16 B for the sort)."""
 import json
 import os
@@ -35,6 +36,10 @@ if name.startswith("small16"):
     if name == "small16_ord64":  # payloads over all 64 bits: the composite sort needs more passes
         S[:, 1] = S[:, 1] * 0x9E3779B97F4A7C15
     fl = {"count": 0, "mat": H.HMJ_MATERIALIZE, "ord": H.HMJ_ORDERED, "ord64": H.HMJ_ORDERED}[name.split("_")[1]]
+elif name == "small12_ord":
+    R, S, fl = ex.gen_build(1 << 12), ex.gen_uniform_domain(n26, 1 << 12), H.HMJ_ORDERED
+elif name == "small10_ord28":
+    R, S, fl = ex.gen_build(1 << 10), ex.gen_uniform_domain(n28, 1 << 10), H.HMJ_ORDERED
 elif name == "small11_count":
     R, S, fl = ex.gen_build(1 << 11), ex.gen_uniform_domain(n26, 1 << 11), 0
 elif name == "mid20_count":
