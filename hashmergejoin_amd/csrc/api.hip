@@ -2082,16 +2082,25 @@ static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe, 
   if (!c->rank_runs_mode || !c->slab_mode || n_build < 4 || n_probe > 0xFFFFFFFFull ||
       n_probe < (1u << 16))  // (a slab pass wants a few dozen tiles of rows)
     return false;
-  const int rank_bits = 64 - __builtin_clzll(n_build - 1);
-  if (rank_bits < 2 || rank_bits > 2 * hmj::SLAB_MAX_BITS) return false;
+  const int rank_bits = 64 - __builtin_clzll(n_build - 1), max_bits = 2 * hmj::SLAB_MAX_BITS;
+  if (rank_bits < 2) return false;
   double f = (double)n_probe / (double)n_build;
   if (f < 16.0) return false;
+  if (rank_bits > max_bits) {
+    // more ranks than two slab passes tell apart: 2^gb consecutive ranks to a partition (*tb = -gb), sorted there by (rank's
+    // low bits, payload) as one word -- where 2^gb runs still fit one workgroup's sort
+    const int gb = rank_bits - max_bits;
+    const double m = f * (double)(1u << (gb < 8 ? gb : 8));
+    if (gb > c->rank_runs_max_group || m + 8.0 * std::sqrt(m) + 24.0 > (double)hmj::rank_sort_max_run()) return false;
+    *tb = -gb;
+    return true;
+  }
   int t = 0;
   while (f + 8.0 * std::sqrt(f) + 24.0 > (double)hmj::rank_sort_max_run()) {
     f *= 0.5;
     t++;
   }
-  if (t > c->rank_runs_max_cut || rank_bits + t > 2 * hmj::SLAB_MAX_BITS) return false;
+  if (t > c->rank_runs_max_cut || rank_bits + t > max_bits) return false;
   if (t > 0) {
     // Payloads that grow with the row's position (row ids, timestamps): a worker of pass A reads `places` chunks from all
     // over the probe side (radix.hip, slab_a_body's strided form), each inside ONE piece; the fullest of its slabs must
@@ -2108,7 +2117,7 @@ static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe, 
 }
 // (what a workload's memo says on top: the form rests after it gave up; cut runs exist only with the lookup inside pass A)
 static bool rank_runs_rested(const hmj_ctx* c, int tb) {
-  return c->wm->rank_runs_cooldown == 0 && (tb == 0 || c->wm->rank_lookup_cooldown == 0);
+  return c->wm->rank_runs_cooldown == 0 && (tb <= 0 || c->wm->rank_lookup_cooldown == 0);
 }
 
 int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
@@ -2146,8 +2155,10 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     int run_tb = 0;
     const bool runs = rank_runs_fit(c, n_build, n_probe, &run_tb) && rank_runs_rested(c, run_tb);
     const double rank_ns = (chain ? m.comp_ns_chain : m.comp_ns_exact) + (n_build > c->gtable_max_rows ? m.comp_ns_beyond_l2 : 0.0);
-    const double rank_ms = runs ? m.runs_fixed_ms + (m.runs_ns + (run_tb ? m.runs_range_ns : 0.0)) * rows +
-                                      m.runs_ns_per_run * (double)(n_build << run_tb) * 1e-6
+    const double n_parts = run_tb >= 0 ? (double)(n_build << run_tb) : (double)(n_build >> -run_tb);
+    const double lb = std::log2((double)n_build) - 14.0;
+    const double rank_ms = runs ? m.runs_fixed_ms + (m.runs_ns + (run_tb > 0 ? m.runs_range_ns : 0.0) + (lb > 0.0 ? lb * m.runs_ns_per_log2_build : 0.0)) * rows +
+                                      m.runs_ns_per_run * n_parts * 1e-6
                                 : m.comp_fixed_ms + rank_ns * rows;
     if (c->gtable_sort_fanout > 1 && rank_ms >= m.part_fixed_ms + part_ns * rows) {
       c->plan.refused |= HMJ_REFUSED_RANK_SORT_MODEL;
@@ -2204,7 +2215,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     const u64 init[5] = {0, ~0ull, 0, ~0ull, 0};
     HIP_TRY(hipMemcpyAsync(c->offs64.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hmj::launch_key_exact(R, nb, nullptr, 0u, 0, (u64*)c->offs64.p, c->num_cus, c->stream, true));
-    if (have_range || run_tb > 0) HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream, range_every));
+    if (have_range || (use_runs && run_tb > 0)) HIP_TRY(hmj::launch_sval_range(S, np, (u64*)c->offs64.p + 3, c->num_cus, c->stream, range_every));
     HIP_TRY(hipMemcpyAsync(hh, c->offs64.p, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
@@ -2261,12 +2272,12 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   bool runs_done = false;
   u64 n = 0;
   if (use_runs) {
-    // the partition number: rank << tb | piece of the run (hmj_dev.h, rank_run_bucket)
-    const int TB = rank_bits + run_tb;
+    // the partition number: rank << tb | piece of the run (hmj_dev.h, rank_run_bucket); tb < 0: rank >> -tb
+    const int TB = rank_bits + run_tb, gb = run_tb < 0 ? -run_tb : 0, cut = run_tb > 0 ? run_tb : 0;
     const int bb = TB / 2, ba = TB - bb;  // LSD: pass A on the low digit, pass B on the high one
     const u32 P = 1u << TB;
     const int pre = range_bits > 32 ? range_bits - 32 : 0;
-    const u64 mult = run_tb ? ((u64)1 << (run_tb + 32)) / (((svmax - svmin) >> pre) + 1) : 0;
+    const u64 mult = cut ? ((u64)1 << (cut + 32)) / (((svmax - svmin) >> pre) + 1) : 0;
     u64* acc = (u64*)c->accum.p;
     const char* why = "";
     // rows -> partitions (fused: straight from the probe rows) -> offsets -> sorted runs; 0 ok, 1 gave up, < 0 error
@@ -2290,15 +2301,15 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       auto launch = [&](hipError_t e, const char* what) { return e == hipSuccess ? HMJ_OK : fail(c, HMJ_E_HIP, what, e); };
       int s2 = span_begin(c, K_SCATTER, 1, 0);
       if (fused)
-        r2 = launch(hmj::launch_slab_a_ranks(S, np, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->gtab.p,
-                                             log_cap, extra, run_tb, svmin, svmax - svmin, pre, mult, c->stream), "launch_slab_a_ranks");
+        r2 = launch(hmj::launch_slab_a_ranks(S, np, gb, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4, acc, c->gtab.p,
+                                             log_cap, extra, cut, svmin, svmax - svmin, pre, mult, c->stream), "launch_slab_a_ranks");
       else
-        r2 = launch(hmj::launch_slab_a(c->sbuf[0].p, (u32)rows, 0, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4,
+        r2 = launch(hmj::launch_slab_a(c->sbuf[0].p, (u32)rows, gb, ba, g, c->slab_a.p, c->slab_a.cap / 16, (u32*)c->cnt_a.p, c->cnt_a.cap / 4,
                                        acc, c->stream), "launch_slab_a");
       span_end(c, s2);
       if (r2 != HMJ_OK) return r2;
       s2 = span_begin(c, K_SCATTER, 1, 1);
-      r2 = launch(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, ba, bb, g, c->slab_bs.p, c->slab_bs.cap / 16, (u32*)c->cnt_bs.p,
+      r2 = launch(hmj::launch_slab_b(c->slab_a.p, (const u32*)c->cnt_a.p, ba, gb + ba, bb, g, c->slab_bs.p, c->slab_bs.cap / 16, (u32*)c->cnt_bs.p,
                                      c->cnt_bs.cap / 4, acc, c->stream), "launch_slab_b");
       span_end(c, s2);
       if (r2 != HMJ_OK) return r2;
@@ -2354,7 +2365,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
         runs_done = true;
       }
     }
-    if (!runs_done && run_tb == 0) {  // (cut runs: the emit below writes ranks, not partition numbers -- on to the composites)
+    if (!runs_done && run_tb <= 0) {  // (cut runs: the emit below writes ranks, not partition numbers -- on to the composites)
       HIP_TRY(hmj::launch_gtable_emit_ranks(S, np, c->gtab.p, log_cap, (u64*)c->accum.p, c->sbuf[0].p, extra, c->num_cus, c->gtable_wg_per_cu, c->stream));
       span_end(c, sp);
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -2650,6 +2661,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_GTABLE")) c->gtable_mode = atoi(e) != 0;  // 0: small build sides are partitioned too
   if (const char* e = getenv("HMJ_RANK_RUNS")) c->rank_runs_mode = atoi(e) != 0;  // 0: ordered small-build joins always sort composites
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_CUT")) c->rank_runs_max_cut = atoi(e) < 0 ? 0 : atoi(e) > 16 ? 16 : atoi(e);
+  if (const char* e = getenv("HMJ_RANK_RUNS_MAX_GROUP")) c->rank_runs_max_group = atoi(e) < 0 ? 0 : atoi(e) > 4 ? 4 : atoi(e);
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
   if (const char* e = getenv("HMJ_SORT_MSD")) c->sort_msd = atoi(e) != 0;  // 0: hmj_sort_u64_device never takes its MSD form (two slab passes + an LDS sort per partition)
@@ -2733,7 +2745,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
         {"comp_ns_exact", &c->ordered_model.comp_ns_exact}, {"comp_ns_wide", &c->ordered_model.comp_ns_wide},
         {"comp_ns_beyond_l2", &c->ordered_model.comp_ns_beyond_l2}, {"runs_fixed_ms", &c->ordered_model.runs_fixed_ms},
         {"runs_ns", &c->ordered_model.runs_ns}, {"runs_ns_per_run", &c->ordered_model.runs_ns_per_run},
-        {"runs_range_ns", &c->ordered_model.runs_range_ns}};
+        {"runs_range_ns", &c->ordered_model.runs_range_ns}, {"runs_ns_per_log2_build", &c->ordered_model.runs_ns_per_log2_build}};
     std::string spec(e);
     size_t pos = 0;
     while (pos < spec.size()) {

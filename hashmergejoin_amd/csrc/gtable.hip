@@ -823,7 +823,10 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
   return true;
 }
 
-template <bool EXTRA>
+// GROUP: more than 2^18 ranks -- a partition holds the runs of 2^gb consecutive ranks (gb = -tb), its rows are sorted by
+// (rank's low gb bits, sval) as ONE word, sub << bits(range) | (sval - min): the same sorts on a composite.  Payloads that
+// leave no room for the gb bits (a range beyond 2^(64 - gb)) raise ERR_FASTPATH.
+template <bool EXTRA, bool GROUP>
 __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
                                                                      u32 P, const u64* __restrict__ out_off,
                                                                      const Tup* __restrict__ sortedR, u32 nb, int tb, u64* __restrict__ out_key,
@@ -844,22 +847,31 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
     const u32 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
     const u32 n = c0 + c1 + c2 + c3;
     if (n == 0) continue;
-    if (n > (u32)RS_CAP || (p >> tb) >= nb || c0 > cap || c1 > cap || c2 > cap || c3 > cap) {  // (uniform) a run beyond the kernel, or counts no slab pass wrote
+    const int gb = GROUP ? -tb : 0;
+    if (n > (u32)RS_CAP || (GROUP ? ((u64)p << gb) : (u64)(p >> tb)) >= nb || c0 > cap || c1 > cap || c2 > cap || c3 > cap) {  // (uniform) a run beyond the kernel, or counts no slab pass wrote
       bad = true;
       continue;
     }
     const Tup* __restrict__ base = slabs + (u64)p * SLAB_KB * cap;
     // ---- the run's payloads, coalesced piece by piece; their range
     u64 sv[RS_EPT];
+    u32 sub[GROUP ? RS_EPT : 1];
     u64 mn = ~0ull, mx = 0;
 #pragma unroll
     for (int r = 0; r < RS_EPT; r++) {
       const u32 i = (u32)tid + (u32)r * RS_THREADS;
       sv[r] = 0;
+      if (GROUP) sub[r] = 0;
       if (i < n) {
         const u32 k = i < c0 ? 0u : i < c0 + c1 ? 1u : i < c0 + c1 + c2 ? 2u : 3u;
         const u32 start = k == 0 ? 0u : k == 1 ? c0 : k == 2 ? c0 + c1 : c0 + c1 + c2;
-        sv[r] = load_stream(&base[(u64)k * cap + (i - start)]).val;
+        if (GROUP) {
+          const Tup row = load_stream(&base[(u64)k * cap + (i - start)]);
+          sv[r] = row.val;
+          sub[r] = (u32)row.key & ((1u << gb) - 1u);
+        } else {
+          sv[r] = load_stream(&base[(u64)k * cap + (i - start)]).val;
+        }
         mn = sv[r] < mn ? sv[r] : mn;
         mx = sv[r] > mx ? sv[r] : mx;
       }
@@ -880,10 +892,25 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
       mn = wmn[w] < mn ? wmn[w] : mn;
       mx = wmx[w] > mx ? wmx[w] : mx;
     }
-    const u64 range = mx - mn;
+    u64 range = mx - mn;
+    const u64 mn_s = mn;
+    int rb = 0;
+    if (GROUP) {  // the composite: (rank's low bits, sval - min) in one word
+      rb = range ? 64 - __builtin_clzll(range) : 0;
+      if (rb + gb > 64) {  // (uniform)
+        bad = true;
+        lds_barrier();
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < RS_EPT; r++) sv[r] = (rb < 64 ? (u64)sub[r] << rb : 0ull) | (sv[r] - mn_s);
+      range = (rb < 64 ? (u64)((1u << gb) - 1u) << rb : 0ull) | range;
+      mn = 0;
+    }
     u32 N = 8;
     while (N < n) N <<= 1;
-    const Tup b = sortedR[p >> tb];  // (tb > 0: a key's run is cut into 2^tb partitions by the position of the payload in the payloads' range)
+    // (tb > 0: a key's run is cut into 2^tb partitions by the position of the payload in the payloads' range)
+    const Tup b = GROUP ? Tup{0, 0} : sortedR[p >> tb];
     const u64 off = out_off[p];
     if (range == 0) {
       // one payload value in the whole run: nothing to sort
@@ -938,17 +965,24 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
     for (int r = 0; r < RS_EPT; r++) {
       const u32 i = (u32)tid + (u32)r * RS_THREADS;
       if (i < n) {
-        out_key[off + i] = b.key;
-        out_rval[off + i] = b.val;
-        out_sval[off + i] = sv[r];
+        Tup br = b;
+        u64 s1 = sv[r];
+        if (GROUP) {
+          br = sortedR[((u64)p << gb) + (rb < 64 ? s1 >> rb : 0ull)];
+          s1 = (rb < 64 ? s1 & (((u64)1 << rb) - 1) : s1) + mn_s;
+          acc_r += br.val;
+        }
+        out_key[off + i] = br.key;
+        out_rval[off + i] = br.val;
+        out_sval[off + i] = s1;
         if (EXTRA) {
-          const u64 m = tmix(b.key, b.val, sv[r]);
+          const u64 m = tmix(br.key, br.val, s1);
           acc_x ^= m;
           acc_m += m;
         }
       }
     }
-    if (tid == 0) acc_r += b.val * (u64)n;
+    if (!GROUP && tid == 0) acc_r += b.val * (u64)n;
     lds_barrier();  // (keys / wmn / wmx are rewritten by the next run)
   }
   if (bad && tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
@@ -1170,16 +1204,20 @@ hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u3
 int rank_sort_max_run() { return RS_CAP; }
 hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb, int tb,
                                   u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st) {
-  if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0 || tb < 0 || tb > 16)
+  // tb > 0: a rank's run is 2^tb partitions; tb < 0: a partition is the runs of 2^-tb consecutive ranks
+  if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0 || tb < -4 || tb > 16)
     return hipErrorInvalidValue;
   u32 grid = (u32)num_cus * 5u;  // what is resident at once: 96 registers (launch bounds) and 28 KiB of LDS per 256-thread workgroup
   if (grid > P) grid = P;
-  if (extra)
-    hipLaunchKernelGGL((rank_sort_write_kernel<true>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
-                       static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum);
-  else
-    hipLaunchKernelGGL((rank_sort_write_kernel<false>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
-                       static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum);
+#define HMJ_RSW(E, G)                                                                                                                            \
+  hipLaunchKernelGGL((rank_sort_write_kernel<E, G>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off, \
+                     static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum)
+  if (tb < 0) {
+    if (extra) HMJ_RSW(true, true); else HMJ_RSW(false, true);
+  } else {
+    if (extra) HMJ_RSW(true, false); else HMJ_RSW(false, false);
+  }
+#undef HMJ_RSW
   return hipGetLastError();
 }
 

@@ -86,6 +86,7 @@ struct OrderedCostModel {
   double comp_ns_beyond_l2 = 0.02;                      // + where the key -> rank table leaves an XCD's L2
   // rank runs: two slab passes on the rank + an LDS sort per run
   double runs_fixed_ms = 0.25, runs_ns = 0.0215, runs_ns_per_run = 7.5;
+  double runs_ns_per_log2_build = 0.0023;  // ... + this per probe row and doubling of the build side beyond 2^14 rows (the rank table and the build rows leave the L2: 2^14 / 2^18 / 2^20 x 2^28 rows 8.5 / 11.0 / 12.6 ms)
   double runs_range_ns = 0.0;    // cut runs: the range of the payloads comes from a sample of ~2^17 rows (a pass over all of them cost 0.003)
 };
 }  // namespace hmj_host
@@ -160,6 +161,7 @@ struct hmj_ctx {
   u32 gtable_sort_fanout = 128;    // ... from this many probe rows per build row on (HMJ_GTABLE_SORT_FANOUT)
   bool rank_runs_mode = true;      // ordered, small build side, fan-out from 16: partition by rank, sort every rank's run in LDS (HMJ_RANK_RUNS=0: composites)
   int rank_runs_max_cut = 10;       // ... runs beyond ~1700 rows cut into up to 2^this pieces by payload position (HMJ_RANK_RUNS_MAX_CUT; 0: such joins sort composites)
+  int rank_runs_max_group = 3;     // ... more than 2^18 build rows: up to 2^this consecutive ranks share a partition (HMJ_RANK_RUNS_MAX_GROUP; 0: such joins take other paths)
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)

@@ -168,7 +168,7 @@ hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u3
                                   hipStream_t st);
 hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb, int tb,
                                   u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st);
-hipError_t launch_slab_a_ranks(const void* in, u32 n, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
+hipError_t launch_slab_a_ranks(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
                                u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, int tb, u64 svmin, u64 svrange, int pre,
                                u64 mult, hipStream_t st);
 hipError_t launch_slab_offsets(const u32* cnt /* P x SLAB_KB piece counts */, u32 P, u64* off /* P + 1 */, u64* scratch /* ceil(P / 1024) */,

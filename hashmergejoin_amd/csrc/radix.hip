@@ -1344,14 +1344,14 @@ struct RankXform {
 };
 template <int THREADS, int MAXD, bool CUT>
 __global__ __launch_bounds__(THREADS, (THREADS * (MAXD <= 256 ? 2 : 1)) / 256) void radix_slab_a_rank_kernel(
-    const Tup* __restrict__ in, u32 n, int bits, u32 rows_per_worker, Tup* __restrict__ slab, u32 CA, u32 WA,
+    const Tup* __restrict__ in, u32 n, int shift, int bits, u32 rows_per_worker, Tup* __restrict__ slab, u32 CA, u32 WA,
     u32* __restrict__ cnt_out, u64* __restrict__ accum, const Tup* __restrict__ tab, int log_cap, bool extra, int tb, u64 svmin, u64 svrange,
     int pre, u64 mult, u32 slot_mult) {
   // (duplicate build keys or a table that gave up -- the host sees the same words and discards this pass -- need no early
   //  exit: the table is fully initialised either way, every walk ends at an empty slot, every rank is a build row's index;
   //  and pass B trusts the counts written below, so they must be written)
   RankXform<CUT> xf{slot_mult, tab, (1u << log_cap) - 1, 64 - log_cap, tb, pre, svmin, svrange, mult, 0ull, 0ull, false};
-  slab_a_body<THREADS, MAXD, false, RankXform<CUT>>(in, n, 0, bits, rows_per_worker, slab, CA, WA, cnt_out, accum, 0u, xf);
+  slab_a_body<THREADS, MAXD, false, RankXform<CUT>>(in, n, shift, bits, rows_per_worker, slab, CA, WA, cnt_out, accum, 0u, xf);  // (shift: ranks grouped 2^shift to a partition)
   // sums: one set of atomics per workgroup
   __shared__ u64 wsum[THREADS / kWave], wrows[THREADS / kWave];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1493,11 +1493,11 @@ hipError_t launch_slab_a(const void* in, u32 n, int shift, int bits, const SlabG
 }
 
 // pass A of the rank-run form with the key -> rank lookup in front (radix_slab_a_rank_kernel): in = PROBE rows
-hipError_t launch_slab_a_ranks(const void* in, u32 n, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
+hipError_t launch_slab_a_ranks(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
                                u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, int tb, u64 svmin, u64 svrange, int pre,
                                u64 mult, hipStream_t st) {
   if (bits < 1 || bits > SLAB_MAX_BITS || g.WA == 0 || g.CA == 0 || (u64)g.WA * g.rpw < n || !tab || log_cap < 4 || log_cap > 30 || tb < 0 ||
-      tb > 16 || pre < 0 || pre > 32)
+      tb > 16 || pre < 0 || pre > 32 || shift < 0 || shift > 4 || (shift && tb))
     return hipErrorInvalidValue;
   if (slab_a_rows < ((u64)g.WA << bits) * g.CA || cnt_a_n < ((u64)g.WA << bits)) return hipErrorInvalidValue;
   if (((u64)g.WA << bits) * g.CA >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
@@ -1521,7 +1521,7 @@ hipError_t launch_slab_a_ranks(const void* in, u32 n, int bits, const SlabGeom& 
     static SmemAttrOnce once;                                                                                                         \
     if (hipError_t e = ensure_max_smem(once, reinterpret_cast<const void*>(radix_slab_a_rank_kernel<T, M, C>), sizeof(Smem)); e != hipSuccess) \
       return e;                                                                                                                       \
-    hipLaunchKernelGGL((radix_slab_a_rank_kernel<T, M, C>), dim3(g.WA), dim3(T), sizeof(Smem), st, static_cast<const Tup*>(in), n, bits, g.rpw, \
+    hipLaunchKernelGGL((radix_slab_a_rank_kernel<T, M, C>), dim3(g.WA), dim3(T), sizeof(Smem), st, static_cast<const Tup*>(in), n, shift, bits, g.rpw, \
                        static_cast<Tup*>(slab_a), g.CA, g.WA, cnt_a, accum, static_cast<const Tup*>(tab), log_cap, extra, tb, svmin, svrange, pre, mult, \
                        slot_mult);                                                                                                    \
   }

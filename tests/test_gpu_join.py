@@ -580,13 +580,18 @@ def test_full_size_closed_form(ex, H, G, log2n, bits):
 
 
 def _rank_runs_cut(nb, npb, chunk_rows=64, max_run=2048, max_cut=10):
-    """The host's rank_runs_fit (api.hip): None where the rank-run form does not apply, else log2 of the pieces a key's run is cut into."""
+    """The host's rank_runs_fit (api.hip): None where the rank-run form does not apply, else log2 of the pieces a key's run is cut into
+    (negative: log2 of the ranks that share a partition)."""
     if nb < 4 or npb < 1 << 16 or npb >= 1 << 32:
         return None
     rank_bits = (nb - 1).bit_length()
     f = npb / nb
-    if rank_bits < 2 or rank_bits > 18 or f < 16:
+    if rank_bits < 2 or f < 16:
         return None
+    if rank_bits > 18:  # 2^gb consecutive ranks share a partition: -gb
+        gb = rank_bits - 18
+        m = f * (1 << gb)
+        return -gb if gb <= 3 and m + 8 * m ** 0.5 + 24 <= max_run else None
     t = 0
     while f + 8 * f ** 0.5 + 24 > max_run:
         f, t = f / 2, t + 1
@@ -605,16 +610,18 @@ def _rank_runs_cut(nb, npb, chunk_rows=64, max_run=2048, max_cut=10):
     return t
 
 
-@pytest.mark.parametrize("log2b,log2p,wide", [(16, 26, False), (16, 26, True), (18, 26, False), (12, 26, False), (10, 26, True), (14, 24, True)])
+@pytest.mark.parametrize("log2b,log2p,wide", [(16, 26, False), (16, 26, True), (18, 27, False), (12, 26, False), (10, 26, True), (14, 24, True),
+                                              (19, 27, False)])
 def test_full_size_ordered_small_build_side(ex_fresh, H, log2b, log2p, wide):
     # The operator's mode for a dimension table under a fact table at sizes no CPU oracle reaches in seconds (the bench's
     # small_build_2p16_x_2p26_ordered entry): checked ROW BY ROW on the device through the generators' own arithmetic.
     # Every result row must pair the build row and the probe row it names (rval is the build row's index, sval identifies
     # the probe row), every probe row must appear exactly once, keys must ascend and, inside a key, probe payloads must
     # ascend (unsigned) -- that is HashMergeJoin's iteration order for unique build keys (hashjoin.h:104-154).
-    # (16 / 18, 26): rank runs (fan-out 1024 / 256); wide: payloads spanning 64 bits; (12 / 10, 26): runs of 16384 / 65536 rows,
+    # (16, 26) / (18, 27): rank runs (fan-out 1024 / 512; at 2^18 x 2^26 the cost model prefers the partitioned write by a hair); wide: payloads spanning 64 bits; (12 / 10, 26): runs of 16384 / 65536 rows,
     # cut into 16 / 64 pieces by the position of the payload in the payloads' range (the generator's payloads are row ids:
-    # pieces and row positions go together, the case the strided pass A is for).
+    # pieces and row positions go together, the case the strided pass A is for).  (19, 27): more ranks than two slab passes tell
+    # apart -- two ranks to a partition, sorted there by (rank's low bit, payload).
     import torch
 
     from hashmergejoin_amd.join import _memcpy_d2d
@@ -630,7 +637,7 @@ def test_full_size_ordered_small_build_side(ex_fresh, H, log2b, log2p, wide):
     t = ex.last_timing()
     assert int(r.n_matches) == npb
     assert t["path"] & H.HMJ_PATH_ORDER_BY_RANK_SORT, hex(t["path"])
-    assert _rank_runs_cut(nb, npb) == {16: 0, 18: 0, 14: 0, 12: 4, 10: 6}[log2b]
+    assert _rank_runs_cut(nb, npb) == {16: 0, 18: 0, 14: 0, 12: 4, 10: 6, 19: -1}[log2b]
     assert t["path"] & H.HMJ_PATH_RANK_RUNS and t["path"] & H._lib.HMJ_PATH_RANK_LOOKUP_IN_PASS, hex(t["path"])
     cols = []
     for ptr in (r.key, r.rval, r.sval):
@@ -1444,7 +1451,11 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
                                # 64-bit payloads, a ragged last chunk, probe rows without a build row (-> composites), payloads
                                # of seven values (pieces that cannot be even -> composites)
                                (300, 1 << 22, 0, "ids"), (300, (1 << 22) - 77, 0, "rowid"), (500, 3000001, 0, "wide"),
-                               (37, 1 << 20, 0, "rowid"), (300, 1 << 22, 3, "offset"), (100, 1 << 21, 0, "ties7")]:
+                               (37, 1 << 20, 0, "rowid"), (300, 1 << 22, 3, "offset"), (100, 1 << 21, 0, "ties7"),
+                               # more than 2^18 build rows: two / four ranks to a partition, sorted by (rank's low bits, payload) as one
+                               # word; with unmatched probe rows (emit route); 64-bit payloads leave no room for the rank bits -> composites
+                               (300000, 1 << 23, 0, "rowid"), (300001, (1 << 23) + 5, 3, "offset"), (600000, 1 << 24, 0, "ids"),
+                               (280000, 5000000, 0, "wide")]:
         B = oracle.gen_build(nb)
         P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
         if pay == "hot":  # a third of the probe rows carry one key: its run is beyond any workgroup
@@ -1478,7 +1489,8 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             assert took == (pay in ("ids", "rowid", "offset", "wide", "hot", "ties7", "const", "extremes")), (nb, npb, pay, fl, hex(t["path"]))
             cut = _rank_runs_cut(nb, npb)
             # (cut runs exist only with the lookup inside pass A, and their pieces are even only where the payloads are spread)
-            runs = pay in ("ids", "rowid", "offset", "wide", "ties7", "const") and cut is not None and (cut == 0 or (miss == 0 and pay != "ties7"))
+            runs = pay in ("ids", "rowid", "offset", "wide", "ties7", "const") and cut is not None and (
+                cut == 0 or (cut > 0 and miss == 0 and pay != "ties7") or (cut < 0 and pay != "wide"))
             assert bool(t["path"] & RR) == runs, (nb, npb, pay, fl, hex(t["path"]))
             # every probe row has its build row (miss == 0): the rank lookup runs inside the first slab pass; unmatched
             # probe rows make that attempt give way to emit + pass A (and the workload remembers)
