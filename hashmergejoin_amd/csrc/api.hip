@@ -2077,43 +2077,55 @@ static double ordered_part_ns(const OrderedCostModel& m, double f, double n_prob
 // spread (mean + 8 sigma of a run of a uniform foreign key), both digits of the partition number must be slab passes, and
 // the partitions must be long enough for a workgroup each to pay.  A partition is a rank's whole run up to fan-outs of
 // ~1700 (*tb = 0); beyond, a run is cut into 2^tb partitions by the position of the payload in the payloads' range.
-static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe, int* tb) {
+static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe, int* tb, int* level) {
   *tb = 0;
+  *level = 0;
   if (!c->rank_runs_mode || !c->slab_mode || n_build < 4 || n_probe > 0xFFFFFFFFull ||
       n_probe < (1u << 16))  // (a slab pass wants a few dozen tiles of rows)
     return false;
   const int rank_bits = 64 - __builtin_clzll(n_build - 1), max_bits = 2 * hmj::SLAB_MAX_BITS;
   if (rank_bits < 2) return false;
-  double f = (double)n_probe / (double)n_build;
-  if (f < 16.0) return false;
+  const double f0 = (double)n_probe / (double)n_build;
+  if (f0 < 16.0) return false;
+  auto fits = [](double m, int lv) { return m + 8.0 * std::sqrt(m) + 24.0 <= (double)hmj::rank_sort_max_run(lv); };
   if (rank_bits > max_bits) {
     // more ranks than two slab passes tell apart: 2^gb consecutive ranks to a partition (*tb = -gb), sorted there by (rank's
     // low bits, payload) as one word -- where 2^gb runs still fit one workgroup's sort
     const int gb = rank_bits - max_bits;
-    const double m = f * (double)(1u << (gb < 8 ? gb : 8));
-    if (gb > c->rank_runs_max_group || m + 8.0 * std::sqrt(m) + 24.0 > (double)hmj::rank_sort_max_run()) return false;
+    if (gb > c->rank_runs_max_group) return false;
+    const double m = f0 * (double)(1u << gb);
+    int lv = 0;
+    while (lv <= c->rank_runs_max_level && !fits(m, lv)) lv++;
+    if (lv > c->rank_runs_max_level) return false;
     *tb = -gb;
+    *level = lv;
     return true;
   }
-  int t = 0;
-  while (f + 8.0 * std::sqrt(f) + 24.0 > (double)hmj::rank_sort_max_run()) {
-    f *= 0.5;
-    t++;
+  // the smallest workgroup shape (the fastest: most workgroups per CU) whose cut stays within two slab passes
+  for (int lv = 0; lv <= c->rank_runs_max_level; lv++) {
+    double f = f0;
+    int t = 0;
+    while (!fits(f, lv)) {
+      f *= 0.5;
+      t++;
+    }
+    if (rank_bits + t > max_bits || t > c->rank_runs_max_cut) continue;
+    if (t > 0) {
+      // Payloads that grow with the row's position (row ids, timestamps): a worker of pass A reads `places` chunks from all
+      // over the probe side (radix.hip, slab_a_body's strided form), each inside ONE piece; the fullest of its slabs must
+      // still be within a slab's capacity (slab_geometry: mean + 8 sqrt(mean) + 24), or the attempt is known to overflow.
+      const int TB = rank_bits + t, ba = TB - TB / 2;
+      const double tile = ba > 8 ? 4096.0 : 2048.0, tiles = std::ceil((double)n_probe / tile), tpw = std::ceil(tiles / 2048.0);
+      const double rpw = tpw * tile, places = rpw / (double)hmj::RANK_PASS_CHUNK_ROWS, pieces = (double)(1u << t);
+      const double skew = places >= pieces ? std::ceil(places / pieces) / (places / pieces) : pieces / places;
+      const double mean = rpw / (double)(1u << ba);
+      if (skew * mean + 4.0 * std::sqrt(skew * mean) > mean + 8.0 * std::sqrt(mean) + 24.0) return false;
+    }
+    *tb = t;
+    *level = lv;
+    return true;
   }
-  if (t > c->rank_runs_max_cut || rank_bits + t > max_bits) return false;
-  if (t > 0) {
-    // Payloads that grow with the row's position (row ids, timestamps): a worker of pass A reads `places` chunks from all
-    // over the probe side (radix.hip, slab_a_body's strided form), each inside ONE piece; the fullest of its slabs must
-    // still be within a slab's capacity (slab_geometry: mean + 8 sqrt(mean) + 24), or the attempt is known to overflow.
-    const int TB = rank_bits + t, ba = TB - TB / 2;
-    const double tile = ba > 8 ? 4096.0 : 2048.0, tiles = std::ceil((double)n_probe / tile), tpw = std::ceil(tiles / 2048.0);
-    const double rpw = tpw * tile, places = rpw / (double)hmj::RANK_PASS_CHUNK_ROWS, pieces = (double)(1u << t);
-    const double skew = places >= pieces ? std::ceil(places / pieces) / (places / pieces) : pieces / places;
-    const double mean = rpw / (double)(1u << ba);
-    if (skew * mean + 4.0 * std::sqrt(skew * mean) > mean + 8.0 * std::sqrt(mean) + 24.0) return false;
-  }
-  *tb = t;
-  return true;
+  return false;
 }
 // (what a workload's memo says on top: the form rests after it gave up; cut runs exist only with the lookup inside pass A)
 static bool rank_runs_rested(const hmj_ctx* c, int tb) {
@@ -2152,8 +2164,8 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     //  one piece only and its slab for that digit overflows, whichever digit the piece bits go into: the pass with the
     //  lookup reads 4 KiB chunks from all over the relation instead (radix.hip, RankXform::kStrided); + one pass over the
     //  payloads for their range)
-    int run_tb = 0;
-    const bool runs = rank_runs_fit(c, n_build, n_probe, &run_tb) && rank_runs_rested(c, run_tb);
+    int run_tb = 0, run_level = 0;
+    const bool runs = rank_runs_fit(c, n_build, n_probe, &run_tb, &run_level) && rank_runs_rested(c, run_tb);
     const double rank_ns = (chain ? m.comp_ns_chain : m.comp_ns_exact) + (n_build > c->gtable_max_rows ? m.comp_ns_beyond_l2 : 0.0);
     const double n_parts = run_tb >= 0 ? (double)(n_build << run_tb) : (double)(n_build >> -run_tb);
     const double lb = std::log2((double)n_build) - 14.0;
@@ -2200,8 +2212,8 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
   };
   // ---- 1. which 8-bit digits the build keys differ in, and -- for the composite form -- the range of the probe payloads
   // (one read-back)
-  int run_tb = 0;
-  bool use_runs = rank_runs_fit(c, n_build, n_probe, &run_tb);
+  int run_tb = 0, run_level = 0;
+  bool use_runs = rank_runs_fit(c, n_build, n_probe, &run_tb, &run_level);
   if (use_runs && !rank_runs_rested(c, run_tb)) {
     if (c->wm->rank_runs_cooldown > 0)
       c->wm->rank_runs_cooldown--;
@@ -2319,7 +2331,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
       if (r2 != HMJ_OK) return r2;
       s2 = span_begin(c, K_PROBE_WRITE, -1);
       r2 = launch(hmj::launch_rank_sort_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, sortedR, nb,
-                                              run_tb, (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, acc, extra, c->num_cus, c->stream),
+                                              run_tb, (u64*)c->out_key.p, (u64*)c->out_rval.p, (u64*)c->out_sval.p, acc, extra, run_level, c->num_cus, c->stream),
                   "launch_rank_sort_write");
       span_end(c, s2);
       if (r2 != HMJ_OK) return r2;
@@ -2662,9 +2674,11 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_RANK_RUNS")) c->rank_runs_mode = atoi(e) != 0;  // 0: ordered small-build joins always sort composites
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_CUT")) c->rank_runs_max_cut = atoi(e) < 0 ? 0 : atoi(e) > 16 ? 16 : atoi(e);
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_GROUP")) c->rank_runs_max_group = atoi(e) < 0 ? 0 : atoi(e) > 4 ? 4 : atoi(e);
+  if (const char* e = getenv("HMJ_RANK_RUNS_MAX_LEVEL")) c->rank_runs_max_level = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);  // 0: the LDS sorts' 256-thread shape only (2048 rows per partition)
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
   if (const char* e = getenv("HMJ_SORT_MSD")) c->sort_msd = atoi(e) != 0;  // 0: hmj_sort_u64_device never takes its MSD form (two slab passes + an LDS sort per partition)
+  if (const char* e = getenv("HMJ_SORT_MSD_MAX_BITS")) c->sort_msd_max_bits = atoi(e) < 2 ? 2 : atoi(e) > 18 ? 18 : atoi(e);  // fewer, larger partitions (up to 8192 rows each)
   if (const char* e = getenv("HMJ_SORT_MSD_MIN_LOG2")) {
     const int l = atoi(e);
     if (l >= 16 && l <= 32) c->sort_msd_min = 1ull << l;
@@ -3287,11 +3301,14 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
         if (dens > 64.0) dens = 64.0;
       }
       mean = dens * (double)n / std::ldexp(1.0, TB);
-    } while (TB < 18 && mean > 1200.0);
+    } while (TB < c->sort_msd_max_bits && mean > 1200.0);
     if (TB > hi) TB = 0;
+    // (beyond 4.5 * 10^8 rows the 2^18 partitions outgrow the 256-thread sort: 512 / 1024 threads hold 4096 / 8192 rows)
+    int level = 0;
+    while (level < c->rank_runs_max_level && mean + 8.0 * std::sqrt(mean) + 24.0 > (double)hmj::rank_sort_max_run(level)) level++;
     const int bb = TB / 2, ba = TB - bb, shift_a = hi - TB, shift_b = shift_a + ba;
     hmj::SlabGeom g;
-    if (TB >= 2 && ba <= hmj::SLAB_MAX_BITS && mean + 8.0 * std::sqrt(mean) + 24.0 <= (double)hmj::rank_sort_max_run() &&
+    if (TB >= 2 && ba <= hmj::SLAB_MAX_BITS && mean + 8.0 * std::sqrt(mean) + 24.0 <= (double)hmj::rank_sort_max_run(level) &&
         hmj::slab_geometry((u32)n, ba, bb, &g, 0, 1.0, dens)) {
       const u32 P = 1u << TB;
       if ((rc = ensure_dev(c, c->accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
@@ -3314,8 +3331,8 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
       span_end(c, sp);
       HIP_TRY(hmj::launch_slab_offsets((const u32*)c->cnt_bs.p, P, (u64*)c->part_out_off.p, (u64*)c->part_count.p, c->stream));
       sp = span_begin(c, K_ORDER, -1);
-      HIP_TRY(hmj::launch_sort_runs_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, out_aos_dev, acc, c->num_cus,
-                                          c->stream));
+      HIP_TRY(hmj::launch_sort_runs_write(c->slab_bs.p, (const u32*)c->cnt_bs.p, g.CB, P, (const u64*)c->part_out_off.p, out_aos_dev, acc, level,
+                                          c->num_cus, c->stream));
       span_end(c, sp);
       HIP_TRY(hipMemcpyAsync(hh, c->accum.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));

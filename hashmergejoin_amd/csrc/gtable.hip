@@ -646,9 +646,22 @@ __global__ __launch_bounds__(256) void pieces_compact_kernel(const Tup* __restri
 // in LDS -- a register-tiled bitonic network on 32-bit keys sval - min (or the 64-bit svals where a run spans more) -- and
 // writes (key, rval, sval) at the rank's offset.  Two global passes instead of five, no payload range needed, payload
 // width irrelevant.  Fan-outs beyond ~1700: the host cuts every run into 2^tb pieces by payload position (partition =
-// rank << tb | piece, api.hip / radix.hip RankXform<true>).  Partitions beyond RS_CAP rows (a hot key) raise ERR_FASTPATH: the
+// rank << tb | piece, api.hip / radix.hip RankXform<true>).  Partitions beyond the workgroup's capacity (a hot key) raise ERR_FASTPATH: the
 // composite form runs.
-constexpr int RS_THREADS = 256, RS_EPT = 8, RS_CAP = RS_THREADS * RS_EPT;  // 2048 rows per rank at most
+constexpr int RS_EPT = 8;  // rows per thread: a workgroup of T = 256 / 512 / 1024 threads sorts up to 2048 / 4096 / 8192 rows
+// (the 256-thread shape is the fast one -- five workgroups per CU; the larger ones exist for partitions that two 9-bit slab
+//  passes cannot make smaller: sorts beyond 4.5 * 10^8 rows, ordered joins under > 2^29 probe rows)
+// LDS of one workgroup (dynamic: 129 KiB at T = 1024).  OIDX: the stable sort's original positions (hmj_sort_u64_device only)
+template <int T, bool OIDX>
+struct RsSmem {
+  u64 keys[T * RS_EPT];                       // the run's keys (64-bit, or 32-bit in its first half); later payloads by the same slots
+  u32 bcnt[T * RS_EPT + 2];                   // bucket counts / starts (+ pad: what follows stays 8-byte aligned)
+  unsigned short sidx[T * RS_EPT];            // bucket sort: slot of the i-th smallest key
+  unsigned short oidx[OIDX ? T * RS_EPT : 4];
+  u32 wsc[2 * (T / kWave)];
+  u64 wmn[T / kWave], wmx[T / kWave];
+  u64 red[8];
+};
 // LDS position of element i: the low three index bits XORed with bits 5..7, so that the eight consecutive elements a
 // thread takes in the stride-1 steps fall into different banks than its neighbours' (16-way conflicts otherwise)
 __device__ __forceinline__ u32 rs_sw(u32 i) { return i ^ ((i >> 5) & 7u); }
@@ -670,7 +683,7 @@ __device__ __forceinline__ void rs_three_levels(K (&v)[RS_EPT], bool asc) {
 #pragma unroll
   for (int i = 0; i < 8; i += 2) rs_ce(v[i], v[i + 1], asc);
 }
-// Sort s[rs_sw(0 .. N)) ascending; N a power of two in [8, RS_CAP]; threads tid < N / 8 work, all threads pass the barriers.
+// Sort s[rs_sw(0 .. N)) ascending; N a power of two in [8, 8 T]; threads tid < N / 8 work, all threads pass the barriers.
 // (not inlined: the network is the fallback of the bucket sort below, and its 16 + 16 key registers would otherwise count
 //  against the occupancy of the kernel's common path)
 template <typename K>
@@ -727,22 +740,22 @@ __device__ __attribute__((noinline)) void rs_bitonic(K* __restrict__ s, u32 N, i
 // the order the atomics happened to number them -- fine where only the keys are of interest).  slot_out[r]: where the
 // thread's r-th key was put in tmp (the caller moves the keys' payloads through the same slots).
 constexpr u32 RS_MAXBUCKET = 24;
-template <typename K, bool STABLE = false>
+template <typename K, int T, bool STABLE = false>
 __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, u64 range, u32 n, K* __restrict__ tmp, unsigned short* __restrict__ idx,
                                                u32* __restrict__ cnt, u32* __restrict__ wsc, int tid, unsigned short* __restrict__ oidx = nullptr,
                                                u32* slot_out = nullptr) {
   const int lane = tid & 63, wv = tid >> 6;
-  u32 NB = RS_THREADS;
+  u32 NB = T;
   while (NB < n) NB <<= 1;
   const int lg = 31 - __builtin_clz(NB);
   const int bits = 64 - __builtin_clzll(range);  // (range > 0)
   const int sh = bits > lg ? bits - lg : 0;
-  for (u32 i = (u32)tid; i <= NB; i += RS_THREADS) cnt[i] = 0;
+  for (u32 i = (u32)tid; i <= NB; i += T) cnt[i] = 0;
   lds_barrier();
   u32 bk[RS_EPT], ar[RS_EPT];
 #pragma unroll
   for (int r = 0; r < RS_EPT; r++) {
-    const u32 i = (u32)tid + (u32)r * RS_THREADS;
+    const u32 i = (u32)tid + (u32)r * T;
     bk[r] = ar[r] = 0;
     if (i < n) {
       bk[r] = (u32)((sv[r] - mn) >> sh);
@@ -751,7 +764,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
   }
   lds_barrier();
   // exclusive scan of the NB counts in place (thread t: entries [t * E, (t + 1) * E)), and the longest bucket
-  const u32 E = NB / RS_THREADS;  // 1 ... 8
+  const u32 E = NB / T;  // 1 ... 8
   u32 loc[RS_EPT], sum = 0, big = 0;
 #pragma unroll
   for (int e = 0; e < RS_EPT; e++) {
@@ -771,13 +784,13 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
     big = b2 > big ? b2 : big;
   }
   if (lane == kWave - 1) wsc[wv] = incl;
-  if (lane == 0) wsc[4 + wv] = big;
+  if (lane == 0) wsc[T / kWave + wv] = big;
   lds_barrier();
   u32 before = 0;
 #pragma unroll
-  for (int w = 0; w < RS_THREADS / kWave; w++) {
+  for (int w = 0; w < T / kWave; w++) {
     if (w < wv) before += wsc[w];
-    big = wsc[4 + w] > big ? wsc[4 + w] : big;
+    big = wsc[T / kWave + w] > big ? wsc[T / kWave + w] : big;
   }
   if (big > RS_MAXBUCKET) {  // (uniform) ties or clustered payloads
     lds_barrier();
@@ -790,12 +803,12 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
       cnt[(u32)tid * E + (u32)e] = run;
       run += loc[e];
     }
-  if (tid == RS_THREADS - 1) cnt[NB] = n;
+  if (tid == T - 1) cnt[NB] = n;
   lds_barrier();
   // keys to their buckets (arrival order), then every key ranks itself inside its bucket
 #pragma unroll
   for (int r = 0; r < RS_EPT; r++) {
-    const u32 i = (u32)tid + (u32)r * RS_THREADS;
+    const u32 i = (u32)tid + (u32)r * T;
     if (i < n) {
       const u32 me = cnt[bk[r]] + ar[r];
       tmp[me] = (K)(sv[r] - mn);
@@ -806,7 +819,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
   lds_barrier();
 #pragma unroll
   for (int r = 0; r < RS_EPT; r++) {
-    const u32 i = (u32)tid + (u32)r * RS_THREADS;
+    const u32 i = (u32)tid + (u32)r * T;
     if (i < n) {
       const u32 s0 = cnt[bk[r]], e0 = cnt[bk[r] + 1], me = s0 + ar[r];
       const K key = (K)(sv[r] - mn);
@@ -826,18 +839,22 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
 // GROUP: more than 2^18 ranks -- a partition holds the runs of 2^gb consecutive ranks (gb = -tb), its rows are sorted by
 // (rank's low gb bits, sval) as ONE word, sub << bits(range) | (sval - min): the same sorts on a composite.  Payloads that
 // leave no room for the gb bits (a range beyond 2^(64 - gb)) raise ERR_FASTPATH.
-template <bool EXTRA, bool GROUP>
-__global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
+template <bool EXTRA, bool GROUP, int T>
+__global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
                                                                      u32 P, const u64* __restrict__ out_off,
                                                                      const Tup* __restrict__ sortedR, u32 nb, int tb, u64* __restrict__ out_key,
                                                                      u64* __restrict__ out_rval, u64* __restrict__ out_sval,
                                                                      u64* __restrict__ accum) {
-  __shared__ __attribute__((aligned(16))) u64 keys[RS_CAP];  // 16 KiB: the run's keys (64-bit, or 32-bit in its first half)
-  __shared__ unsigned short sidx[RS_CAP];                    // bucket sort: slot of the i-th smallest key
-  __shared__ u32 bcnt[RS_CAP + 1];
-  __shared__ u32 wsc[2 * (RS_THREADS / kWave)];
-  __shared__ u64 red[8];
-  __shared__ u64 wmn[RS_THREADS / kWave], wmx[RS_THREADS / kWave];
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem_raw[];
+  RsSmem<T, false>& sm = *reinterpret_cast<RsSmem<T, false>*>(rs_smem_raw);
+  u64* const keys = sm.keys;
+  unsigned short* const sidx = sm.sidx;
+  u32* const bcnt = sm.bcnt;
+  u32* const wsc = sm.wsc;
+  u64* const red = sm.red;
+  u64* const wmn = sm.wmn;
+  u64* const wmx = sm.wmx;
+  constexpr u32 RS_CAP = T * RS_EPT, RS_THREADS = T;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid < 8) red[tid] = 0;
   u64 acc_r = 0, acc_x = 0, acc_m = 0;
@@ -916,7 +933,7 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
       // one payload value in the whole run: nothing to sort
     } else if (range < 0xFFFFFFFFull) {  // 32-bit keys sval - min
       u32* k32 = reinterpret_cast<u32*>(keys);
-      if (rs_bucket_sort<u32>(sv, mn, range, n, k32, sidx, bcnt, wsc, tid)) {
+      if (rs_bucket_sort<u32, T>(sv, mn, range, n, k32, sidx, bcnt, wsc, tid)) {
 #pragma unroll
         for (int r = 0; r < RS_EPT; r++) {
           const u32 i = (u32)tid + (u32)r * RS_THREADS;
@@ -936,7 +953,7 @@ __global__ __launch_bounds__(RS_THREADS, 5) void rank_sort_write_kernel(const Tu
           if (i < n) sv[r] = (u64)k32[rs_sw(i)] + mn;
         }
       }
-    } else if (range != ~0ull && rs_bucket_sort<u64>(sv, mn, range, n, keys, sidx, bcnt, wsc, tid)) {
+    } else if (range != ~0ull && rs_bucket_sort<u64, T>(sv, mn, range, n, keys, sidx, bcnt, wsc, tid)) {
 #pragma unroll
       for (int r = 0; r < RS_EPT; r++) {
         const u32 i = (u32)tid + (u32)r * RS_THREADS;
@@ -1076,14 +1093,20 @@ hipError_t launch_slab_offsets(const u32* cnt, u32 P, u64* off, u64* scratch, hi
 // order, as the passes are stable), 32-bit keys where the run spans < 2^32 -- and writes the rows at the partition's offset:
 // 3 x 32 B per row whatever the key width.  A run beyond the kernel or a bucket of > 24 equal / clustered keys raises
 // ERR_FASTPATH: the output is garbage, the host runs the chain from the untouched input (out-of-place calls only).
-__global__ __launch_bounds__(RS_THREADS, 4) void sort_runs_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap, u32 P,
+template <int T>
+__global__ __launch_bounds__(T, 4) void sort_runs_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap, u32 P,
                                                                         const u64* __restrict__ out_off, Tup* __restrict__ out,
                                                                         u64* __restrict__ accum) {
-  __shared__ __attribute__((aligned(16))) u64 keys[RS_CAP];  // the run's keys by bucket slot, later its payloads by the same slots
-  __shared__ unsigned short sidx[RS_CAP], oidx[RS_CAP];
-  __shared__ u32 bcnt[RS_CAP + 1];
-  __shared__ u32 wsc[2 * (RS_THREADS / kWave)];
-  __shared__ u64 wmn[RS_THREADS / kWave], wmx[RS_THREADS / kWave];
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem_raw[];
+  RsSmem<T, true>& sm = *reinterpret_cast<RsSmem<T, true>*>(rs_smem_raw);
+  u64* const keys = sm.keys;  // the run's keys by bucket slot, later its payloads by the same slots
+  unsigned short* const sidx = sm.sidx;
+  unsigned short* const oidx = sm.oidx;
+  u32* const bcnt = sm.bcnt;
+  u32* const wsc = sm.wsc;
+  u64* const wmn = sm.wmn;
+  u64* const wmx = sm.wmx;
+  constexpr u32 RS_CAP = T * RS_EPT, RS_THREADS = T;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   bool bad = false;
   for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
@@ -1147,7 +1170,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void sort_runs_write_kernel(const Tu
       continue;
     } else if (range < 0xFFFFFFFFull) {
       u32* k32 = reinterpret_cast<u32*>(keys);
-      sorted_ok = rs_bucket_sort<u32, true>(kv, mn, range, n, k32, sidx, bcnt, wsc, tid, oidx, slot);
+      sorted_ok = rs_bucket_sort<u32, T, true>(kv, mn, range, n, k32, sidx, bcnt, wsc, tid, oidx, slot);
       if (sorted_ok) {
 #pragma unroll
         for (int r = 0; r < RS_EPT; r++) {
@@ -1156,7 +1179,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void sort_runs_write_kernel(const Tu
         }
       }
     } else {
-      sorted_ok = rs_bucket_sort<u64, true>(kv, mn, range, n, keys, sidx, bcnt, wsc, tid, oidx, slot);
+      sorted_ok = rs_bucket_sort<u64, T, true>(kv, mn, range, n, keys, sidx, bcnt, wsc, tid, oidx, slot);
       if (sorted_ok) {
 #pragma unroll
         for (int r = 0; r < RS_EPT; r++) {
@@ -1191,35 +1214,62 @@ __global__ __launch_bounds__(RS_THREADS, 4) void sort_runs_write_kernel(const Tu
   if (bad && tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
 }
 
-hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, void* out, u64* accum, int num_cus,
-                                  hipStream_t st) {
-  if (!slabs || !cnt || !out_off || !out || !accum || P == 0 || cap == 0) return hipErrorInvalidValue;
-  u32 grid = (u32)num_cus * 4u;  // what is resident at once (launch bounds; 32 KiB of LDS per workgroup)
+// level: 0 / 1 / 2 = workgroups of 256 / 512 / 1024 threads, partitions of up to 2048 / 4096 / 8192 rows (rank_sort_max_run)
+template <typename Kern>
+static hipError_t rs_launch_prep(Kern kern, size_t smem, SmemAttrOnce& once) {
+  return smem > 64 * 1024 ? ensure_max_smem(once, reinterpret_cast<const void*>(kern), smem) : hipSuccess;
+}
+hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, void* out, u64* accum, int level,
+                                  int num_cus, hipStream_t st) {
+  if (!slabs || !cnt || !out_off || !out || !accum || P == 0 || cap == 0 || level < 0 || level > 2) return hipErrorInvalidValue;
+  u32 grid = (u32)num_cus * (level == 0 ? 4u : level == 1 ? 2u : 1u);  // what is resident at once (launch bounds; 32 / 64 / 129 KiB of LDS per workgroup)
   if (grid > P) grid = P;
-  hipLaunchKernelGGL(sort_runs_write_kernel, dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off,
-                     static_cast<Tup*>(out), accum);
+#define HMJ_SRW(T)                                                                                                                    \
+  {                                                                                                                                   \
+    static SmemAttrOnce once;                                                                                                         \
+    const size_t smem = sizeof(RsSmem<T, true>);                                                                                      \
+    if (hipError_t e = rs_launch_prep(sort_runs_write_kernel<T>, smem, once); e != hipSuccess) return e;                              \
+    hipLaunchKernelGGL((sort_runs_write_kernel<T>), dim3(grid), dim3(T), smem, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off, \
+                       static_cast<Tup*>(out), accum);                                                                                \
+  }
+  if (level == 0) HMJ_SRW(256) else if (level == 1) HMJ_SRW(512) else HMJ_SRW(1024)
+#undef HMJ_SRW
   return hipGetLastError();
 }
 
-int rank_sort_max_run() { return RS_CAP; }
+int rank_sort_max_run(int level) { return (256 << (level < 0 ? 0 : level > 2 ? 2 : level)) * RS_EPT; }
 hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb, int tb,
-                                  u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st) {
+                                  u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int level, int num_cus, hipStream_t st) {
   // tb > 0: a rank's run is 2^tb partitions; tb < 0: a partition is the runs of 2^-tb consecutive ranks
-  if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0 || tb < -4 || tb > 16)
+  if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0 || tb < -4 || tb > 16 ||
+      level < 0 || level > 2)
     return hipErrorInvalidValue;
-  u32 grid = (u32)num_cus * 5u;  // what is resident at once: 96 registers (launch bounds) and 28 KiB of LDS per 256-thread workgroup
+  // what is resident at once: 96 registers (launch bounds) and 28 KiB of LDS per 256-thread workgroup -- five per CU; two of 512 threads; one of 1024
+  u32 grid = (u32)num_cus * (level == 0 ? 5u : level == 1 ? 2u : 1u);
   if (grid > P) grid = P;
-#define HMJ_RSW(E, G)                                                                                                                            \
-  hipLaunchKernelGGL((rank_sort_write_kernel<E, G>), dim3(grid), dim3(RS_THREADS), 0, st, static_cast<const Tup*>(slabs), cnt, cap, P, out_off, \
-                     static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum)
-  if (tb < 0) {
-    if (extra) HMJ_RSW(true, true); else HMJ_RSW(false, true);
-  } else {
-    if (extra) HMJ_RSW(true, false); else HMJ_RSW(false, false);
+#define HMJ_RSW(E, G, T)                                                                                                          \
+  {                                                                                                                               \
+    static SmemAttrOnce once;                                                                                                     \
+    const size_t smem = sizeof(RsSmem<T, false>);                                                                                 \
+    if (hipError_t e = rs_launch_prep(rank_sort_write_kernel<E, G, T>, smem, once); e != hipSuccess) return e;                    \
+    hipLaunchKernelGGL((rank_sort_write_kernel<E, G, T>), dim3(grid), dim3(T), smem, st, static_cast<const Tup*>(slabs), cnt, cap, P, \
+                       out_off, static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum);                     \
   }
+#define HMJ_RSW_T(E, G)                                                        \
+  {                                                                            \
+    if (level == 0) HMJ_RSW(E, G, 256) else if (level == 1) HMJ_RSW(E, G, 512) \
+    else HMJ_RSW(E, G, 1024)                                                   \
+  }
+  if (tb < 0) {
+    if (extra) HMJ_RSW_T(true, true) else HMJ_RSW_T(false, true)
+  } else {
+    if (extra) HMJ_RSW_T(true, false) else HMJ_RSW_T(false, false)
+  }
+#undef HMJ_RSW_T
 #undef HMJ_RSW
   return hipGetLastError();
 }
+
 
 hipError_t launch_pieces_compact(const void* slabs, const u32* cnt, const u64* off, u32 n_pieces, u32 cap, void* out, int num_cus,
                                  hipStream_t st) {

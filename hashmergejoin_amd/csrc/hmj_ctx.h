@@ -162,6 +162,7 @@ struct hmj_ctx {
   bool rank_runs_mode = true;      // ordered, small build side, fan-out from 16: partition by rank, sort every rank's run in LDS (HMJ_RANK_RUNS=0: composites)
   int rank_runs_max_cut = 10;       // ... runs beyond ~1700 rows cut into up to 2^this pieces by payload position (HMJ_RANK_RUNS_MAX_CUT; 0: such joins sort composites)
   int rank_runs_max_group = 3;     // ... more than 2^18 build rows: up to 2^this consecutive ranks share a partition (HMJ_RANK_RUNS_MAX_GROUP; 0: such joins take other paths)
+  int rank_runs_max_level = 2;     // the LDS sorts (rank runs, hmj_sort_u64_device's MSD form): workgroups of up to 256 << this threads, 2048 << this rows per partition (HMJ_RANK_RUNS_MAX_LEVEL)
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)
@@ -170,6 +171,7 @@ struct hmj_ctx {
   bool expand_allow_rebits = true;  // (false during the retry that already took one more bit)
   int expand_rebits = 0;            // the bits that retry plans         // ordered joins to keep on write + sort after a partition did not fit the expansion kernel
   bool sort_msd = true;            // hmj_sort_u64_device, out of place: two MSD slab passes + an LDS sort per partition (HMJ_SORT_MSD=0: the LSD chain)
+  int sort_msd_max_bits = 18;      // ... its window: at most this many key bits make the partitions (HMJ_SORT_MSD_MAX_BITS)
   u64 sort_msd_min = 1ull << 22;   // ... from this many rows on (HMJ_SORT_MSD_MIN_LOG2)
   bool sort_slab = true;           // hmj_sort_u64_device: LSD passes as a chain of slab passes + one compaction (HMJ_SORT_SLAB=0: exact passes)
   u64 sort_slab_min = 1ull << 25;  // ... from this many rows on (HMJ_SORT_SLAB_MIN_LOG2)

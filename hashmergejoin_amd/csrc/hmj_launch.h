@@ -161,13 +161,14 @@ hipError_t launch_gtable_swap(const void* in, void* out, u64 n, int num_cus, hip
 // the rank-run form: {rank, sval} rows, partitioned by rank with two slab passes, every rank's run sorted in LDS and written
 hipError_t launch_gtable_emit_ranks(const void* S, u32 np, const void* tab, int log_cap, u64* accum, void* pairs, bool extra, int num_cus,
                                     int wg_per_cu, hipStream_t st);
-int rank_sort_max_run();
+// rows one workgroup of the LDS sorts holds: level 0 / 1 / 2 = 256 / 512 / 1024 threads = 2048 / 4096 / 8192 rows
+int rank_sort_max_run(int level = 0);
 // hmj_sort_u64_device's MSD form: the rows partitioned on their top varying key bits by two slab passes (partition p = four
 // pieces of `cap` rows, counts cnt[p * 4 ..]), every partition sorted on the remaining bits in LDS (stable) and written at out_off[p]
-hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, void* out, u64* accum, int num_cus,
-                                  hipStream_t st);
+hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, void* out, u64* accum, int level,
+                                  int num_cus, hipStream_t st);
 hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb, int tb,
-                                  u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int num_cus, hipStream_t st);
+                                  u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int level, int num_cus, hipStream_t st);
 hipError_t launch_slab_a_ranks(const void* in, u32 n, int shift, int bits, const SlabGeom& g, void* slab_a, u64 slab_a_rows, u32* cnt_a,
                                u64 cnt_a_n, u64* accum, const void* tab, int log_cap, bool extra, int tb, u64 svmin, u64 svrange, int pre,
                                u64 mult, hipStream_t st);

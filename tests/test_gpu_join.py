@@ -579,35 +579,42 @@ def test_full_size_closed_form(ex, H, G, log2n, bits):
         ex.set_radix_bits(None)
 
 
-def _rank_runs_cut(nb, npb, chunk_rows=64, max_run=2048, max_cut=10):
-    """The host's rank_runs_fit (api.hip): None where the rank-run form does not apply, else log2 of the pieces a key's run is cut into
-    (negative: log2 of the ranks that share a partition)."""
+def _rank_runs_cut(nb, npb, chunk_rows=64, max_cut=10, max_level=2):
+    """The host's rank_runs_fit (api.hip): None where the rank-run form does not apply, else (log2 of the pieces a key's run is cut
+    into -- negative: log2 of the ranks that share a partition --, level of the LDS sort: 256 << level threads, 2048 << level rows)."""
     if nb < 4 or npb < 1 << 16 or npb >= 1 << 32:
         return None
     rank_bits = (nb - 1).bit_length()
-    f = npb / nb
-    if rank_bits < 2 or f < 16:
+    f0 = npb / nb
+    if rank_bits < 2 or f0 < 16:
         return None
+    fits = lambda m, lv: m + 8 * m ** 0.5 + 24 <= 2048 << lv
     if rank_bits > 18:  # 2^gb consecutive ranks share a partition: -gb
         gb = rank_bits - 18
-        m = f * (1 << gb)
-        return -gb if gb <= 3 and m + 8 * m ** 0.5 + 24 <= max_run else None
-    t = 0
-    while f + 8 * f ** 0.5 + 24 > max_run:
-        f, t = f / 2, t + 1
-    if t > max_cut or rank_bits + t > 18:
-        return None
-    if t:
-        tb = rank_bits + t
-        ba = tb - tb // 2
-        tile = 4096 if ba > 8 else 2048
-        tpw = -(-(-(-npb // tile)) // 2048)
-        rpw = tpw * tile
-        places, pieces, mean = rpw / chunk_rows, 1 << t, rpw / (1 << ba)
-        skew = -(-places // pieces) / (places / pieces) if places >= pieces else pieces / places
-        if skew * mean + 4 * (skew * mean) ** 0.5 > mean + 8 * mean ** 0.5 + 24:
+        if gb > 3:
             return None
-    return t
+        for lv in range(max_level + 1):
+            if fits(f0 * (1 << gb), lv):
+                return -gb, lv
+        return None
+    for lv in range(max_level + 1):
+        f, t = f0, 0
+        while not fits(f, lv):
+            f, t = f / 2, t + 1
+        if rank_bits + t > 18 or t > max_cut:
+            continue
+        if t:
+            tb = rank_bits + t
+            ba = tb - tb // 2
+            tile = 4096 if ba > 8 else 2048
+            tpw = -(-(-(-npb // tile)) // 2048)
+            rpw = tpw * tile
+            places, pieces, mean = rpw / chunk_rows, 1 << t, rpw / (1 << ba)
+            skew = -(-places // pieces) / (places / pieces) if places >= pieces else pieces / places
+            if skew * mean + 4 * (skew * mean) ** 0.5 > mean + 8 * mean ** 0.5 + 24:
+                return None
+        return t, lv
+    return None
 
 
 @pytest.mark.parametrize("log2b,log2p,wide", [(16, 26, False), (16, 26, True), (18, 27, False), (12, 26, False), (10, 26, True), (14, 24, True),
@@ -637,7 +644,7 @@ def test_full_size_ordered_small_build_side(ex_fresh, H, log2b, log2p, wide):
     t = ex.last_timing()
     assert int(r.n_matches) == npb
     assert t["path"] & H.HMJ_PATH_ORDER_BY_RANK_SORT, hex(t["path"])
-    assert _rank_runs_cut(nb, npb) == {16: 0, 18: 0, 14: 0, 12: 4, 10: 6, 19: -1}[log2b]
+    assert _rank_runs_cut(nb, npb) == {16: (0, 0), 18: (0, 0), 14: (0, 0), 12: (4, 0), 10: (6, 0), 19: (-1, 0)}[log2b]
     assert t["path"] & H.HMJ_PATH_RANK_RUNS and t["path"] & H._lib.HMJ_PATH_RANK_LOOKUP_IN_PASS, hex(t["path"])
     cols = []
     for ptr in (r.key, r.rval, r.sval):
@@ -997,6 +1004,23 @@ def test_sort_msd_two_slab_passes_and_an_lds_sort_per_partition(H):
         if msd is False and name == "few_values":  # the size remembers: no second attempt for its next sorts
             got = to_np(ex.sort_device(to_dev(a)))
             assert not ex.last_timing()["path"] & MSD and np.array_equal(got, want)
+    # partitions beyond the 256-thread sort's 2048 rows (what 2^18 partitions hold of more than 4.5 * 10^8 rows): workgroups of
+    # 512 / 1024 threads sort up to 4096 / 8192 rows.  Here the window is capped instead (HMJ_SORT_MSD_MAX_BITS): 2^11 / 2^10
+    # partitions of ~2050 / ~4100 rows; with 2^9 the partitions outgrow the largest shape and the chain answers.
+    # ("duplicates" are 63-bit keys: they fill half of the window, so its 2^11 partitions hold ~4100 rows -- the 1024-thread shape)
+    for max_bits, names, msd in ((11, ("uniform", "duplicates"), True), (10, ("uniform",), True), (9, ("uniform",), False)):
+        os.environ["HMJ_SORT_MSD_MAX_BITS"] = str(max_bits)
+        try:
+            ex2 = H.Executor(0)
+        finally:
+            del os.environ["HMJ_SORT_MSD_MAX_BITS"]
+        for name in names:
+            keys = shapes[name][0]
+            a = np.stack([keys, np.arange(n, dtype=np.uint64)], 1)
+            got = to_np(ex2.sort_device(to_dev(a)))
+            assert bool(ex2.last_timing()["path"] & MSD) == msd, (max_bits, name, hex(ex2.last_timing()["path"]))
+            assert np.array_equal(got, a[np.argsort(keys, kind="stable")]), (max_bits, name)
+        ex2.close()
     # in place (radix_int_inplace's replacement) keeps the chain: the MSD form reads its input while it writes the output
     a = np.stack([shapes["uniform"][0], np.arange(n, dtype=np.uint64)], 1)
     d = to_dev(a)
@@ -1488,6 +1512,7 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             # (payloads spanning all 64 bits go as two words: sorted by payload, then stably by rank)
             assert took == (pay in ("ids", "rowid", "offset", "wide", "hot", "ties7", "const", "extremes")), (nb, npb, pay, fl, hex(t["path"]))
             cut = _rank_runs_cut(nb, npb)
+            cut = cut and cut[0]
             # (cut runs exist only with the lookup inside pass A, and their pieces are even only where the payloads are spread)
             runs = pay in ("ids", "rowid", "offset", "wide", "ties7", "const") and cut is not None and (
                 cut == 0 or (cut > 0 and miss == 0 and pay != "ties7") or (cut < 0 and pay != "wide"))
@@ -1522,6 +1547,40 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
         assert bool(ex.last_timing()["path"] & RS) == want, (nb, npb, hex(ex.last_timing()["path"]))
         assert r.checks() == ck and np.array_equal(ex.columns_to_numpy(r, host=False), rows), (nb, npb)
         ex.release_result()
+
+
+def test_rank_runs_in_the_larger_workgroup_shapes(H, oracle):
+    # The LDS sort of a partition exists for workgroups of 256 / 512 / 1024 threads (2048 / 4096 / 8192 rows).  The larger ones
+    # serve where two slab passes cannot make the partitions smaller (more than 2^29 probe rows); here the cut is switched off
+    # (HMJ_RANK_RUNS_MAX_CUT=0) so that runs of ~3500 / ~5200 rows reach them whole.  Exact row sequences against the oracle.
+    os.environ["HMJ_GTABLE_SORT_FANOUT"] = "1"
+    os.environ["HMJ_RANK_RUNS_MAX_CUT"] = "0"
+    try:
+        ex = H.Executor(0)
+    finally:
+        del os.environ["HMJ_GTABLE_SORT_FANOUT"], os.environ["HMJ_RANK_RUNS_MAX_CUT"]
+    rng = np.random.default_rng(5)
+    for nb, npb, pay, level in [(300, 1 << 20, "rowid", 1), (200, (1 << 20) + 321, "ids", 2), (310, 1 << 20, "wide", 1), (150, 1 << 20, "ids", 2),
+                                (100, 1 << 20, "ids", None)]:
+        assert _rank_runs_cut(nb, npb, max_cut=0) == (None if level is None else (0, level))
+        B, P = oracle.gen_build(nb), oracle.gen_uniform_domain(npb, nb)
+        if pay == "ids":
+            P[:, 1] = rng.permutation(npb).astype(np.uint64)
+        elif pay == "rowid":
+            P[:, 1] = np.uint64(77) + np.arange(npb, dtype=np.uint64) * np.uint64(5)
+        else:
+            P[:, 1] = rng.integers(0, 1 << 63, size=npb, dtype=np.uint64) * np.uint64(2)
+        ck, rows = oracle.equijoin(B, P)
+        for fl in (H.HMJ_ORDERED, H.HMJ_ORDERED | H.HMJ_CHECKSUM):
+            r = ex.join_device(to_dev(B), to_dev(P), fl)
+            t = ex.last_timing()
+            assert bool(t["path"] & H.HMJ_PATH_RANK_RUNS) == (level is not None), (nb, npb, hex(t["path"]))
+            assert t["path"] & H.HMJ_PATH_ORDER_BY_RANK_SORT
+            if fl & H.HMJ_CHECKSUM:
+                assert r.checks() == ck
+            assert np.array_equal(ex.columns_to_numpy(r, host=False), rows), (nb, npb, pay, fl)
+        ex.release_result()
+    ex.close()
 
 
 def test_rank_payload_composites_sorted_by_a_chain_of_slab_passes(H, oracle):
