@@ -2136,7 +2136,7 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
                             hmj_result* out, bool to_host, bool* done) {
   *done = false;
   if (!c->gtable_mode || !c->gtable_sort_mode || !(flags & HMJ_ORDERED) || c->prepare_only || c->force_bits >= 0 ||
-      !c->arrive_ev.empty() || n_build == 0 || n_build > 8 * c->gtable_max_rows || n_probe > 0xFFFFFFFFull ||
+      !c->arrive_ev.empty() || n_build == 0 || n_build > 16 * c->gtable_max_rows || n_probe > 0xFFFFFFFFull ||
       n_probe < (uint64_t)c->gtable_sort_fanout * n_build ||
       (c->prep.valid && c->prep.ptr == R && c->prep.n == (u32)n_build))
     return HMJ_OK;
@@ -2166,6 +2166,10 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     //  payloads for their range)
     int run_tb = 0, run_level = 0;
     const bool runs = rank_runs_fit(c, n_build, n_probe, &run_tb, &run_level) && rank_runs_rested(c, run_tb);
+    // (2^20 ... 2^21 build rows: the rank-run form only -- there for the joins whose fullest 18-bit partition outgrows the
+    //  one-pass ordered write: 2^21 x 2^29 rows took 166 ms on the exact path with the order epilogue, profiles/r05y_*)
+    const double P18 = (double)(1u << (2 * hmj::SLAB_MAX_BITS));
+    if (n_build > 8 * c->gtable_max_rows && (!runs || fk_probe_rows_hi((double)n_probe / P18, f, P18) <= 6144.0)) return HMJ_OK;
     const double rank_ns = (chain ? m.comp_ns_chain : m.comp_ns_exact) + (n_build > c->gtable_max_rows ? m.comp_ns_beyond_l2 : 0.0);
     const double n_parts = run_tb >= 0 ? (double)(n_build << run_tb) : (double)(n_build >> -run_tb);
     const double lb = std::log2((double)n_build) - 14.0;
