@@ -483,6 +483,8 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a.gpus, a.timeout_s, steps=a.steps, warmup=a.warmup))  # before anything touches the GPU
     watchdog = arm_process_watchdog(a.timeout_s, int(os.environ.get("RANK", "0")), a.gpus, a.steps, a.warmup)
+    # (multi-process GPU work on this image needs dmabuf IPC: RCCL fails with hipIpcGetMemHandle otherwise; set before HIP starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
