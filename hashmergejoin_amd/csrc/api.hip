@@ -2094,14 +2094,19 @@ static bool rank_runs_fit(const hmj_ctx* c, uint64_t n_build, uint64_t n_probe, 
     const int gb = rank_bits - max_bits;
     if (gb > c->rank_runs_max_group) return false;
     const double m = f0 * (double)(1u << gb);
-    int lv = 0;
+    int lv = c->rank_runs_wave ? -1 : 0;
     while (lv <= c->rank_runs_max_level && !fits(m, lv)) lv++;
     if (lv > c->rank_runs_max_level) return false;
     *tb = -gb;
     *level = lv;
     return true;
   }
-  // the smallest workgroup shape (the fastest: most workgroups per CU) whose cut stays within two slab passes
+  // the smallest workgroup shape (the fastest: most sorters per CU) whose cut stays within two slab passes; the wave
+  // shape (level -1: 512 rows) only for whole runs -- cutting a run further to reach it would only add partitions
+  if (c->rank_runs_wave && fits(f0, -1)) {
+    *level = -1;
+    return true;
+  }
   for (int lv = 0; lv <= c->rank_runs_max_level; lv++) {
     double f = f0;
     int t = 0;
@@ -2173,8 +2178,10 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     const double rank_ns = (chain ? m.comp_ns_chain : m.comp_ns_exact) + (n_build > c->gtable_max_rows ? m.comp_ns_beyond_l2 : 0.0);
     const double n_parts = run_tb >= 0 ? (double)(n_build << run_tb) : (double)(n_build >> -run_tb);
     const double lb = std::log2((double)n_build) - 14.0;
-    const double rank_ms = runs ? m.runs_fixed_ms + (m.runs_ns + (run_tb > 0 ? m.runs_range_ns : 0.0) + (lb > 0.0 ? lb * m.runs_ns_per_log2_build : 0.0)) * rows +
-                                      m.runs_ns_per_run * n_parts * 1e-6
+    const bool wave = run_level < 0;
+    const double rank_ms = runs ? m.runs_fixed_ms + (m.runs_ns + (wave ? m.runs_wave_ns : 0.0) + (run_tb > 0 ? m.runs_range_ns : 0.0) +
+                                                    (lb > 0.0 ? lb * m.runs_ns_per_log2_build : 0.0)) * rows +
+                                      (wave ? m.runs_wave_ns_per_run : m.runs_ns_per_run) * n_parts * 1e-6
                                 : m.comp_fixed_ms + rank_ns * rows;
     if (c->gtable_sort_fanout > 1 && rank_ms >= m.part_fixed_ms + part_ns * rows) {
       c->plan.refused |= HMJ_REFUSED_RANK_SORT_MODEL;
@@ -2678,6 +2685,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_RANK_RUNS")) c->rank_runs_mode = atoi(e) != 0;  // 0: ordered small-build joins always sort composites
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_CUT")) c->rank_runs_max_cut = atoi(e) < 0 ? 0 : atoi(e) > 16 ? 16 : atoi(e);
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_GROUP")) c->rank_runs_max_group = atoi(e) < 0 ? 0 : atoi(e) > 4 ? 4 : atoi(e);
+  if (const char* e = getenv("HMJ_RANK_RUNS_WAVE")) c->rank_runs_wave = atoi(e) != 0;  // 0: partitions of <= 512 rows are sorted by 256-thread workgroups too
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_LEVEL")) c->rank_runs_max_level = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);  // 0: the LDS sorts' 256-thread shape only (2048 rows per partition)
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
@@ -2763,7 +2771,8 @@ int hmj_create(hmj_ctx** out, int device_id) {
         {"comp_ns_exact", &c->ordered_model.comp_ns_exact}, {"comp_ns_wide", &c->ordered_model.comp_ns_wide},
         {"comp_ns_beyond_l2", &c->ordered_model.comp_ns_beyond_l2}, {"runs_fixed_ms", &c->ordered_model.runs_fixed_ms},
         {"runs_ns", &c->ordered_model.runs_ns}, {"runs_ns_per_run", &c->ordered_model.runs_ns_per_run},
-        {"runs_range_ns", &c->ordered_model.runs_range_ns}, {"runs_ns_per_log2_build", &c->ordered_model.runs_ns_per_log2_build}};
+        {"runs_range_ns", &c->ordered_model.runs_range_ns}, {"runs_ns_per_log2_build", &c->ordered_model.runs_ns_per_log2_build},
+        {"runs_wave_ns_per_run", &c->ordered_model.runs_wave_ns_per_run}, {"runs_wave_ns", &c->ordered_model.runs_wave_ns}};
     std::string spec(e);
     size_t pos = 0;
     while (pos < spec.size()) {

@@ -662,6 +662,19 @@ struct RsSmem {
   u64 wmn[T / kWave], wmx[T / kWave];
   u64 red[8];
 };
+// T == 64 is the WAVE shape: a 256-thread workgroup whose four waves each sort their own partitions of up to 512 rows, with
+// their own RsSmem<64> and no workgroup barrier -- a wave's LDS operations complete in order, so waiting for them is all the
+// synchronisation its lanes need.  For partitions of a few hundred rows (fan-outs 16 ... ~330) the 256-thread shape left
+// three quarters of its threads idle through a dozen barriers per partition (7.5 ns per partition; profiles/r05k_*).
+template <int T>
+__device__ __forceinline__ void rs_sync() {
+  if constexpr (T == 64) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    lds_barrier();
+  }
+}
 // LDS position of element i: the low three index bits XORed with bits 5..7, so that the eight consecutive elements a
 // thread takes in the stride-1 steps fall into different banks than its neighbours' (16-way conflicts otherwise)
 __device__ __forceinline__ u32 rs_sw(u32 i) { return i ^ ((i >> 5) & 7u); }
@@ -686,7 +699,7 @@ __device__ __forceinline__ void rs_three_levels(K (&v)[RS_EPT], bool asc) {
 // Sort s[rs_sw(0 .. N)) ascending; N a power of two in [8, 8 T]; threads tid < N / 8 work, all threads pass the barriers.
 // (not inlined: the network is the fallback of the bucket sort below, and its 16 + 16 key registers would otherwise count
 //  against the occupancy of the kernel's common path)
-template <typename K>
+template <typename K, int T>
 __device__ __attribute__((noinline)) void rs_bitonic(K* __restrict__ s, u32 N, int tid) {
   const bool active = (u32)tid < (N >> 3);
   K v[RS_EPT];
@@ -706,7 +719,7 @@ __device__ __attribute__((noinline)) void rs_bitonic(K* __restrict__ s, u32 N, i
 #pragma unroll
     for (int i = 0; i < 8; i++) s[rs_sw(base + i)] = v[i];
   }
-  lds_barrier();
+  rs_sync<T>();
   for (u32 k = 16; k <= N; k <<= 1) {
     // Levels k/2 ... 1 of this merge, three per round trip through LDS: a group works on the strides (4q, 2q, q).  q starts
     // at k/8 and drops by 8 while a full group is left; the last group is always (4, 2, 1).  Where that repeats a level
@@ -722,7 +735,7 @@ __device__ __attribute__((noinline)) void rs_bitonic(K* __restrict__ s, u32 N, i
 #pragma unroll
         for (int i = 0; i < 8; i++) s[rs_sw(base + (u32)i * q)] = v[i];
       }
-      lds_barrier();
+      rs_sync<T>();
       if (q == 1) break;
       q = q >= 8 ? (q >> 3) : 1u;
     }
@@ -751,7 +764,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
   const int bits = 64 - __builtin_clzll(range);  // (range > 0)
   const int sh = bits > lg ? bits - lg : 0;
   for (u32 i = (u32)tid; i <= NB; i += T) cnt[i] = 0;
-  lds_barrier();
+  rs_sync<T>();
   u32 bk[RS_EPT], ar[RS_EPT];
 #pragma unroll
   for (int r = 0; r < RS_EPT; r++) {
@@ -762,7 +775,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
       ar[r] = atomicAdd(&cnt[bk[r]], 1u);
     }
   }
-  lds_barrier();
+  rs_sync<T>();
   // exclusive scan of the NB counts in place (thread t: entries [t * E, (t + 1) * E)), and the longest bucket
   const u32 E = NB / T;  // 1 ... 8
   u32 loc[RS_EPT], sum = 0, big = 0;
@@ -785,7 +798,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
   }
   if (lane == kWave - 1) wsc[wv] = incl;
   if (lane == 0) wsc[T / kWave + wv] = big;
-  lds_barrier();
+  rs_sync<T>();
   u32 before = 0;
 #pragma unroll
   for (int w = 0; w < T / kWave; w++) {
@@ -793,7 +806,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
     big = wsc[T / kWave + w] > big ? wsc[T / kWave + w] : big;
   }
   if (big > RS_MAXBUCKET) {  // (uniform) ties or clustered payloads
-    lds_barrier();
+    rs_sync<T>();
     return false;
   }
   u32 run = before + incl - sum;
@@ -804,7 +817,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
       run += loc[e];
     }
   if (tid == T - 1) cnt[NB] = n;
-  lds_barrier();
+  rs_sync<T>();
   // keys to their buckets (arrival order), then every key ranks itself inside its bucket
 #pragma unroll
   for (int r = 0; r < RS_EPT; r++) {
@@ -816,7 +829,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
       if (slot_out) slot_out[r] = me;
     }
   }
-  lds_barrier();
+  rs_sync<T>();
 #pragma unroll
   for (int r = 0; r < RS_EPT; r++) {
     const u32 i = (u32)tid + (u32)r * T;
@@ -832,7 +845,7 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
       idx[s0 + rank] = (unsigned short)me;
     }
   }
-  lds_barrier();
+  rs_sync<T>();
   return true;
 }
 
@@ -840,26 +853,29 @@ __device__ __forceinline__ bool rs_bucket_sort(const u64 (&sv)[RS_EPT], u64 mn, 
 // (rank's low gb bits, sval) as ONE word, sub << bits(range) | (sval - min): the same sorts on a composite.  Payloads that
 // leave no room for the gb bits (a range beyond 2^(64 - gb)) raise ERR_FASTPATH.
 template <bool EXTRA, bool GROUP, int T>
-__global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
+__global__ __launch_bounds__(T == 64 ? 256 : T, T <= 256 ? 5 : 4) void rank_sort_write_kernel(const Tup* __restrict__ slabs, const u32* __restrict__ cnt, u32 cap,
                                                                      u32 P, const u64* __restrict__ out_off,
                                                                      const Tup* __restrict__ sortedR, u32 nb, int tb, u64* __restrict__ out_key,
                                                                      u64* __restrict__ out_rval, u64* __restrict__ out_sval,
                                                                      u64* __restrict__ accum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem_raw[];
-  RsSmem<T, false>& sm = *reinterpret_cast<RsSmem<T, false>*>(rs_smem_raw);
+  constexpr bool WAVE = T == 64;  // (rs_sync above: every wave of the workgroup is a sorter of its own)
+  RsSmem<T, false>* const sms = reinterpret_cast<RsSmem<T, false>*>(rs_smem_raw);
+  RsSmem<T, false>& sm = sms[WAVE ? threadIdx.x >> 6 : 0];
   u64* const keys = sm.keys;
   unsigned short* const sidx = sm.sidx;
   u32* const bcnt = sm.bcnt;
   u32* const wsc = sm.wsc;
-  u64* const red = sm.red;
+  u64* const red = sms[0].red;
   u64* const wmn = sm.wmn;
   u64* const wmx = sm.wmx;
   constexpr u32 RS_CAP = T * RS_EPT, RS_THREADS = T;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid < 8) red[tid] = 0;
+  const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
   u64 acc_r = 0, acc_x = 0, acc_m = 0;
   bool bad = false;
-  for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
+  const u32 p_first = WAVE ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x, p_step = WAVE ? gridDim.x * 4u : gridDim.x;
+  for (u32 p = p_first; p < P; p += p_step) {
     const u32* q = cnt + (u64)p * SLAB_KB;
     const u32 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
     const u32 n = c0 + c1 + c2 + c3;
@@ -903,7 +919,7 @@ __global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(co
       wmn[wv] = mn;
       wmx[wv] = mx;
     }
-    lds_barrier();
+    rs_sync<T>();
 #pragma unroll
     for (int w = 0; w < RS_THREADS / kWave; w++) {
       mn = wmn[w] < mn ? wmn[w] : mn;
@@ -916,7 +932,7 @@ __global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(co
       rb = range ? 64 - __builtin_clzll(range) : 0;
       if (rb + gb > 64) {  // (uniform)
         bad = true;
-        lds_barrier();
+        rs_sync<T>();
         continue;
       }
 #pragma unroll
@@ -945,8 +961,8 @@ __global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(co
           const u32 i = (u32)tid + (u32)r * RS_THREADS;
           if (i < N) k32[rs_sw(i)] = i < n ? (u32)(sv[r] - mn) : 0xFFFFFFFFu;
         }
-        lds_barrier();
-        rs_bitonic<u32>(k32, N, tid);
+        rs_sync<T>();
+        rs_bitonic<u32, T>(k32, N, tid);
 #pragma unroll
         for (int r = 0; r < RS_EPT; r++) {
           const u32 i = (u32)tid + (u32)r * RS_THREADS;
@@ -965,8 +981,8 @@ __global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(co
         const u32 i = (u32)tid + (u32)r * RS_THREADS;
         if (i < N) keys[rs_sw(i)] = i < n ? sv[r] - mn : ~0ull;
       }
-      lds_barrier();
-      rs_bitonic<u64>(keys, N, tid);
+      rs_sync<T>();
+      rs_bitonic<u64, T>(keys, N, tid);
 #pragma unroll
       for (int r = 0; r < RS_EPT; r++) {
         const u32 i = (u32)tid + (u32)r * RS_THREADS;
@@ -974,7 +990,7 @@ __global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(co
       }
     } else {  // payloads 0 and 2^64 - 1 in one run: no value is free for the padding
       bad = true;
-      lds_barrier();
+      rs_sync<T>();
       continue;
     }
     // ---- rows out: the rank's key and payload, the sorted probe payloads
@@ -1000,7 +1016,7 @@ __global__ __launch_bounds__(T, T == 256 ? 5 : 4) void rank_sort_write_kernel(co
       }
     }
     if (!GROUP && tid == 0) acc_r += b.val * (u64)n;
-    lds_barrier();  // (keys / wmn / wmx are rewritten by the next run)
+    rs_sync<T>();  // (keys / wmn / wmx are rewritten by the next run)
   }
   if (bad && tid == 0) atomicOr(reinterpret_cast<unsigned long long*>(&accum[ACC_ERR]), (unsigned long long)ERR_FASTPATH);
   __syncthreads();
@@ -1237,28 +1253,29 @@ hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u3
   return hipGetLastError();
 }
 
-int rank_sort_max_run(int level) { return (256 << (level < 0 ? 0 : level > 2 ? 2 : level)) * RS_EPT; }
+int rank_sort_max_run(int level) { return level < 0 ? 64 * RS_EPT : (256 << (level > 2 ? 2 : level)) * RS_EPT; }
 hipError_t launch_rank_sort_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, const void* sortedR, u32 nb, int tb,
                                   u64* out_key, u64* out_rval, u64* out_sval, u64* accum, bool extra, int level, int num_cus, hipStream_t st) {
   // tb > 0: a rank's run is 2^tb partitions; tb < 0: a partition is the runs of 2^-tb consecutive ranks
   if (!slabs || !cnt || !out_off || !sortedR || !out_key || !out_rval || !out_sval || !accum || P == 0 || cap == 0 || nb == 0 || tb < -4 || tb > 16 ||
-      level < 0 || level > 2)
+      level < -1 || level > 2)
     return hipErrorInvalidValue;
   // what is resident at once: 96 registers (launch bounds) and 28 KiB of LDS per 256-thread workgroup -- five per CU; two of 512 threads; one of 1024
-  u32 grid = (u32)num_cus * (level == 0 ? 5u : level == 1 ? 2u : 1u);
-  if (grid > P) grid = P;
+  u32 grid = (u32)num_cus * (level <= 0 ? 5u : level == 1 ? 2u : 1u);
+  const u32 per_wg = level < 0 ? 4u : 1u;  // (the wave shape: four partitions in flight per workgroup)
+  if (grid > (P + per_wg - 1) / per_wg) grid = (P + per_wg - 1) / per_wg;
 #define HMJ_RSW(E, G, T)                                                                                                          \
   {                                                                                                                               \
     static SmemAttrOnce once;                                                                                                     \
-    const size_t smem = sizeof(RsSmem<T, false>);                                                                                 \
+    const size_t smem = sizeof(RsSmem<T, false>) * (T == 64 ? 4 : 1);                                                             \
     if (hipError_t e = rs_launch_prep(rank_sort_write_kernel<E, G, T>, smem, once); e != hipSuccess) return e;                    \
-    hipLaunchKernelGGL((rank_sort_write_kernel<E, G, T>), dim3(grid), dim3(T), smem, st, static_cast<const Tup*>(slabs), cnt, cap, P, \
-                       out_off, static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum);                     \
+    hipLaunchKernelGGL((rank_sort_write_kernel<E, G, T>), dim3(grid), dim3(T == 64 ? 256 : T), smem, st, static_cast<const Tup*>(slabs), cnt, cap, \
+                       P, out_off, static_cast<const Tup*>(sortedR), nb, tb, out_key, out_rval, out_sval, accum);                  \
   }
-#define HMJ_RSW_T(E, G)                                                        \
-  {                                                                            \
-    if (level == 0) HMJ_RSW(E, G, 256) else if (level == 1) HMJ_RSW(E, G, 512) \
-    else HMJ_RSW(E, G, 1024)                                                   \
+#define HMJ_RSW_T(E, G)                                                                                              \
+  {                                                                                                                  \
+    if (level < 0) HMJ_RSW(E, G, 64) else if (level == 0) HMJ_RSW(E, G, 256) else if (level == 1) HMJ_RSW(E, G, 512) \
+    else HMJ_RSW(E, G, 1024)                                                                                         \
   }
   if (tb < 0) {
     if (extra) HMJ_RSW_T(true, true) else HMJ_RSW_T(false, true)

@@ -87,6 +87,7 @@ struct OrderedCostModel {
   // rank runs: two slab passes on the rank + an LDS sort per run
   double runs_fixed_ms = 0.25, runs_ns = 0.0215, runs_ns_per_run = 7.5;
   double runs_ns_per_log2_build = 0.0023;  // ... + this per probe row and doubling of the build side beyond 2^14 rows (the rank table and the build rows leave the L2: 2^14 / 2^18 / 2^20 x 2^28 rows 8.5 / 11.0 / 12.6 ms)
+  double runs_wave_ns_per_run = 1.2, runs_wave_ns = 0.007;  // partitions of <= 512 rows, one wave each: per partition, and on top of runs_ns per row (profiles/r05aa_*)
   double runs_range_ns = 0.0;    // cut runs: the range of the payloads comes from a sample of ~2^17 rows (a pass over all of them cost 0.003)
 };
 }  // namespace hmj_host
@@ -163,6 +164,7 @@ struct hmj_ctx {
   int rank_runs_max_cut = 10;       // ... runs beyond ~1700 rows cut into up to 2^this pieces by payload position (HMJ_RANK_RUNS_MAX_CUT; 0: such joins sort composites)
   int rank_runs_max_group = 3;     // ... more than 2^18 build rows: up to 2^this consecutive ranks share a partition (HMJ_RANK_RUNS_MAX_GROUP; 0: such joins take other paths)
   int rank_runs_max_level = 2;     // the LDS sorts (rank runs, hmj_sort_u64_device's MSD form): workgroups of up to 256 << this threads, 2048 << this rows per partition (HMJ_RANK_RUNS_MAX_LEVEL)
+  bool rank_runs_wave = true;      // ... partitions of <= 512 rows: one WAVE sorts a partition, four partitions per workgroup (HMJ_RANK_RUNS_WAVE=0: off)
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)

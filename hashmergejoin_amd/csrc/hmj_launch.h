@@ -161,7 +161,8 @@ hipError_t launch_gtable_swap(const void* in, void* out, u64 n, int num_cus, hip
 // the rank-run form: {rank, sval} rows, partitioned by rank with two slab passes, every rank's run sorted in LDS and written
 hipError_t launch_gtable_emit_ranks(const void* S, u32 np, const void* tab, int log_cap, u64* accum, void* pairs, bool extra, int num_cus,
                                     int wg_per_cu, hipStream_t st);
-// rows one workgroup of the LDS sorts holds: level 0 / 1 / 2 = 256 / 512 / 1024 threads = 2048 / 4096 / 8192 rows
+// rows one sorter of the LDS sorts holds: level 0 / 1 / 2 = workgroups of 256 / 512 / 1024 threads = 2048 / 4096 / 8192 rows;
+// level -1 (rank_sort_write only) = one wave = 512 rows, four partitions in flight per 256-thread workgroup
 int rank_sort_max_run(int level = 0);
 // hmj_sort_u64_device's MSD form: the rows partitioned on their top varying key bits by two slab passes (partition p = four
 // pieces of `cap` rows, counts cnt[p * 4 ..]), every partition sorted on the remaining bits in LDS (stable) and written at out_off[p]

@@ -581,22 +581,25 @@ def test_full_size_closed_form(ex, H, G, log2n, bits):
 
 def _rank_runs_cut(nb, npb, chunk_rows=64, max_cut=10, max_level=2):
     """The host's rank_runs_fit (api.hip): None where the rank-run form does not apply, else (log2 of the pieces a key's run is cut
-    into -- negative: log2 of the ranks that share a partition --, level of the LDS sort: 256 << level threads, 2048 << level rows)."""
+    into -- negative: log2 of the ranks that share a partition --, level of the LDS sort: 256 << level threads, 2048 << level rows;
+    -1: a wave, 512 rows)."""
     if nb < 4 or npb < 1 << 16 or npb >= 1 << 32:
         return None
     rank_bits = (nb - 1).bit_length()
     f0 = npb / nb
     if rank_bits < 2 or f0 < 16:
         return None
-    fits = lambda m, lv: m + 8 * m ** 0.5 + 24 <= 2048 << lv
+    fits = lambda m, lv: m + 8 * m ** 0.5 + 24 <= (512 if lv < 0 else 2048 << lv)  # (level -1: one wave sorts a partition)
     if rank_bits > 18:  # 2^gb consecutive ranks share a partition: -gb
         gb = rank_bits - 18
         if gb > 3:
             return None
-        for lv in range(max_level + 1):
+        for lv in range(-1, max_level + 1):
             if fits(f0 * (1 << gb), lv):
                 return -gb, lv
         return None
+    if fits(f0, -1):
+        return 0, -1
     for lv in range(max_level + 1):
         f, t = f0, 0
         while not fits(f, lv):
