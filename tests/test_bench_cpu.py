@@ -67,3 +67,17 @@ def test_rank0s_own_error_line_is_not_doubled():
             "sys.exit(5)")
     rc, out, err, dt = run(bench, 2, 60.0, code)
     assert rc == 5 and len([l for l in out.splitlines() if l.startswith("{")]) == 1, (rc, out)
+
+
+def test_live_traffic_measurement_gives_way_quietly_without_a_gpu(monkeypatch):
+    # roofline.traffic is measured by two rocprofv3 --pmc child runs of bench.py (N = 1).  Whatever goes wrong there -- no
+    # profiler, no GPU (this container), a pass past its time -- must come back as (None, reason), never as an exception:
+    # the line then carries the committed constant, labelled as such.
+    bench = load_bench()
+    t0 = time.time()
+    got, why = bench.measure_traffic_live(20, timeout_s=90.0)
+    assert got is None and isinstance(why, str) and why, (got, why)
+    assert time.time() - t0 < 120
+    monkeypatch.setenv("PATH", "/nonexistent")
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: False)
+    assert bench.measure_traffic_live(20, timeout_s=5.0) == (None, "rocprofv3 not found")
