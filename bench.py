@@ -463,15 +463,25 @@ def measure_traffic_live(log2n, timeout_s=150.0):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="hmj_pmc_")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extra", "--no-traffic", "--log2n", str(log2n)]
+               "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extra", "--no-traffic", "--log2n", str(log2n), "--timeout-s", "120"]
         env = dict(os.environ, TMPDIR="/tmp", HMJ_BENCH_SELF_LAUNCHED="1")
         try:
             left = t_end - time.time()
             if left < 10:
                 return None, "out of time before the %s pass" % counter
-            p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
+            # (its own process group: past the limit the profiler AND the program under it are stopped, by that handle)
+            p = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, perr = p.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    pass
+                p.communicate()
+                return None, "%s pass did not finish in time" % counter
             if p.returncode != 0:
-                return None, "%s pass exited %d: %s" % (counter, p.returncode, p.stderr.decode(errors="replace")[-200:])
+                return None, "%s pass exited %d: %s" % (counter, p.returncode, perr.decode(errors="replace")[-200:])
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None, "%s pass wrote no counter file" % counter
@@ -481,8 +491,6 @@ def measure_traffic_live(log2n, timeout_s=150.0):
                     name = "slab_a" if "radix_slab_a_kernel" in k else "slab_b" if "radix_slab_b_kernel" in k else None
                     if name and row.get("Counter_Name") == counter:
                         per_kernel.setdefault(name, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
-        except subprocess.TimeoutExpired:
-            return None, "%s pass did not finish in time" % counter
         except Exception as e:  # (a measurement beside the line: never the reason a run fails)
             return None, "%s pass: %r" % (counter, e)
         finally:
