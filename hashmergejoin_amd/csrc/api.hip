@@ -2690,6 +2690,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
   if (const char* e = getenv("HMJ_EXPAND_FK_FANOUT")) c->expand_fk_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // 0: never for unique build keys
   if (const char* e = getenv("HMJ_SORT_MSD")) c->sort_msd = atoi(e) != 0;  // 0: hmj_sort_u64_device never takes its MSD form (two slab passes + an LDS sort per partition)
+  if (const char* e = getenv("HMJ_SORT_MSD_MEAN")) c->sort_msd_mean = atof(e) >= 64.0 ? atof(e) : c->sort_msd_mean;  // the window narrows until partitions average at most this many rows
   if (const char* e = getenv("HMJ_SORT_MSD_MAX_BITS")) c->sort_msd_max_bits = atoi(e) < 2 ? 2 : atoi(e) > 18 ? 18 : atoi(e);  // fewer, larger partitions (up to 8192 rows each)
   if (const char* e = getenv("HMJ_SORT_MSD_MIN_LOG2")) {
     const int l = atoi(e);
@@ -3314,7 +3315,9 @@ int hmj_sort_u64_device(hmj_ctx* c, const void* in_aos_dev, uint64_t n, void* ou
         if (dens > 64.0) dens = 64.0;
       }
       mean = dens * (double)n / std::ldexp(1.0, TB);
-    } while (TB < c->sort_msd_max_bits && mean > 1200.0);
+      // (a 17th / 18th bit makes a pass a 9-bit pass -- 1.95 / 2.17 ms per 2^28 rows against 1.5 / 1.6 -- and is only worth
+      //  partitions beyond the 512-thread sort's comfort: 2^27 / 2^28 rows 3.43 / 7.06 -> 3.32 / 6.84 ms, profiles/r05ad_*)
+    } while (TB < c->sort_msd_max_bits && mean > (TB >= 16 ? 2.0 : 1.0) * c->sort_msd_mean);
     if (TB > hi) TB = 0;
     // (beyond 4.5 * 10^8 rows the 2^18 partitions outgrow the 256-thread sort: 512 / 1024 threads hold 4096 / 8192 rows)
     int level = 0;

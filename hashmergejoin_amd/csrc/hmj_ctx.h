@@ -173,6 +173,7 @@ struct hmj_ctx {
   bool expand_allow_rebits = true;  // (false during the retry that already took one more bit)
   int expand_rebits = 0;            // the bits that retry plans         // ordered joins to keep on write + sort after a partition did not fit the expansion kernel
   bool sort_msd = true;            // hmj_sort_u64_device, out of place: two MSD slab passes + an LDS sort per partition (HMJ_SORT_MSD=0: the LSD chain)
+  double sort_msd_mean = 1200.0;   // ... narrowed until its partitions average at most this many rows (HMJ_SORT_MSD_MEAN)
   int sort_msd_max_bits = 18;      // ... its window: at most this many key bits make the partitions (HMJ_SORT_MSD_MAX_BITS)
   u64 sort_msd_min = 1ull << 22;   // ... from this many rows on (HMJ_SORT_MSD_MIN_LOG2)
   bool sort_slab = true;           // hmj_sort_u64_device: LSD passes as a chain of slab passes + one compaction (HMJ_SORT_SLAB=0: exact passes)
