@@ -689,7 +689,9 @@ def main():
             except Exception:
                 traffic = None
         traffic_detail = None
-        if world == 1 and not distributed and not a.no_traffic and slab and os.environ.get("HMJ_BENCH_TRAFFIC", "1") != "0":
+        # (not under a profiler: a run that is itself being profiled -- tools/profile_gpu.sh, anybody's rocprofv3 -- starts none)
+        profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ)
+        if world == 1 and not distributed and not a.no_traffic and slab and not profiled and os.environ.get("HMJ_BENCH_TRAFFIC", "1") != "0":
             live, detail = measure_traffic_live(a.log2n)
             if live is not None:
                 traffic, traffic_detail = live, detail
