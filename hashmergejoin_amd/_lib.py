@@ -24,6 +24,7 @@ HMJ_PATH_LDS_TABLE = 0x800000
 HMJ_PATH_RANK_RUNS = 0x1000000
 HMJ_PATH_RANK_LOOKUP_IN_PASS = 0x2000000
 HMJ_PATH_SORT_MSD = 0x4000000
+HMJ_PATH_KEY_RANGES = 0x8000000
 HMJ_PATH_SLAB_ONE_PASS = 0x80000
 HMJ_PATH_HOST_PIPELINE = 0x4000
 HMJ_PATH_SORTED_FK_HALF = 0x8000

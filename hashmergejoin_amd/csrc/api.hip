@@ -1012,7 +1012,11 @@ static int plan_join(hmj_ctx* c, const void* R, uint64_t n_build, const void* S,
     // overflowed a piece, the join started over with probe-side slabs only: 3.9 ms against 2.7 ms, tools/exp_cliffs_fk.py)
     if (!materialize)
       while (Bp < 16 && fk_probe_rows_hi((double)np_dense / (double)(1ull << Bp) / 4.0, f / 4.0, 4.0 * (double)(1ull << Bp)) > 1280.0) Bp++;
-    fk_wide_plan = wide_ok && wide_ok_override && !take_half && Bp < B_narrow;
+    // (the wide shape where it saves a bit -- or where 18 bits, the most two slab passes make, still leave the fullest
+    //  partition beyond the narrow shape's 5120 rows: 2^25 x 2^30 rows were planned narrow at 18 bits, overflowed, and took
+    //  the exact path, 107 ms)
+    const bool narrow_holds = fk_probe_rows_hi((double)np_dense / (double)(1ull << B_narrow), f, (double)(1ull << B_narrow)) <= 5120.0;
+    fk_wide_plan = wide_ok && wide_ok_override && !take_half && (Bp < B_narrow || !narrow_holds);
     const bool slab_ok = allow_slab && c->slab_mode && c->wm->slab_cooldown == 0 && slab_sizes_ok(c, nb, np_plan);
     // (count joins whose build-side plan is ONE pass keep it when the probe side can stay in that pass's slabs -- the
     //  one-pass slab path below: 2^21 x 2^28 rows, 18-bit probe-side plan 7.0 ms, 9-bit build-side plan 2.9 ms)
@@ -2563,12 +2567,158 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
 
 static int join_device_planned(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags,
                                hmj_result* out, bool to_host);
+// ---- ordered foreign-key joins beyond what ONE 18-bit plan holds (round 5) ----------------------------------------------
+// Two 9-bit slab passes make 2^18 partitions; under 2^30 probe rows those average 4096 rows, the fullest outgrow the
+// one-pass ordered write's 6144-row shape, and with more than 2^21 build rows the rank-run form is out of reach too: the
+// exact path with split partitions and the order epilogue ran, 134-432 ms (profiles/r05y_grid_fk_2p29_2p30.txt).  Ordered
+// output is a concatenation over KEY RANGES: both relations are cut on their top h varying key bits (one exact radix pass:
+// dense ranges + offsets), range after range is joined by the planner as a join of its own -- half or a quarter of the
+// rows, so its plan fits again -- and its rows are appended to the result columns.  One more pass over both relations
+// (48 B per row) and one copy of the result (48 B per row) buy a plan that works.
+static bool key_ranges_wanted(const hmj_ctx* c, uint64_t nb, uint64_t np, uint32_t flags, bool to_host, int* h) {
+  if (!(flags & HMJ_ORDERED) || to_host || c->prepare_only || !c->arrive_ev.empty() || c->force_bits >= 0 || nb == 0 || np == 0 ||
+      np > 0xFFFFFFFFull || nb > 0xFFFFFFFFull)
+    return false;
+  if (c->key_ranges_force > 0) {  // (tests: any ordered device-resident join, 2^force ranges)
+    *h = c->key_ranges_force;
+    return true;
+  }
+  // (the reasoning below is about 18-bit plans: what the planner takes from ~2^29 probe rows on)
+  if (!c->key_ranges || np < c->big_join_rows || np < 8 * nb || (c->prep.valid && c->prep.n == (u32)nb)) return false;
+  const double P18 = (double)(1u << (2 * hmj::SLAB_MAX_BITS));
+  auto held = [&](double b, double p) {  // does one plan hold a join of b x p rows: the one-pass ordered write, or the rank-run form
+    if (fk_probe_rows_hi(p / P18, p / b, P18) <= 6144.0) return true;
+    int tb = 0, lv = 0;
+    return b <= 16.0 * (double)c->gtable_max_rows && rank_runs_fit(c, (uint64_t)b, (uint64_t)p, &tb, &lv);
+  };
+  if (held((double)nb, (double)np)) return false;
+  // (a range's share of the rows is not exactly 1 / 2^h: a twentieth of room)
+  for (int hh = 1; hh <= 3; hh++)
+    if (held(1.05 * (double)nb / (double)(1 << hh), 1.05 * (double)np / (double)(1 << hh))) {
+      *h = hh;
+      return true;
+    }
+  return false;
+}
+
+static int join_by_key_ranges(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe, uint32_t flags, hmj_result* out,
+                              int h, bool* done) {
+  *done = false;
+  int rc;
+  if (!out) return fail(c, HMJ_E_ARG, "out is NULL");
+  if ((rc = check_rel(c, R, n_build, "build_aos is NULL")) != HMJ_OK) return rc;
+  if ((rc = check_rel(c, S, n_probe, "probe_aos is NULL")) != HMJ_OK) return rc;
+  const u32 nb = (u32)n_build, np = (u32)n_probe;
+  if ((rc = ensure_dev(c, c->offs64, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  if ((rc = ensure_host(c, c->h_accum, 8 * sizeof(u64))) != HMJ_OK) return rc;
+  u64* hh = (u64*)c->h_accum.p;
+  // ---- 1. the bits in which keys differ, over both relations
+  {
+    const u64 init[3] = {0, ~0ull, 0};
+    HIP_TRY(hipMemcpyAsync(c->offs64.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hmj::launch_key_exact(R, nb, S, np, 0ull, (u64*)c->offs64.p, c->num_cus, c->stream, true));
+    HIP_TRY(hipMemcpyAsync(hh, c->offs64.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  const u64 diff = hh[0];
+  if (diff == 0) return HMJ_OK;  // one key value in all: nothing to cut on, the planner's own paths answer
+  const int hb = 63 - __builtin_clzll(diff);
+  if (h > hb + 1) h = hb + 1;
+  const int shift = hb + 1 - h;
+  const u32 D = 1u << h;
+  // ---- 2. both relations cut into their 2^h key ranges (stable, dense, + range starts)
+  if ((rc = ensure_dev(c, c->split_r, (size_t)nb * 16 + 16)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->split_s, (size_t)np * 16 + 16)) != HMJ_OK) return rc;
+  if ((rc = ensure_dev(c, c->split_off, 2 * ((size_t)D + 1) * 8)) != HMJ_OK) return rc;
+  std::vector<u64> off(2 * ((size_t)D + 1));
+  u64* od = (u64*)c->split_off.p;
+  if ((rc = radix_pass(c, R, c->split_r.p, nb, shift, h, 0, od, 0)) != HMJ_OK) return rc;
+  if ((rc = radix_pass(c, S, c->split_s.p, np, shift, h, 1, od + D + 1, 0)) != HMJ_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(off.data(), od, off.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // ---- 3. range after range: a join of its own, its rows appended
+  hmj_result tot;
+  std::memset(&tot, 0, sizeof(tot));
+  u64 rows_done = 0;
+  u32 path = 0;
+  auto grow = [&](u64 need_rows) -> int {  // the three result columns hold need_rows (what is there stays)
+    const size_t bytes = (size_t)need_rows * 8;
+    DevBuf* cols[3] = {&c->cat_key, &c->cat_rval, &c->cat_sval};
+    for (DevBuf* b : cols) {
+      if (bytes <= b->cap) continue;
+      DevBuf nw;
+      int r2 = ensure_dev(c, nw, bytes + (bytes >> 2));
+      if (r2 != HMJ_OK) return r2;
+      if (rows_done) HIP_TRY(hipMemcpyAsync(nw.p, b->p, (size_t)rows_done * 8, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      free_dev(*b);
+      *b = nw;
+    }
+    return HMJ_OK;
+  };
+  for (u32 d = 0; d < D; d++) {
+    const u64 r0 = off[d], nr = off[d + 1] - off[d], s0 = off[D + 1 + d], ns = off[D + 1 + d + 1] - off[D + 1 + d];
+    if (ns == 0) continue;                              // no probe rows: no result rows, no probe payloads
+    if (nr == 0 && !(flags & HMJ_SUM_PROBE)) continue;  // nothing can match
+    hmj_result sub;
+    std::memset(&sub, 0, sizeof(sub));
+    rc = join_device_planned(c, (const char*)c->split_r.p + r0 * 16, nr, (const char*)c->split_s.p + s0 * 16, ns, flags, &sub, false);
+    if (rc != HMJ_OK) return rc;
+    path |= c->timing.path;
+    if (sub.n_matches) {
+      if (rows_done == 0 && d + 1 < D) {  // (first range: room for the whole result at this range's rate, so that growing is rare)
+        const double est = (double)sub.n_matches * (double)np / (double)ns * 1.05 + 4096.0;
+        if ((rc = grow(est > (double)sub.n_matches ? (u64)est : sub.n_matches)) != HMJ_OK) return rc;
+      }
+      if ((rc = grow(rows_done + sub.n_matches)) != HMJ_OK) return rc;
+      const size_t bytes = (size_t)sub.n_matches * 8;
+      HIP_TRY(hipMemcpyAsync((u64*)c->cat_key.p + rows_done, sub.key, bytes, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync((u64*)c->cat_rval.p + rows_done, sub.rval, bytes, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync((u64*)c->cat_sval.p + rows_done, sub.sval, bytes, hipMemcpyDeviceToDevice, c->stream));
+      rows_done += sub.n_matches;
+    }
+    tot.n_matches += sub.n_matches;
+    tot.sum_r += sub.sum_r;
+    tot.sum_s += sub.sum_s;
+    tot.xor_fold ^= sub.xor_fold;
+    tot.mix_sum += sub.mix_sum;
+    tot.sum_probe_all += sub.sum_probe_all;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = tot;
+  out->key = rows_done ? (const uint64_t*)c->cat_key.p : nullptr;
+  out->rval = rows_done ? (const uint64_t*)c->cat_rval.p : nullptr;
+  out->sval = rows_done ? (const uint64_t*)c->cat_sval.p : nullptr;
+  c->timing.path = path | HMJ_PATH_KEY_RANGES;
+  *done = true;
+  return HMJ_OK;
+}
+
 int join_device(hmj_ctx* c, const void* R, uint64_t n_build, const void* S, uint64_t n_probe,
                 uint32_t flags, hmj_result* out, bool to_host) {
+  // An UNORDERED materialising foreign-key join whose fullest 18-bit partition outgrows the unique-key write's 5120 rows but
+  // not the ordered write's wide shape (6144) is run as an ordered one -- ordered rows are a valid answer, and the exact
+  // path with split partitions that would run otherwise is slower than the ordered write (2^25 ... 2^26.6 x 2^30 rows:
+  // 46-56 ms against 34; profiles/r05af_*).
+  if ((flags & HMJ_MATERIALIZE) && !(flags & HMJ_ORDERED) && !c->prepare_only && c->promote_to_ordered && n_build > 0 &&
+      n_probe <= 0xFFFFFFFFull && n_probe >= c->big_join_rows && (double)n_probe >= 2.5 * (double)n_build && c->force_bits < 0) {
+    const double P18 = (double)(1u << (2 * hmj::SLAB_MAX_BITS));
+    const double hi = fk_probe_rows_hi((double)n_probe / P18, (double)n_probe / (double)n_build, P18);
+    if (hi > 5120.0 && hi <= 6144.0) flags |= HMJ_ORDERED;
+  }
   // the workload this call belongs to (a prepared build side: the join it was announced for) and what is known about it
   memo_for(c, workload_signature(n_build, c->prepare_only ? c->probe_hint : n_probe, flags, 0));
   std::memset(&c->plan, 0, sizeof(c->plan));
-  const int rc = join_device_planned(c, R, n_build, S, n_probe, flags, out, to_host);
+  int rc = HMJ_OK, kr_h = 0;
+  bool kr_done = false;
+  if (key_ranges_wanted(c, n_build, n_probe, flags, to_host, &kr_h)) {
+    rc = join_by_key_ranges(c, R, n_build, S, n_probe, flags, out, kr_h, &kr_done);
+  } else if (c->cat_key.p) {  // (the appended columns of an earlier join by key ranges: results live until the next join)
+    free_dev(c->cat_key);
+    free_dev(c->cat_rval);
+    free_dev(c->cat_sval);
+  }
+  if (rc == HMJ_OK && !kr_done) rc = join_device_planned(c, R, n_build, S, n_probe, flags, out, to_host);
   hmj_plan_desc& p = c->plan;
   p.struct_size = sizeof(p);
   p.path = c->timing.path;
@@ -2685,6 +2835,9 @@ int hmj_create(hmj_ctx** out, int device_id) {
   if (const char* e = getenv("HMJ_RANK_RUNS")) c->rank_runs_mode = atoi(e) != 0;  // 0: ordered small-build joins always sort composites
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_CUT")) c->rank_runs_max_cut = atoi(e) < 0 ? 0 : atoi(e) > 16 ? 16 : atoi(e);
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_GROUP")) c->rank_runs_max_group = atoi(e) < 0 ? 0 : atoi(e) > 4 ? 4 : atoi(e);
+  if (const char* e = getenv("HMJ_PROMOTE_TO_ORDERED")) c->promote_to_ordered = atoi(e) != 0;  // 0: an unordered materialising join is never run as an ordered one
+  if (const char* e = getenv("HMJ_KEY_RANGES")) c->key_ranges = atoi(e) != 0;  // 0: ordered joins are never cut into key ranges joined one after the other
+  if (const char* e = getenv("HMJ_KEY_RANGES_FORCE")) c->key_ranges_force = atoi(e) < 0 ? 0 : atoi(e) > 4 ? 4 : atoi(e);  // tests: every ordered device-resident join in 2^n key ranges
   if (const char* e = getenv("HMJ_RANK_RUNS_WAVE")) c->rank_runs_wave = atoi(e) != 0;  // 0: partitions of <= 512 rows are sorted by 256-thread workgroups too
   if (const char* e = getenv("HMJ_RANK_RUNS_MAX_LEVEL")) c->rank_runs_max_level = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);  // 0: the LDS sorts' 256-thread shape only (2048 rows per partition)
   if (const char* e = getenv("HMJ_GTABLE_SORT")) c->gtable_sort_mode = atoi(e) != 0;  // 0: ordered joins never sort composites of (rank, payload)
@@ -2815,7 +2968,8 @@ void hmj_destroy(hmj_ctx* c) {
                     &c->hist, &c->totals, &c->r_off, &c->s_off, &c->part_count,
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
                     &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched, &c->vparts,
-                    &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs, &c->lookback, &c->gtab, &c->piece_off};
+                    &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs, &c->lookback, &c->gtab, &c->piece_off,
+                    &c->split_r, &c->split_s, &c->split_off, &c->cat_key, &c->cat_rval, &c->cat_sval};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);
@@ -3206,6 +3360,9 @@ void hmj_release_result(hmj_ctx* c) {
   free_dev(c->out_key);
   free_dev(c->out_rval);
   free_dev(c->out_sval);
+  free_dev(c->cat_key);
+  free_dev(c->cat_rval);
+  free_dev(c->cat_sval);
   free_dev(c->ord_key);
   free_dev(c->ord_rval);
   free_dev(c->ord_sval);

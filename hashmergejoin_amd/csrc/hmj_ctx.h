@@ -103,7 +103,8 @@ struct hmj_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
       out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
-      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback, gtab, piece_off;
+      slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback, gtab, piece_off,
+      split_r, split_s, split_off, cat_key, cat_rval, cat_sval;  // joins by key ranges: both relations cut, the appended result columns
   HostBuf h_accum, h_key, h_rval, h_sval;
   int host_threads = 0;  // staging threads for pageable input (0 = default)
   std::vector<hipStream_t> up_streams;
@@ -164,6 +165,10 @@ struct hmj_ctx {
   int rank_runs_max_cut = 10;       // ... runs beyond ~1700 rows cut into up to 2^this pieces by payload position (HMJ_RANK_RUNS_MAX_CUT; 0: such joins sort composites)
   int rank_runs_max_group = 3;     // ... more than 2^18 build rows: up to 2^this consecutive ranks share a partition (HMJ_RANK_RUNS_MAX_GROUP; 0: such joins take other paths)
   int rank_runs_max_level = 2;     // the LDS sorts (rank runs, hmj_sort_u64_device's MSD form): workgroups of up to 256 << this threads, 2048 << this rows per partition (HMJ_RANK_RUNS_MAX_LEVEL)
+  uint64_t big_join_rows = 1ull << 29;  // probe rows from which the planner is at its 18-bit limit: what the two rules below reason about
+  bool promote_to_ordered = true;  // unordered materialising foreign-key joins between the narrow and the wide write's capacity at 18 bits run ordered (HMJ_PROMOTE_TO_ORDERED=0: off)
+  bool key_ranges = true;          // ordered foreign-key joins no single plan holds are cut into key ranges joined one after the other (HMJ_KEY_RANGES=0: off)
+  int key_ranges_force = 0;        // HMJ_KEY_RANGES_FORCE=n (tests): every ordered device-resident join in 2^n key ranges
   bool rank_runs_wave = true;      // ... partitions of <= 512 rows: one WAVE sorts a partition, four partitions per workgroup (HMJ_RANK_RUNS_WAVE=0: off)
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)

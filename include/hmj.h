@@ -49,7 +49,8 @@ typedef struct hmj_ctx hmj_ctx;
 
 /* flags for hmj_join_* */
 #define HMJ_MATERIALIZE 0x01u /* produce the (key, rval, sval) columns; else count/sums only --   */
-                              /* the reduction hashjoin_bench.cc:131-133 performs                 */
+                              /* the reduction hashjoin_bench.cc:131-133 performs.  Row order is  */
+                              /* unspecified without HMJ_ORDERED (a join may come back ordered)   */
 #define HMJ_ORDERED 0x02u     /* rows sorted by (key, rval, sval): HashMergeJoin iteration order  */
                               /* (hashjoin.h:104-154); implies HMJ_MATERIALIZE                    */
 #define HMJ_FIRST_WINS 0x04u  /* each probe row pairs with the FIRST build row of its key in      */
@@ -126,6 +127,7 @@ typedef struct {
 #define HMJ_PATH_RANK_RUNS 0x1000000u /* ... rows partitioned by key rank -- longer runs: by (rank, piece of the payloads' range) -- with two slab passes, each partition sorted in LDS */
 #define HMJ_PATH_RANK_LOOKUP_IN_PASS 0x2000000u /* ... with the key -> rank lookup inside the first slab pass (every probe row had its build row) */
 #define HMJ_PATH_SORT_MSD 0x4000000u /* hmj_sort_u64_device: two slab passes on the top varying key bits + an LDS sort of every partition */
+#define HMJ_PATH_KEY_RANGES 0x8000000u /* ordered join no single plan holds: both relations cut into key ranges, joined one after the other, rows appended */
 #define HMJ_PATH_ORDERED_EXPANSION 0x400000u /* ordered, duplicate build keys: rows written in order partition by partition (no sort of result rows) */
 #define HMJ_PATH_LDS_TABLE 0x800000u /* ... of <= 2048 build rows (1024 with HMJ_CHECKSUM / HMJ_SUM_PROBE) under >= 2^16 probe rows, count modes: that table in LDS, one copy per workgroup */
 #define HMJ_PATH_GLOBAL_TABLE 0x100000u /* small build side: one global hash table, the probe side streamed unpartitioned */

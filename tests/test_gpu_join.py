@@ -1586,6 +1586,59 @@ def test_rank_runs_in_the_larger_workgroup_shapes(H, oracle):
     ex.close()
 
 
+def test_ordered_join_by_key_ranges(H, oracle):
+    # Ordered foreign-key joins that no single 18-bit plan holds (2^30 probe rows over a few million build rows) are cut into
+    # 2^h key ranges on the top varying key bits, joined one after the other, their rows appended (HMJ_PATH_KEY_RANGES).
+    # Here every ordered device-resident join is sent that way (HMJ_KEY_RANGES_FORCE = 1 / 2): exact row sequences against the
+    # oracle for unique and duplicate keys, unmatched rows, dense keys (the varying bits are the low ones), a build side that
+    # misses whole ranges (with and without the probe-payload sum), one key value in all (nothing to cut on), tiny inputs.
+    rng = np.random.default_rng(23)
+    for force in (1, 2):
+        os.environ["HMJ_KEY_RANGES_FORCE"] = str(force)
+        try:
+            ex = H.Executor(0)
+        finally:
+            del os.environ["HMJ_KEY_RANGES_FORCE"]
+        cases = []
+        B = oracle.gen_build(50000)
+        cases.append(("fk", B, oracle.gen_uniform_domain(400001, 50000)))
+        cases.append(("miss", B, oracle.gen_probe(300000, 50000, miss_mod=3)))
+        kd = rng.integers(0, 20000, 60000).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        cases.append(("dups", np.stack([kd[:30000], np.arange(30000, dtype=np.uint64)], 1), np.stack([kd[30000:], np.arange(30000, dtype=np.uint64) * np.uint64(7)], 1)))
+        dense = rng.permutation(1 << 17).astype(np.uint64)
+        cases.append(("dense", np.stack([dense[:100000], np.arange(100000, dtype=np.uint64)], 1),
+                      np.stack([dense[rng.integers(0, 1 << 17, 250000)], np.arange(250000, dtype=np.uint64)], 1)))
+        low = B[B[:, 0] < np.uint64(1 << 62)]  # build keys in the lowest quarter of the key range only
+        cases.append(("build_misses_ranges", low, oracle.gen_uniform_domain(200000, 50000)))
+        one = np.full(3000, 0xABCDEF0123, dtype=np.uint64)
+        cases.append(("one_key", np.stack([one[:3], np.arange(3, dtype=np.uint64)], 1), np.stack([one, np.arange(3000, dtype=np.uint64)], 1)))
+        cases.append(("tiny", B[:3].copy(), oracle.gen_uniform_domain(7, 3)))
+        for name, Bc, Pc in cases:
+            Bc, Pc = np.ascontiguousarray(Bc), np.ascontiguousarray(Pc)
+            ck, rows = oracle.equijoin(Bc, Pc)
+            for fl in (H.HMJ_ORDERED, H.HMJ_ORDERED | H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE):
+                r = ex.join_device(to_dev(Bc), to_dev(Pc), fl)
+                took = bool(ex.last_timing()["path"] & H.HMJ_PATH_KEY_RANGES)
+                assert took == (name != "one_key"), (force, name, hex(ex.last_timing()["path"]))
+                assert (int(r.n_matches), int(r.sum_r), int(r.sum_s)) == (ck["n_matches"], ck["sum_r"], ck["sum_s"]), (force, name, fl)
+                if fl & H.HMJ_CHECKSUM:
+                    assert r.checks() == ck and int(r.sum_probe_all) == int(Pc[:, 1].sum(dtype=np.uint64)), (force, name)
+                assert np.array_equal(ex.columns_to_numpy(r, host=False), rows), (force, name, fl)
+            # (count modes and host-resident calls never go that way)
+            r = ex.join_device(to_dev(Bc), to_dev(Pc), H.HMJ_CHECKSUM)
+            assert not ex.last_timing()["path"] & H.HMJ_PATH_KEY_RANGES and r.checks() == ck
+        rh = ex.join_host(cases[0][1], cases[0][2], H.HMJ_ORDERED)
+        assert not ex.last_timing()["path"] & H.HMJ_PATH_KEY_RANGES
+        assert np.array_equal(ex.columns_to_numpy(rh, host=True), oracle.equijoin(cases[0][1], cases[0][2])[1])
+        ex.close()
+    # the gate: nothing the planner's own paths hold goes that way
+    ex = H.Executor(0)
+    Bc, Pc = oracle.gen_build(50000), oracle.gen_uniform_domain(400001, 50000)
+    ex.join_device(to_dev(Bc), to_dev(Pc), H.HMJ_ORDERED)
+    assert not ex.last_timing()["path"] & H.HMJ_PATH_KEY_RANGES
+    ex.close()
+
+
 def test_rank_payload_composites_sorted_by_a_chain_of_slab_passes(H, oracle):
     # The composite sort's LSD passes as histogram-free slab passes: slab pass A over the dense composites, then slab pass B
     # chained into itself (its input is "the worker-private slabs of the pass before", its output has the same shape), the last
