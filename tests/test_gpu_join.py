@@ -1705,8 +1705,8 @@ def test_mid_size_build_side_probes_the_slabs_of_one_pass(ex_fresh, H, oracle):
             B[dup - 1::dup, 0] = B[0::dup, 0][:m]
         P = oracle.gen_uniform_domain(npb, nb) if miss == 0 else oracle.gen_probe(npb, nb, miss_mod=miss)
         Bd, Pd = to_dev(B), to_dev(P)
+        ck, _ = oracle.equijoin(B, P, cap=0)
         for fl in (0, H.HMJ_CHECKSUM, H.HMJ_SUM_PROBE, H.HMJ_CHECKSUM | H.HMJ_SUM_PROBE):
-            ck, _ = oracle.equijoin(B, P, cap=0)
             ex.set_profiling(True)
             r = ex.join_device(Bd, Pd, fl)
             t = ex.last_timing()

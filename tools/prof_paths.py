@@ -5,7 +5,7 @@ the join paths that only had wall-clock sweeps.  Prints one JSON
 
 Names: small16_count small16_mat small16_ord small11_count mid20_count dup8_ord fk22_ord sort28 fk24_ord
        small16_ord64 (payloads spanning 64 bits) headline small12_ord (runs of 16384 rows: cut into 16 pieces)
-       small10_ord28 (2^10 x 2^28: 256 pieces per run)
+       small10_ord28 (2^10 x 2^28: 256 pieces per run) configs1_26 (2^26 x 2^26 count)
 Algorithmic bytes: every input row read once (16 B), every result row written once (24 B; 16 B for the sort)."""
 import json
 import os
@@ -52,6 +52,8 @@ elif name == "fk24_ord":
     R, S, fl = ex.gen_build(1 << 24), ex.gen_uniform_domain(n28, 1 << 24), H.HMJ_ORDERED
 elif name == "headline":
     R, S, fl = ex.gen_build(n28), ex.gen_probe(n28, n28), 0
+elif name == "configs1_26":  # BASELINE configs[1]'s size under the planner's own bits
+    R, S, fl = ex.gen_build(n26), ex.gen_probe(n26, n26), 0
 elif name == "sort28":
     R, S, fl, sort = ex.gen_build(n28), None, 0, True
 else:
