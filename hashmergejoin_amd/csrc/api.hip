@@ -36,6 +36,37 @@ int fail(hmj_ctx* c, int code, const char* what, hipError_t e) {
   return code;
 }
 
+// the per-phase times and byte counts of one (sub-)join, added to the step's totals
+void add_timing(hmj_timing* acc, const hmj_timing& t) {
+  acc->ms_total += t.ms_total;
+  acc->ms_partition_build += t.ms_partition_build;
+  acc->ms_partition_probe += t.ms_partition_probe;
+  acc->ms_hist += t.ms_hist;
+  acc->ms_scan += t.ms_scan;
+  acc->ms_scatter += t.ms_scatter;
+  acc->ms_offsets += t.ms_offsets;
+  acc->ms_probe_count += t.ms_probe_count;
+  acc->ms_out_scan += t.ms_out_scan;
+  acc->ms_probe_write += t.ms_probe_write;
+  acc->ms_order += t.ms_order;
+  acc->n_scatter_launches += t.n_scatter_launches;
+  acc->n_split_retries += t.n_split_retries;
+  acc->bytes_scatter += t.bytes_scatter;
+  acc->bytes_hist += t.bytes_hist;
+  acc->bytes_probe_count += t.bytes_probe_count;
+  acc->bytes_probe_write += t.bytes_probe_write;
+  acc->path |= t.path;
+  acc->ms_scatter_pass[0] += t.ms_scatter_pass[0];
+  acc->ms_scatter_pass[1] += t.ms_scatter_pass[1];
+  if (t.radix_passes) {  // the plan of the latest sub-join that partitioned anything
+    acc->radix_bits = t.radix_bits;
+    acc->radix_passes = t.radix_passes;
+    acc->key_prefix_bits = t.key_prefix_bits;
+    acc->key_window_low = t.key_window_low;
+  }
+  acc->n_probe_items += t.n_probe_items;
+}
+
 #define HIP_TRY(expr)                                                   \
   do {                                                                  \
     hipError_t _e = (expr);                                             \
@@ -2639,8 +2670,9 @@ static int join_by_key_ranges(hmj_ctx* c, const void* R, uint64_t n_build, const
   // ---- 3. range after range: a join of its own, its rows appended
   hmj_result tot;
   std::memset(&tot, 0, sizeof(tot));
+  hmj_timing tsum;  // (the call's phases: the sum over its ranges)
+  std::memset(&tsum, 0, sizeof(tsum));
   u64 rows_done = 0;
-  u32 path = 0;
   auto grow = [&](u64 need_rows) -> int {  // the three result columns hold need_rows (what is there stays)
     const size_t bytes = (size_t)need_rows * 8;
     DevBuf* cols[3] = {&c->cat_key, &c->cat_rval, &c->cat_sval};
@@ -2649,8 +2681,12 @@ static int join_by_key_ranges(hmj_ctx* c, const void* R, uint64_t n_build, const
       DevBuf nw;
       int r2 = ensure_dev(c, nw, bytes + (bytes >> 2));
       if (r2 != HMJ_OK) return r2;
-      if (rows_done) HIP_TRY(hipMemcpyAsync(nw.p, b->p, (size_t)rows_done * 8, hipMemcpyDeviceToDevice, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      hipError_t e = rows_done ? hipMemcpyAsync(nw.p, b->p, (size_t)rows_done * 8, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) {
+        free_dev(nw);  // (the column keeps what it held; the join fails)
+        return fail(c, HMJ_E_HIP, "growing a result column of a join by key ranges", e);
+      }
       free_dev(*b);
       *b = nw;
     }
@@ -2664,7 +2700,7 @@ static int join_by_key_ranges(hmj_ctx* c, const void* R, uint64_t n_build, const
     std::memset(&sub, 0, sizeof(sub));
     rc = join_device_planned(c, (const char*)c->split_r.p + r0 * 16, nr, (const char*)c->split_s.p + s0 * 16, ns, flags, &sub, false);
     if (rc != HMJ_OK) return rc;
-    path |= c->timing.path;
+    add_timing(&tsum, c->timing);
     if (sub.n_matches) {
       if (rows_done == 0 && d + 1 < D) {  // (first range: room for the whole result at this range's rate, so that growing is rare)
         const double est = (double)sub.n_matches * (double)np / (double)ns * 1.05 + 4096.0;
@@ -2689,7 +2725,8 @@ static int join_by_key_ranges(hmj_ctx* c, const void* R, uint64_t n_build, const
   out->key = rows_done ? (const uint64_t*)c->cat_key.p : nullptr;
   out->rval = rows_done ? (const uint64_t*)c->cat_rval.p : nullptr;
   out->sval = rows_done ? (const uint64_t*)c->cat_sval.p : nullptr;
-  c->timing.path = path | HMJ_PATH_KEY_RANGES;
+  c->timing = tsum;
+  c->timing.path |= HMJ_PATH_KEY_RANGES;
   *done = true;
   return HMJ_OK;
 }

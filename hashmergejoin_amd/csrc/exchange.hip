@@ -906,36 +906,6 @@ void add_result(hmj_result* acc, const hmj_result& r) {
   acc->sum_probe_all += r.sum_probe_all;
 }
 
-// the per-phase times and byte counts of one (sub-)join, added to the step's totals
-void add_timing(hmj_timing* acc, const hmj_timing& t) {
-  acc->ms_total += t.ms_total;
-  acc->ms_partition_build += t.ms_partition_build;
-  acc->ms_partition_probe += t.ms_partition_probe;
-  acc->ms_hist += t.ms_hist;
-  acc->ms_scan += t.ms_scan;
-  acc->ms_scatter += t.ms_scatter;
-  acc->ms_offsets += t.ms_offsets;
-  acc->ms_probe_count += t.ms_probe_count;
-  acc->ms_out_scan += t.ms_out_scan;
-  acc->ms_probe_write += t.ms_probe_write;
-  acc->ms_order += t.ms_order;
-  acc->n_scatter_launches += t.n_scatter_launches;
-  acc->n_split_retries += t.n_split_retries;
-  acc->bytes_scatter += t.bytes_scatter;
-  acc->bytes_hist += t.bytes_hist;
-  acc->bytes_probe_count += t.bytes_probe_count;
-  acc->bytes_probe_write += t.bytes_probe_write;
-  acc->path |= t.path;
-  acc->ms_scatter_pass[0] += t.ms_scatter_pass[0];
-  acc->ms_scatter_pass[1] += t.ms_scatter_pass[1];
-  if (t.radix_passes) {  // the plan of the latest sub-join that partitioned anything
-    acc->radix_bits = t.radix_bits;
-    acc->radix_passes = t.radix_passes;
-    acc->key_prefix_bits = t.key_prefix_bits;
-    acc->key_window_low = t.key_window_low;
-  }
-  acc->n_probe_items += t.n_probe_items;
-}
 float kernel_ms(const hmj_timing& t) {
   return t.ms_hist + t.ms_scan + t.ms_scatter + t.ms_offsets + t.ms_probe_count + t.ms_out_scan + t.ms_probe_write + t.ms_order;
 }

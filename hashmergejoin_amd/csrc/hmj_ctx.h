@@ -224,6 +224,8 @@ struct hmj_ctx {
 
 namespace hmj_host {
 int fail(hmj_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+// the per-phase times and byte counts of one (sub-)join, added to a call's totals (exchange rounds, key ranges); api.hip
+void add_timing(hmj_timing* acc, const hmj_timing& t);
 int ensure_dev(hmj_ctx* c, DevBuf& b, size_t bytes);
 int ensure_host(hmj_ctx* c, HostBuf& b, size_t bytes, bool pinned = true);
 void free_dev(DevBuf& b);
