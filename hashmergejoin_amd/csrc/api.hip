@@ -2297,9 +2297,45 @@ int try_small_build_ordered(hmj_ctx* c, const void* R, uint64_t n_build, const v
     }
   }
   if (nb > 1 && key_diff == 0) return give_up("duplicate build keys");
-  // ---- 2. the build side in key order: stable LSD passes over the digits in which keys differ
+  // ---- 2. the build side in key order.  MSD: ONE exact pass on the top varying key bits -- partitions of ~512 rows -- and a
+  // stable LDS sort of every partition on the rest (gtable.hip, sort_runs_write_kernel on dense partitions): 4 launches
+  // instead of the 24 of eight LSD passes, which were 0.3 of the 2.4 ms of a 2^16 x 2^26-row join (profiles/r05u_small16_ord_*).
+  // Keys crowded into few partitions or clustered inside one raise ERR_FASTPATH (one 8-byte read-back): the LSD passes run.
   const void* sortedR = R;
-  {
+  bool build_sorted = false;
+  if (c->build_sort_msd && key_diff != 0 && nb >= 2) {
+    const int hb = 63 - __builtin_clzll(key_diff);
+    int h = 0;
+    while (h < hmj::RP_MAX_BITS && ((u64)nb >> h) > 512) h++;
+    if (h > hb + 1) h = hb + 1;
+    const double mean = (double)nb / (double)(1u << h);
+    int level = 0;
+    while (level < 2 && mean + 8.0 * std::sqrt(mean) + 24.0 > (double)hmj::rank_sort_max_run(level)) level++;
+    if (mean + 8.0 * std::sqrt(mean) + 24.0 <= (double)hmj::rank_sort_max_run(level)) {
+      const u32 P = 1u << h;
+      if ((rc = ensure_dev(c, c->msd_off, ((size_t)P + 1) * 8)) != HMJ_OK) return rc;
+      HIP_TRY(hipMemsetAsync(c->accum.p, 0, 8 * sizeof(u64), c->stream));
+      const void* parted = R;
+      if (h > 0) {
+        if ((rc = radix_pass(c, R, c->rbuf[0].p, nb, hb + 1 - h, h, 0, (u64*)c->msd_off.p, 0)) != HMJ_OK) return rc;
+        parted = c->rbuf[0].p;
+      } else {
+        const u64 off01[2] = {0, nb};
+        HIP_TRY(hipMemcpyAsync(c->msd_off.p, off01, sizeof(off01), hipMemcpyHostToDevice, c->stream));
+      }
+      const int so = span_begin(c, K_ORDER, -1);
+      HIP_TRY(hmj::launch_sort_runs_write(parted, nullptr, 0, P, (const u64*)c->msd_off.p, c->rbuf[1].p, (u64*)c->accum.p, level, c->num_cus,
+                                          c->stream));
+      span_end(c, so);
+      HIP_TRY(hipMemcpyAsync(hh, (u64*)c->accum.p + hmj::ACC_ERR, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (!(hh[0] & hmj::ERR_FASTPATH)) {
+        sortedR = c->rbuf[1].p;
+        build_sorted = true;
+      }
+    }
+  }
+  if (!build_sorted) {
     u32 digits = 0;
     for (int i = 0; i < 8; i++) digits |= ((key_diff >> (8 * i)) & 0xFFu) ? (1u << i) : 0u;
     int k = 0;
@@ -2930,6 +2966,7 @@ int hmj_create(hmj_ctx** out, int device_id) {
   }
   if (const char* e = getenv("HMJ_GTABLE_FANOUT")) c->gtable_min_fanout = atoi(e) > 0 ? (u32)atoi(e) : 0u;
   if (const char* e = getenv("HMJ_GTABLE_WG")) c->gtable_wg_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+  if (const char* e = getenv("HMJ_BUILD_SORT_MSD")) c->build_sort_msd = atoi(e) != 0;  // 0: the rank forms sort their build side by LSD passes
   if (const char* e = getenv("HMJ_GTABLE_SORT_SLAB")) c->gtable_sort_slab = atoi(e) != 0;  // 0: the composites' LSD passes are exact passes (hist + scan + scatter)
   if (const char* e = getenv("HMJ_FK_PAYLOAD_BUCKETS")) c->fk_payload_buckets = atoi(e) > 0 ? (u32)atoi(e) : 0u;  // fan-out from which the ordered foreign-key write buckets by payload (0: never)
   if (const char* e = getenv("HMJ_ORDERED_EXPANSION")) c->expand_mode = atoi(e) != 0;  // 0: ordered joins with duplicate build keys write in probe order and sort the rows
@@ -3006,7 +3043,7 @@ void hmj_destroy(hmj_ctx* c) {
                     &c->part_out_off, &c->accum, &c->out_key, &c->out_rval, &c->out_sval,
                     &c->offs64, &c->irregular, &c->ord_key, &c->ord_rval, &c->ord_sval, &c->matched, &c->vparts,
                     &c->slab_a, &c->slab_br, &c->slab_bs, &c->cnt_a, &c->cnt_br, &c->cnt_bs, &c->lookback, &c->gtab, &c->piece_off,
-                    &c->split_r, &c->split_s, &c->split_off, &c->cat_key, &c->cat_rval, &c->cat_sval};
+                    &c->split_r, &c->split_s, &c->split_off, &c->cat_key, &c->cat_rval, &c->cat_sval, &c->msd_off};
   for (DevBuf* b : devs) free_dev(*b);
   HostBuf* hosts[] = {&c->h_accum, &c->h_key, &c->h_rval, &c->h_sval};
   for (HostBuf* b : hosts) free_host(*b);

@@ -1126,15 +1126,23 @@ __global__ __launch_bounds__(T, 4) void sort_runs_write_kernel(const Tup* __rest
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   bool bad = false;
   for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
-    const u32* q = cnt + (u64)p * SLAB_KB;
-    const u32 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+    u32 c0, c1 = 0, c2 = 0, c3 = 0;
+    const Tup* __restrict__ base;
+    if (cnt) {
+      const u32* q = cnt + (u64)p * SLAB_KB;
+      c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+      base = slabs + (u64)p * SLAB_KB * cap;
+    } else {  // dense partitions (one exact radix pass in front): partition p is rows [out_off[p], out_off[p + 1]) of `slabs` too
+      const u64 o0 = out_off[p], o1 = out_off[p + 1];
+      c0 = o1 - o0 > (u64)RS_CAP ? (u32)RS_CAP + 1u : (u32)(o1 - o0);
+      base = slabs + o0;
+    }
     const u32 n = c0 + c1 + c2 + c3;
     if (n == 0) continue;
     if (n > (u32)RS_CAP || c0 > cap || c1 > cap || c2 > cap || c3 > cap) {  // (uniform)
       bad = true;
       continue;
     }
-    const Tup* __restrict__ base = slabs + (u64)p * SLAB_KB * cap;
     u64 kv[RS_EPT], pv[RS_EPT];
     u64 mn = ~0ull, mx = 0;
 #pragma unroll
@@ -1237,7 +1245,10 @@ static hipError_t rs_launch_prep(Kern kern, size_t smem, SmemAttrOnce& once) {
 }
 hipError_t launch_sort_runs_write(const void* slabs, const u32* cnt, u32 cap, u32 P, const u64* out_off, void* out, u64* accum, int level,
                                   int num_cus, hipStream_t st) {
-  if (!slabs || !cnt || !out_off || !out || !accum || P == 0 || cap == 0 || level < 0 || level > 2) return hipErrorInvalidValue;
+  // cnt == nullptr: dense partitions -- `slabs` holds the rows partitioned in place of the output, partition p = rows
+  // [out_off[p], out_off[p + 1]) (P + 1 offsets), cap is not looked at
+  if (!slabs || !out_off || !out || !accum || P == 0 || (cnt && cap == 0) || level < 0 || level > 2) return hipErrorInvalidValue;
+  if (!cnt) cap = 0xFFFFFFFFu;
   u32 grid = (u32)num_cus * (level == 0 ? 4u : level == 1 ? 2u : 1u);  // what is resident at once (launch bounds; 32 / 64 / 129 KiB of LDS per workgroup)
   if (grid > P) grid = P;
 #define HMJ_SRW(T)                                                                                                                    \

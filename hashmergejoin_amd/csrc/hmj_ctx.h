@@ -104,7 +104,8 @@ struct hmj_ctx {
   DevBuf rbuf[2], sbuf[2], in_r, in_s, hist, totals, r_off, s_off, part_count, part_out_off, accum,
       out_key, out_rval, out_sval, ord_key, ord_rval, ord_sval, offs64, irregular, matched, vparts,
       slab_a, slab_br, slab_bs, cnt_a, cnt_br, cnt_bs, lookback, gtab, piece_off,
-      split_r, split_s, split_off, cat_key, cat_rval, cat_sval;  // joins by key ranges: both relations cut, the appended result columns
+      split_r, split_s, split_off, cat_key, cat_rval, cat_sval,  // joins by key ranges: both relations cut, the appended result columns
+      msd_off;  // the rank forms' build-side sort: partition offsets of its one MSD pass
   HostBuf h_accum, h_key, h_rval, h_sval;
   int host_threads = 0;  // staging threads for pageable input (0 = default)
   std::vector<hipStream_t> up_streams;
@@ -170,6 +171,7 @@ struct hmj_ctx {
   bool key_ranges = true;          // ordered foreign-key joins no single plan holds are cut into key ranges joined one after the other (HMJ_KEY_RANGES=0: off)
   int key_ranges_force = 0;        // HMJ_KEY_RANGES_FORCE=n (tests): every ordered device-resident join in 2^n key ranges
   bool rank_runs_wave = true;      // ... partitions of <= 512 rows: one WAVE sorts a partition, four partitions per workgroup (HMJ_RANK_RUNS_WAVE=0: off)
+  bool build_sort_msd = true;      // the rank forms sort their build side by ONE radix pass + an LDS sort per partition (HMJ_BUILD_SORT_MSD=0: LSD passes)
   bool gtable_sort_slab = true;    // the composites' LSD passes are histogram-free slab passes chained one into the next (HMJ_GTABLE_SORT_SLAB=0: exact passes)
   u64 gtable_sort_slab_min = 1ull << 25;  // ... from this many composites on (HMJ_GTABLE_SORT_SLAB_MIN_LOG2; below: no gain, 2^24 rows 1.7 ms either way)
   bool expand_mode = true;         // ordered joins with duplicate build keys write their rows in order, partition by partition (HMJ_ORDERED_EXPANSION=0: write + sort)

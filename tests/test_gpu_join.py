@@ -1474,6 +1474,9 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
                                (3000, 4500000, 0, "ids"), (3001, 1500000, 5, "wide"), (4000, 1200000, 0, "hot"), (300, 5000, 0, "ids"),
                                (2000, 700000, 0, "ties7"), (2000, 600001, 3, "const"), (1500, 500000, 0, "extremes"),
                                (3000, 400000, 2, "dupbuild"),
+                               # build keys crowded into one partition of the build side's MSD sort (all but three below 4000, three
+                               # near 2^60): its LDS sort gives up and the LSD passes sort the build side
+                               (4000, 2200001, 0, "clustered"),
                                # runs beyond one workgroup's sort, cut by payload position: random and position-ordered payloads,
                                # 64-bit payloads, a ragged last chunk, probe rows without a build row (-> composites), payloads
                                # of seven values (pieces that cannot be even -> composites)
@@ -1496,7 +1499,14 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             P[:, 1] = rng.integers(0, 1 << 62, size=npb, dtype=np.uint64)
             P[::5, 1] = np.uint64(0)
             P[1::5, 1] = np.uint64(M64)
-        if pay == "ids":
+        if pay == "clustered":  # an order-preserving renaming of the keys, on both sides
+            order = np.argsort(B[:, 0], kind="stable")
+            sk = B[order, 0].copy()
+            newk = np.arange(nb, dtype=np.uint64)
+            newk[-3:] = np.uint64(1 << 60) + np.arange(3, dtype=np.uint64) * np.uint64(0x1000000000)
+            P[:, 0] = newk[np.searchsorted(sk, P[:, 0])]
+            B[order, 0] = newk
+        if pay in ("ids", "clustered"):
             P[:, 1] = rng.permutation(npb).astype(np.uint64)
         elif pay == "rowid":  # grows with the row's position, like a fact table's row ids or timestamps
             P[:, 1] = np.uint64(0x0000123400000000) + np.arange(npb, dtype=np.uint64) * np.uint64(3)
@@ -1513,11 +1523,11 @@ def test_ordered_small_build_side_sorts_rank_payload_composites(ex_fresh, H, ora
             t = ex.last_timing()
             took = bool(t["path"] & RS)
             # (payloads spanning all 64 bits go as two words: sorted by payload, then stably by rank)
-            assert took == (pay in ("ids", "rowid", "offset", "wide", "hot", "ties7", "const", "extremes")), (nb, npb, pay, fl, hex(t["path"]))
+            assert took == (pay in ("ids", "rowid", "offset", "wide", "hot", "ties7", "const", "extremes", "clustered")), (nb, npb, pay, fl, hex(t["path"]))
             cut = _rank_runs_cut(nb, npb)
             cut = cut and cut[0]
             # (cut runs exist only with the lookup inside pass A, and their pieces are even only where the payloads are spread)
-            runs = pay in ("ids", "rowid", "offset", "wide", "ties7", "const") and cut is not None and (
+            runs = pay in ("ids", "rowid", "offset", "wide", "ties7", "const", "clustered") and cut is not None and (
                 cut == 0 or (cut > 0 and miss == 0 and pay != "ties7") or (cut < 0 and pay != "wide"))
             assert bool(t["path"] & RR) == runs, (nb, npb, pay, fl, hex(t["path"]))
             # every probe row has its build row (miss == 0): the rank lookup runs inside the first slab pass; unmatched
