@@ -187,6 +187,7 @@ def extra_runs(ex, H, torch):
         out["configs0_strgen_1M_ms"] = sg["ms"]
         out["configs0_strgen_1M"] = {"ms_ctor": sg["ms_ctor"], "ms_iterate": sg["ms_iterate"], "ms_first_call": sg["ms_first_call"],
                                      "host_threads": sg["host_threads"], "tuples_per_s": round(1e6 / (sg["ms"] * 1e-3)),
+                                     "timed": "construct + iterate + reduce to one sum (hashjoin_bench.cc:126-133), best of the repetitions; the count and the ordered FNV come from a second, untimed walk over the same join",
                                      "checked": "count / sum / ordered FNV of the pairs == tests/golden strgen_join (the compiled reference's output)"}
     else:
         out["configs0_strgen_1M_ms"] = None

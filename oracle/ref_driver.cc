@@ -329,10 +329,18 @@ double ref_hashmergejoin_strgen_timed(const char* words_path, uint64_t n, uint64
   for (int it = 0; it < reps; it++) {
     const auto t0 = std::chrono::steady_clock::now();
     HashMergeJoin<KeyValVec::iterator, KeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), threads);
-    uint64_t cnt = 0, sum = 0, fnv = 0xCBF29CE484222325ull;
+    // the timed region is the benchmark's own (hashjoin_bench.cc:126-133): construct, iterate, reduce to one sum
+    uint64_t sum = 0;
+    for (auto t : hmj) sum += *std::get<1>(t) + *std::get<2>(t);
+    const volatile uint64_t keep = sum;
+    (void)keep;
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (sec < best) best = sec;
+    // the check is not timed: a second walk over the same join for the count and the ordered FNV of the pairs
+    uint64_t cnt = 0, sum2 = 0, fnv = 0xCBF29CE484222325ull;
     for (auto t : hmj) {
       const uint64_t w[2] = {*std::get<1>(t), *std::get<2>(t)};
-      sum += w[0] + w[1];
+      sum2 += w[0] + w[1];
       cnt++;
       for (int q = 0; q < 2; q++)
         for (int b = 0; b < 8; b++) {
@@ -340,11 +348,9 @@ double ref_hashmergejoin_strgen_timed(const char* words_path, uint64_t n, uint64
           fnv *= 0x100000001B3ull;
         }
     }
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (sec < best) best = sec;
     if (out3) {
       out3[0] = cnt;
-      out3[1] = sum;
+      out3[1] = sum2 == sum ? sum : ~0ull;  // (the two walks must agree)
       out3[2] = fnv;
     }
   }
