@@ -30,7 +30,10 @@
 #define HASHMERGEJOIN_HIP_HPP 1
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <iterator>
@@ -129,6 +132,17 @@ inline const void* relation_rows(Iter begin, std::size_t n, StagedRows& stage) {
 // equal (eq(r_row, s_row)); inside a run of equal hashes the pairs are ordered by key (less(r_row_a,
 // r_row_b)), as the reference's sort does (radix_hash.h:86-109 breaks hash ties on the key).  Fills the
 // matching row indices in iteration order.
+// a per-thread buffer of 64-bit words that only grows and is never initialised (the {hash, row} rows of the string-key operator)
+inline std::uint64_t* hash_scratch(std::size_t words) {
+  thread_local std::unique_ptr<std::uint64_t[]> buf;
+  thread_local std::size_t cap = 0;
+  if (words > cap) {
+    buf.reset();
+    buf.reset(new std::uint64_t[words + words / 8 + 16]);
+    cap = words + words / 8 + 16;
+  }
+  return buf.get();
+}
 // fn(begin, end) over [0, n) on up to `threads` host threads (the caller's thread takes the last share)
 template <typename Fn>
 inline void parallel_ranges(std::size_t n, unsigned threads, Fn fn) {
@@ -210,6 +224,101 @@ inline void join_hashed_rows(const std::vector<std::pair<std::uint64_t, std::uin
     }
     i = j;
   }
+}
+
+// The same join for a caller that also wants something from every result pair (the string-key operator copies the
+// payloads): in the usual case -- no collision, no repeated hash -- the GPU's columns ARE the answer, so they are kept where
+// they are (pooled host memory, held by `rows`) instead of being copied into vectors, and visit(k, r_row, s_row) runs inside
+// the verification pass, on the thread that has just pulled both rows into its cache (a second pass over 10^6 pairs misses
+// the cache twice per pair again).  prep(n) is called once before the pass.  Otherwise the pairs end up in ri_own / si_own
+// as join_hashed_rows leaves them and `visited` is false: the caller walks them itself.
+struct HashedJoin {
+  std::shared_ptr<hmj_rows> rows;
+  const std::uint64_t* ri = nullptr;
+  const std::uint64_t* si = nullptr;
+  std::size_t n = 0;
+  std::vector<std::uint64_t> ri_own, si_own;
+  bool visited = false;
+  void clear() {
+    rows.reset();
+    ri = si = nullptr;
+    n = 0;
+    ri_own.clear();
+    si_own.clear();
+    visited = false;
+  }
+};
+template <typename Eq, typename Less, typename Prep, typename Visit>
+inline void join_hashed_rows_visit(const std::uint64_t* hr, std::size_t nr, const std::uint64_t* hs, std::size_t ns,
+                                   unsigned num_threads, Eq eq, Less less, Prep prep, Visit visit, HashedJoin& out) {
+  // hr / hs: nr / ns rows of {hash, row index}, two 64-bit words each
+  out.clear();
+  const auto tstart = std::chrono::steady_clock::now();
+  hmj_ctx* c = thread_ctx();
+  hmj_set_host_threads(c, num_threads > 16 ? 16 : (int)num_threads);
+  hmj_result res;
+  hmj_rows* rows = nullptr;
+  check(c, hmj_join_u64_rows(c, nr ? hr : nullptr, nr, ns ? hs : nullptr, ns, HMJ_MATERIALIZE | HMJ_ORDERED, &res, &rows),
+        "hmj_join_u64_rows");
+  std::shared_ptr<hmj_rows> guard(rows, hmj_rows_free);
+  const std::size_t n = (std::size_t)res.n_matches;
+  const bool times = std::getenv("HMJ_DROPIN_TIMES") != nullptr;
+  const auto tj = std::chrono::steady_clock::now();
+  prep(n);
+  const auto tp = std::chrono::steady_clock::now();
+  std::vector<char> bad_flag(1, 0);
+  char* bad = bad_flag.data();
+  parallel_ranges(n, num_threads, [&, bad](std::size_t b, std::size_t e) {
+    for (std::size_t k = b; k < e; k++) {
+      const std::uint64_t r = res.rval[k], q = res.sval[k];
+      if (!eq(r, q) || (k + 1 < n && res.key[k + 1] == res.key[k])) {  // a collision between different keys / a repeated hash
+        *bad = 1;  // (benign race: every writer stores the same value)
+        return;
+      }
+      visit(k, r, q);
+    }
+  });
+  if (times)
+    std::fprintf(stderr, "[hmj drop-in] join of {hash,row} rows %.2f ms (from its start), result arrays %.2f ms, verify + visit %.2f ms\n",
+                 std::chrono::duration<double, std::milli>(tj - tstart).count(), std::chrono::duration<double, std::milli>(tp - tj).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
+  if (*bad == 0) {
+    out.rows = guard;
+    out.ri = res.rval;
+    out.si = res.sval;
+    out.n = n;
+    out.visited = true;
+    return;
+  }
+  // (rare: the general walk of join_hashed_rows over the rows already here)
+  std::vector<std::uint64_t>& ri = out.ri_own;
+  std::vector<std::uint64_t>& si = out.si_own;
+  std::size_t i = 0;
+  while (i < n) {
+    std::size_t j = i + 1;
+    while (j < n && res.key[j] == res.key[i]) j++;
+    const std::size_t first = ri.size();
+    for (std::size_t k = i; k < j; k++)
+      if (eq(res.rval[k], res.sval[k])) {
+        ri.push_back(res.rval[k]);
+        si.push_back(res.sval[k]);
+      }
+    if (ri.size() - first > 1) {  // several rows share this hash: order them by key
+      std::vector<std::pair<std::uint64_t, std::uint64_t>> grp;
+      for (std::size_t k = first; k < ri.size(); k++) grp.emplace_back(ri[k], si[k]);
+      std::stable_sort(grp.begin(), grp.end(),
+                       [&](const std::pair<std::uint64_t, std::uint64_t>& a,
+                           const std::pair<std::uint64_t, std::uint64_t>& b) { return less(a.first, b.first); });
+      for (std::size_t k = 0; k < grp.size(); k++) {
+        ri[first + k] = grp[k].first;
+        si[first + k] = grp[k].second;
+      }
+    }
+    i = j;
+  }
+  out.ri = ri.data();
+  out.si = si.data();
+  out.n = ri.size();
 }
 }  // namespace hmj_detail
 
@@ -332,52 +441,65 @@ class HashMergeJoin<RIter, SIter, false> {
   typedef typename std::iterator_traits<RIter>::value_type::second_type RValue;
   typedef typename std::iterator_traits<SIter>::value_type::second_type SValue;
 
-  template <typename Iter>
-  static void hash_rows(Iter begin, std::size_t n, std::vector<std::pair<std::uint64_t, std::uint64_t>>& out,
-                        unsigned threads) {
-    out.resize(n);
-    if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
-    auto work = [&](std::size_t b, std::size_t e) {
-      std::hash<Key> h;
-      for (std::size_t i = b; i < e; i++) out[i] = std::make_pair((std::uint64_t)h(begin[i].first), (std::uint64_t)i);
-    };
-    if (threads == 1 || n < 65536) {
-      work(0, n);
-      return;
-    }
-    std::vector<std::thread> th;
-    const std::size_t per = (n + threads - 1) / threads;
-    for (unsigned t = 0; t < threads; t++) {
-      const std::size_t b = t * per, e = b + per < n ? b + per : n;
-      if (b < e) th.emplace_back(work, b, e);
-    }
-    for (auto& x : th) x.join();
-  }
-
  public:
   HashMergeJoin() = default;
   HashMergeJoin(RIter r_begin, RIter r_end, SIter s_begin, SIter s_end, unsigned int num_threads = 1)
       : _r(r_begin), _s(s_begin) {
     const std::size_t nr = (std::size_t)std::distance(r_begin, r_end), ns = (std::size_t)std::distance(s_begin, s_end);
-    std::vector<std::pair<std::uint64_t, std::uint64_t>> hr, hs;
-    hash_rows(r_begin, nr, hr, num_threads);
-    hash_rows(s_begin, ns, hs, num_threads);
-    hmj_detail::join_hashed_rows(
-        hr, hs, num_threads,
-        [&](std::uint64_t r, std::uint64_t q) { return r_begin[r].first == s_begin[q].first; },
-        [&](std::uint64_t x, std::uint64_t y) { return r_begin[x].first < r_begin[y].first; }, _ri, _si);
-    // The payloads of the result rows are copied into the join object, in iteration order -- the reference's iterator
-    // walks its own sorted copies too (hashjoin.h:168-173) -- so that iterating does not miss the cache twice per row in
-    // the caller's relations (10^6 rows: 126 ms of a 239 ms join, configs[0]); the copy runs on all host threads.
-    _rv.resize(_ri.size());
-    _sv.resize(_ri.size());
-    hmj_detail::parallel_ranges(_ri.size(), num_threads, [&](std::size_t b, std::size_t e) {
-      for (std::size_t k = b; k < e; k++) {
-        _rv[k] = r_begin[_ri[k]].second;
-        _sv[k] = s_begin[_si[k]].second;
+    const bool times = std::getenv("HMJ_DROPIN_TIMES") != nullptr;  // (developer aid: the ctor's phases on stderr)
+    const auto t0 = std::chrono::steady_clock::now();
+    // {hash, row index} rows of both relations in one scratch buffer that this thread keeps from join to join and that is
+    // never zero-filled (10^6 + 10^6 rows: two fresh std::vectors cost 7 of the 11 ms this phase took -- 32 MiB of page
+    // faults and zeroes on one thread --, the hashing itself 3), filled by ONE team of threads
+    std::uint64_t* const hr = hmj_detail::hash_scratch(2 * (nr + ns));
+    std::uint64_t* const hs = hr + 2 * nr;
+    hmj_detail::parallel_ranges(nr + ns, num_threads, [&](std::size_t b, std::size_t e) {
+      std::hash<Key> h;
+      for (std::size_t i = b; i < e; i++) {
+        if (i < nr) {
+          hr[2 * i] = (std::uint64_t)h(r_begin[i].first);
+          hr[2 * i + 1] = (std::uint64_t)i;
+        } else {
+          hs[2 * (i - nr)] = (std::uint64_t)h(s_begin[i - nr].first);
+          hs[2 * (i - nr) + 1] = (std::uint64_t)(i - nr);
+        }
       }
     });
+    const auto t1 = std::chrono::steady_clock::now();
+    // The payloads of the result rows are copied into the join object, in iteration order -- the reference's iterator
+    // walks its own sorted copies too (hashjoin.h:168-173) -- so that iterating does not miss the cache twice per row in
+    // the caller's relations (10^6 rows: 126 ms of a 239 ms join, configs[0]).  The copy happens inside the pass that
+    // verifies the pairs' keys, which has just pulled both rows into the cache, on all host threads.
+    RValue* rv = nullptr;
+    SValue* sv = nullptr;
+    auto alloc = [&](std::size_t n) {
+      _rv = std::shared_ptr<RValue>(new RValue[n ? n : 1], std::default_delete<RValue[]>());
+      _sv = std::shared_ptr<SValue>(new SValue[n ? n : 1], std::default_delete<SValue[]>());
+      rv = _rv.get();
+      sv = _sv.get();
+    };
+    hmj_detail::join_hashed_rows_visit(
+        hr, nr, hs, ns, num_threads,
+        [&](std::uint64_t r, std::uint64_t q) { return r_begin[r].first == s_begin[q].first; },
+        [&](std::uint64_t x, std::uint64_t y) { return r_begin[x].first < r_begin[y].first; }, alloc,
+        [&](std::size_t k, std::uint64_t r, std::uint64_t q) {
+          rv[k] = r_begin[r].second;
+          sv[k] = s_begin[q].second;
+        },
+        _j);
+    if (times)
+      std::fprintf(stderr, "[hmj drop-in] %zu x %zu rows: hash %.2f ms, GPU join + verify + payloads %.2f ms\n", nr, ns,
+                   std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    if (!_j.visited) {  // (colliding or repeated hashes: the pairs were walked one by one; their payloads now)
+      alloc(_j.n);
+      hmj_detail::parallel_ranges(_j.n, num_threads, [&](std::size_t b, std::size_t e) {
+        for (std::size_t k = b; k < e; k++) {
+          rv[k] = r_begin[_j.ri[k]].second;
+          sv[k] = s_begin[_j.si[k]].second;
+        }
+      });
+    }
   }
 
   class iterator : public std::iterator<std::input_iterator_tag, std::tuple<Key*, RValue*, SValue*>> {
@@ -396,8 +518,8 @@ class HashMergeJoin<RIter, SIter, false> {
     bool operator!=(iterator other) const { return _pos != other._pos; }
     std::tuple<Key*, RValue*, SValue*>& operator*() {
       // (the key's ADDRESS in the caller's relation -- nothing of the row is read unless the caller dereferences it)
-      const typename std::iterator_traits<RIter>::value_type& rr = _owner->_r[_owner->_ri[_pos]];
-      tmp_val = std::make_tuple(const_cast<Key*>(&rr.first), &_owner->_rv[_pos], &_owner->_sv[_pos]);
+      const typename std::iterator_traits<RIter>::value_type& rr = _owner->_r[_owner->_j.ri[_pos]];
+      tmp_val = std::make_tuple(const_cast<Key*>(&rr.first), _owner->_rv.get() + _pos, _owner->_sv.get() + _pos);
       return tmp_val;
     }
 
@@ -408,21 +530,20 @@ class HashMergeJoin<RIter, SIter, false> {
   };
 
   iterator begin() { return iterator(this, 0); }
-  iterator end() { return iterator(this, _ri.size()); }
+  iterator end() { return iterator(this, _j.n); }
   void clear() {
-    _ri.clear();
-    _si.clear();
-    _rv.clear();
-    _sv.clear();
+    _j.clear();
+    _rv.reset();
+    _sv.reset();
   }
-  std::size_t size() const { return _ri.size(); }
+  std::size_t size() const { return _j.n; }
 
  protected:
   RIter _r;
   SIter _s;
-  std::vector<std::uint64_t> _ri, _si;  // matching row indices into the caller's relations
-  std::vector<RValue> _rv;              // the result rows' payloads, in iteration order
-  std::vector<SValue> _sv;
+  hmj_detail::HashedJoin _j;    // matching row indices into the caller's relations (the GPU's result columns, kept where they are)
+  std::shared_ptr<RValue> _rv;  // the result rows' payloads, in iteration order (arrays; copies of the join share them)
+  std::shared_ptr<SValue> _sv;
 };
 
 // ---------------------------------------------------------------------------------------------------
