@@ -248,9 +248,12 @@ struct HashedJoin {
     visited = false;
   }
 };
-template <typename Eq, typename Less, typename Prep, typename Visit>
+// touch(r_row, s_row) is called a few pairs AHEAD of eq / visit: the caller prefetches the two rows (every pair is two cache
+// misses into the caller's relations, and a thread that waits for them one pair at a time leaves most of its memory
+// parallelism unused).
+template <typename Eq, typename Less, typename Prep, typename Visit, typename Touch>
 inline void join_hashed_rows_visit(const std::uint64_t* hr, std::size_t nr, const std::uint64_t* hs, std::size_t ns,
-                                   unsigned num_threads, Eq eq, Less less, Prep prep, Visit visit, HashedJoin& out) {
+                                   unsigned num_threads, Eq eq, Less less, Prep prep, Visit visit, Touch touch, HashedJoin& out) {
   // hr / hs: nr / ns rows of {hash, row index}, two 64-bit words each
   out.clear();
   const auto tstart = std::chrono::steady_clock::now();
@@ -269,7 +272,10 @@ inline void join_hashed_rows_visit(const std::uint64_t* hr, std::size_t nr, cons
   std::vector<char> bad_flag(1, 0);
   char* bad = bad_flag.data();
   parallel_ranges(n, num_threads, [&, bad](std::size_t b, std::size_t e) {
+    constexpr std::size_t kAhead = 12;
+    for (std::size_t k = b; k < e && k < b + kAhead; k++) touch(res.rval[k], res.sval[k]);
     for (std::size_t k = b; k < e; k++) {
+      if (k + kAhead < e) touch(res.rval[k + kAhead], res.sval[k + kAhead]);
       const std::uint64_t r = res.rval[k], q = res.sval[k];
       if (!eq(r, q) || (k + 1 < n && res.key[k + 1] == res.key[k])) {  // a collision between different keys / a repeated hash
         *bad = 1;  // (benign race: every writer stores the same value)
@@ -485,6 +491,10 @@ class HashMergeJoin<RIter, SIter, false> {
         [&](std::size_t k, std::uint64_t r, std::uint64_t q) {
           rv[k] = r_begin[r].second;
           sv[k] = s_begin[q].second;
+        },
+        [&](std::uint64_t r, std::uint64_t q) {
+          __builtin_prefetch(&r_begin[r]);
+          __builtin_prefetch(&s_begin[q]);
         },
         _j);
     if (times)
