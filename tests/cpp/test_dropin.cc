@@ -11,6 +11,7 @@
 #include <string>
 #include <thread>
 #include <utility>
+#include <unordered_map>
 #include <vector>
 
 #include "hashmergejoin_hip.hpp"
@@ -207,6 +208,47 @@ static void run_string_case(uint64_t nr, uint64_t ns, uint64_t seed) {
               (unsigned long long)fnv, keys_ok ? 1 : 0);
 }
 
+// ---- std::string keys that REPEAT on the probe side (outside the reference's domain: its merge drops matches then,
+// hashjoin.h:283-294): several result rows share a hash value, so the operator cannot take the GPU's columns as they are and
+// walks the pairs one by one (hmj_detail::join_hashed_rows_visit's general walk, payloads gathered afterwards).  Expected:
+// every equal-key pair once, ascending hash; count and sum by brute force, the key handed out is the row's key.
+static int run_string_repeats_case(uint64_t nr, uint64_t ns, uint64_t seed) {
+  StrKeyValVec r(nr), s(ns);
+  for (uint64_t k = 0; k < nr; k++) r[k] = std::make_pair(synth_key(k, seed), k);
+  for (uint64_t k = 0; k < ns; k++) s[k] = std::make_pair(synth_key((k * 7 + 1) % (nr + nr / 3 + 1), seed), 100 + k);  // wraps: keys repeat; some miss
+  uint64_t want_cnt = 0, want_sum = 0;
+  {
+    std::unordered_map<std::string, uint64_t> m;
+    for (uint64_t k = 0; k < nr; k++) m[r[k].first] = r[k].second;
+    for (uint64_t k = 0; k < ns; k++) {
+      auto it = m.find(s[k].first);
+      if (it != m.end()) {
+        want_cnt++;
+        want_sum += it->second + s[k].second;
+      }
+    }
+  }
+  HashMergeJoin<StrKeyValVec::iterator, StrKeyValVec::iterator> hmj(r.begin(), r.end(), s.begin(), s.end(), 8);
+  uint64_t cnt = 0, sum = 0, prev_hash = 0;
+  bool ok = true;
+  for (auto tuple : hmj) {
+    const uint64_t rv = *std::get<1>(tuple), sv = *std::get<2>(tuple);
+    const std::string& key = *std::get<0>(tuple);
+    ok = ok && key == r[rv].first && key == s[sv - 100].first;
+    const uint64_t h = std::hash<std::string>()(key);
+    ok = ok && (cnt == 0 || h >= prev_hash);
+    prev_hash = h;
+    sum += rv + sv;
+    cnt++;
+  }
+  ok = ok && cnt == want_cnt && sum == want_sum && hmj.size() == want_cnt;
+  if (!ok)
+    std::printf("string keys with repeats nr=%llu ns=%llu: count %llu (want %llu) sum %llu (want %llu) FAILED\n", (unsigned long long)nr,
+                (unsigned long long)ns, (unsigned long long)cnt, (unsigned long long)want_cnt, (unsigned long long)sum,
+                (unsigned long long)want_sum);
+  return ok ? 0 : 1;
+}
+
 // ---- the reference's benchmark relations themselves: r = create_strvec(n), s = create_strvec(n)
 // (hashjoin_bench.cc:112-113; strgen.cc:27-61 restated in oracle/strgen_restated.h over the word-list fixture
 // tests/golden/words.txt).  Expected count / sum / ordered FNV: the compiled reference's (golden "strgen_join");
@@ -401,6 +443,9 @@ int main(int argc, char** argv) {
   run_string_case(1000, 1000, 1);
   run_string_case(5000, 3000, 2);
   run_string_case(200000, 150000, 3);
+  fails += run_string_repeats_case(10, 100, 4);
+  fails += run_string_repeats_case(3000, 20000, 5);
+  fails += run_string_repeats_case(100000, 400000, 6);
   {
     const std::string words_path = argc > 1 ? argv[1] : "tests/golden/words.txt";
     const std::vector<std::string> words = hmj_strgen::load_words(words_path);
