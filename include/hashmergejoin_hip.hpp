@@ -132,6 +132,10 @@ inline const void* relation_rows(Iter begin, std::size_t n, StagedRows& stage) {
 // equal (eq(r_row, s_row)); inside a run of equal hashes the pairs are ordered by key (less(r_row_a,
 // r_row_b)), as the reference's sort does (radix_hash.h:86-109 breaks hash ties on the key).  Fills the
 // matching row indices in iteration order.
+// what a key points at, if anything (std::string: its characters; inline up to 15 of them, on the heap beyond)
+template <typename K>
+inline void prefetch_key_data(const K&) {}
+inline void prefetch_key_data(const std::string& k) { __builtin_prefetch(k.data()); }
 // a per-thread buffer of 64-bit words that only grows and is never initialised (the {hash, row} rows of the string-key operator)
 inline std::uint64_t* hash_scratch(std::size_t words) {
   thread_local std::unique_ptr<std::uint64_t[]> buf;
@@ -248,9 +252,10 @@ struct HashedJoin {
     visited = false;
   }
 };
-// touch(r_row, s_row) is called a few pairs AHEAD of eq / visit: the caller prefetches the two rows (every pair is two cache
-// misses into the caller's relations, and a thread that waits for them one pair at a time leaves most of its memory
-// parallelism unused).
+// touch(stage, r_row, s_row) is called a few pairs AHEAD of eq / visit: the caller prefetches the two rows (stage 0, twelve
+// pairs ahead) and then what the rows point at (stage 1, six ahead: the characters of a std::string beyond its 15 inline
+// ones) -- every pair is two to four cache misses into the caller's relations, and a thread that waits for them one pair at
+// a time leaves most of its memory parallelism unused.
 template <typename Eq, typename Less, typename Prep, typename Visit, typename Touch>
 inline void join_hashed_rows_visit(const std::uint64_t* hr, std::size_t nr, const std::uint64_t* hs, std::size_t ns,
                                    unsigned num_threads, Eq eq, Less less, Prep prep, Visit visit, Touch touch, HashedJoin& out) {
@@ -272,10 +277,12 @@ inline void join_hashed_rows_visit(const std::uint64_t* hr, std::size_t nr, cons
   std::vector<char> bad_flag(1, 0);
   char* bad = bad_flag.data();
   parallel_ranges(n, num_threads, [&, bad](std::size_t b, std::size_t e) {
-    constexpr std::size_t kAhead = 12;
-    for (std::size_t k = b; k < e && k < b + kAhead; k++) touch(res.rval[k], res.sval[k]);
+    constexpr std::size_t kAhead = 12, kNear = 6;  // stage 0: the rows themselves; stage 1: what they point at (a string's characters)
+    for (std::size_t k = b; k < e && k < b + kAhead; k++) touch(0, res.rval[k], res.sval[k]);
+    for (std::size_t k = b; k < e && k < b + kNear; k++) touch(1, res.rval[k], res.sval[k]);
     for (std::size_t k = b; k < e; k++) {
-      if (k + kAhead < e) touch(res.rval[k + kAhead], res.sval[k + kAhead]);
+      if (k + kAhead < e) touch(0, res.rval[k + kAhead], res.sval[k + kAhead]);
+      if (k + kNear < e) touch(1, res.rval[k + kNear], res.sval[k + kNear]);
       const std::uint64_t r = res.rval[k], q = res.sval[k];
       if (!eq(r, q) || (k + 1 < n && res.key[k + 1] == res.key[k])) {  // a collision between different keys / a repeated hash
         *bad = 1;  // (benign race: every writer stores the same value)
@@ -462,6 +469,8 @@ class HashMergeJoin<RIter, SIter, false> {
     hmj_detail::parallel_ranges(nr + ns, num_threads, [&](std::size_t b, std::size_t e) {
       std::hash<Key> h;
       for (std::size_t i = b; i < e; i++) {
+        // (the rows are read in order, but a long string's characters live wherever the allocator put them)
+        if (i + 16 < e) hmj_detail::prefetch_key_data(i + 16 < nr ? r_begin[i + 16].first : s_begin[i + 16 - nr].first);
         if (i < nr) {
           hr[2 * i] = (std::uint64_t)h(r_begin[i].first);
           hr[2 * i + 1] = (std::uint64_t)i;
@@ -492,9 +501,14 @@ class HashMergeJoin<RIter, SIter, false> {
           rv[k] = r_begin[r].second;
           sv[k] = s_begin[q].second;
         },
-        [&](std::uint64_t r, std::uint64_t q) {
-          __builtin_prefetch(&r_begin[r]);
-          __builtin_prefetch(&s_begin[q]);
+        [&](int stage, std::uint64_t r, std::uint64_t q) {
+          if (stage == 0) {
+            __builtin_prefetch(&r_begin[r]);
+            __builtin_prefetch(&s_begin[q]);
+          } else {
+            hmj_detail::prefetch_key_data(r_begin[r].first);
+            hmj_detail::prefetch_key_data(s_begin[q].first);
+          }
         },
         _j);
     if (times)
