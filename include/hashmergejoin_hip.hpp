@@ -433,8 +433,9 @@ class HashMergeJoin<RIter, SIter, true> {
 // std::hash<Key> once per row (the reference computes it twice, radix_hash.h:314,340) with
 // `num_threads` threads, the GPU joins the 16-byte rows {hash, row index} in hash order, and the host
 // drops the (astronomically rare) pairs whose 64-bit hashes collide on different keys.  Iteration order
-// is the reference's: ascending hash, then key.  operator* points at the key and payloads INSIDE THE
-// CALLER'S RELATIONS (the reference points into its sorted copies), so they must outlive the join.
+// is the reference's: ascending hash, then key.  operator* points at the KEY inside the caller's relation
+// (the reference points into its sorted copies), so the relations must outlive the join; the payload
+// pointers point at copies the join object keeps in iteration order (as the reference's do).
 // ---------------------------------------------------------------------------------------------------
 template <typename RIter, typename SIter>
 class HashMergeJoin<RIter, SIter, false> {
