@@ -137,9 +137,18 @@ template <typename K>
 inline void prefetch_key_data(const K&) {}
 inline void prefetch_key_data(const std::string& k) { __builtin_prefetch(k.data()); }
 // a per-thread buffer of 64-bit words that only grows and is never initialised (the {hash, row} rows of the string-key operator)
-inline std::uint64_t* hash_scratch(std::size_t words) {
+// hash_scratch(0, true) after use gives a buffer beyond 256 MiB back (a one-off join of 10^8 strings must not pin gigabytes
+// in its thread for ever; the usual sizes stay, so that the next join finds its pages faulted in).
+inline std::uint64_t* hash_scratch(std::size_t words, bool done = false) {
   thread_local std::unique_ptr<std::uint64_t[]> buf;
   thread_local std::size_t cap = 0;
+  if (done) {
+    if (cap > (std::size_t)32 << 20) {
+      buf.reset();
+      cap = 0;
+    }
+    return nullptr;
+  }
   if (words > cap) {
     buf.reset();
     buf.reset(new std::uint64_t[words + words / 8 + 16]);
@@ -516,6 +525,7 @@ class HashMergeJoin<RIter, SIter, false> {
       std::fprintf(stderr, "[hmj drop-in] %zu x %zu rows: hash %.2f ms, GPU join + verify + payloads %.2f ms\n", nr, ns,
                    std::chrono::duration<double, std::milli>(t1 - t0).count(),
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    (void)hmj_detail::hash_scratch(0, true);
     if (!_j.visited) {  // (colliding or repeated hashes: the pairs were walked one by one; their payloads now)
       alloc(_j.n);
       hmj_detail::parallel_ranges(_j.n, num_threads, [&](std::size_t b, std::size_t e) {
